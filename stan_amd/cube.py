@@ -1,0 +1,51 @@
+"""Synthetic structured HEX8 cube (SURVEY.md Appendix E conventions).
+
+The reference has no mesh generator; this is the workload generator used by
+bench.py and the tests.  Node IDs 1..(n+1)^3 x-fastest, element IDs 1..n^3
+x-fastest, CHEXA node order = the natural-coordinate sign table of
+FE_Library.cs:225-235, so det J = h^3/8 > 0.
+"""
+import numpy as np
+
+
+def cube_mesh(n, h=1.0, jitter=0.0, seed=12345):
+    """Returns xyz [(n+1)^3, 3] float64 and conn [n^3, 8] int32 of node *indices*
+    (NodeLib order == ID order, index = ID - 1)."""
+    m = n + 1
+    k, j, i = np.meshgrid(np.arange(m), np.arange(m), np.arange(m), indexing="ij")
+    xyz = np.stack([i.ravel(), j.ravel(), k.ravel()], axis=1).astype(np.float64) * h
+    if jitter:
+        rng = np.random.default_rng(seed)
+        xyz = xyz + rng.uniform(-jitter * h, jitter * h, size=xyz.shape)
+    ke, je, ie = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    ie, je, ke = ie.ravel(), je.ravel(), ke.ravel()
+
+    def nid(a, b, c):
+        return a + m * (b + m * c)
+
+    conn = np.stack([nid(ie, je, ke), nid(ie + 1, je, ke), nid(ie + 1, je + 1, ke),
+                     nid(ie, je + 1, ke), nid(ie, je, ke + 1), nid(ie + 1, je, ke + 1),
+                     nid(ie + 1, je + 1, ke + 1), nid(ie, je + 1, ke + 1)], axis=1)
+    return xyz, conn.astype(np.int32)
+
+
+def cube_bcs(n, h=1.0, clamp_faces="x", load=(0.0, 0.0, 50.0)):
+    """SPC (1,1,1) on the nodes of the clamped faces (x=0; 'xyz' = x=0 u y=0 u z=0,
+    needed for HEX8_G1) and PointLoad `load` on every node with x = n*h
+    (README.md:58-69's example values).  Returns
+    (spc_nodes int32[], load_nodes int32[], load float64[3]) as node indices."""
+    m = n + 1
+    idx = np.arange(m ** 3)
+    i = idx % m
+    j = (idx // m) % m
+    k = idx // (m * m)
+    fixed = np.zeros(m ** 3, dtype=bool)
+    if "x" in clamp_faces:
+        fixed |= i == 0
+    if "y" in clamp_faces:
+        fixed |= j == 0
+    if "z" in clamp_faces:
+        fixed |= k == 0
+    spc = idx[fixed].astype(np.int32)
+    ld = idx[i == n].astype(np.int32)
+    return spc, ld, np.asarray(load, dtype=np.float64)
