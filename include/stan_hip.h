@@ -1,0 +1,175 @@
+/*
+ * stan_hip.h -- C-ABI of libstan_hip.so: the MI355X (gfx950) implementation of
+ * STAN's linear-static hot path (HEX8 stiffness assembly -> global sparse K ->
+ * Jacobi-scaled Conjugate Gradient).
+ *
+ * The reference (galuszkm/STAN, C#) has no FFI for this path; the boundary is
+ * the pair of managed methods SolverLinearStatics calls (Solver.cs:156,162):
+ *     alglib.sparsematrix ParallelAssembly_K(Database, int[] nDOF_reduction, int inc, string type)
+ *                                                   -- SolverFunctions.cs:117-180
+ *     double[] LinearSolver_CG(alglib.sparsematrix K, double[] F, Analysis)
+ *                                                   -- SolverFunctions.cs:270-330
+ * K is only ever handed from the first to the second, so here it is an opaque,
+ * device-resident handle (stan_matrix).  INTEGRATION.md shows the P/Invoke stub.
+ *
+ * Conventions: blittable types only, caller-allocated buffers, no callbacks.
+ * Every function returns 0 on success or a negative STAN_E_* code; the text is
+ * available from stan_hip_last_error().  Numerical outcomes of the CG are NOT
+ * errors: they are reported in *termination_type with ALGLIB's lincg codes,
+ * exactly as the reference prints them (SolverFunctions.cs:308-325) and the
+ * solution vector is returned regardless (SolverFunctions.cs:329).
+ *
+ * One context drives ONE GPU (one process per GPU).  For N GPUs every rank
+ * creates a context, joins a communicator (stan_hip_comm_init) and then makes
+ * the same calls with the same full-size arguments; rows of K are sharded by
+ * contiguous block-row ranges in reference DOF order and the CG exchanges halos
+ * and reduces its dot products over RCCL.
+ */
+#ifndef STAN_HIP_H
+#define STAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct stan_ctx stan_ctx;
+typedef struct stan_matrix stan_matrix;
+
+/* error codes */
+#define STAN_OK 0
+#define STAN_E_HIP (-1)          /* HIP runtime failure / no device                      */
+#define STAN_E_ARG (-2)          /* bad argument                                          */
+#define STAN_E_ALLOC (-3)        /* device allocation failed                              */
+#define STAN_E_DETJ (-4)         /* det J == 0 at a Gauss point (MatrixST.cs:315-318
+                                    throws ArgumentException); element via last_error and
+                                    stan_hip_last_bad_element()                           */
+#define STAN_E_DOF_LAYOUT (-5)   /* Node.DOF is not {3i,3i+1,3i+2} (Node.cs:218-223)       */
+#define STAN_E_VALENCE (-6)      /* more than 64 elements share one node                  */
+#define STAN_E_COMM (-7)         /* RCCL failure                                           */
+#define STAN_E_UNSUPPORTED (-8)  /* element type / precision mode not supported           */
+
+/* element type codes (Element.Type strings, Element.cs:15) */
+#define STAN_HEX8_G1 1 /* "HEX8_G1" FE_Library.cs:63-89  */
+#define STAN_HEX8_G2 2 /* "HEX8_G2" FE_Library.cs:91-131 */
+
+/* precision_mode of stan_hip_cg_solve */
+#define STAN_PREC_FP64 0  /* fp64 matrix, fp64 vectors (reference arithmetic)              */
+#define STAN_PREC_MIXED 1 /* fp32 matrix values, fp64 vectors and accumulation             */
+
+/* ---- context ------------------------------------------------------------------------- */
+/* `device` = HIP device ordinal this process drives.  Fails loudly (STAN_E_HIP) when no
+ * GPU is present: there is no CPU fallback. */
+int stan_hip_init(int device, stan_ctx **out);
+void stan_hip_destroy(stan_ctx *ctx);
+const char *stan_hip_last_error(stan_ctx *ctx);
+int64_t stan_hip_last_bad_element(stan_ctx *ctx);
+/* Use an existing hipStream_t (e.g. torch's current stream) for all work; NULL = own stream. */
+int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
+
+/* ---- multi-GPU (RCCL over xGMI) -------------------------------------------------------- */
+/* Rank 0 creates the 128-byte id, the host distributes it (torch.distributed broadcast,
+ * MPI, a file ...), every rank calls comm_init. */
+int stan_hip_comm_unique_id(char id[128]);
+int stan_hip_comm_init(stan_ctx *ctx, int rank, int nranks, const char id[128]);
+
+/* ---- assembly: replaces ParallelAssembly_K (SolverFunctions.cs:117-180) ----------------- */
+/* xyz            [n_nodes*3]  Node.X/Y/Z in NodeLib (wire) order           Node.cs:12-14
+ * node_dof       [n_nodes*3]  Node.DOF after Database.AssignDOF            Database.cs:140-234
+ * conn           [n_elem*8]   Element.NList as node *indices* (position in NodeLib order),
+ *                             CHEXA order                                  Element.cs:18
+ * elem_mat       [n_elem]     index into mat_E_nu (resolved MatLib[MatID]) Element.cs:147
+ * elem_type      [n_elem]     STAN_HEX8_G1 / STAN_HEX8_G2                  Element.cs:15
+ * mat_E_nu       [n_mat*2]    Material.E, Material.Poisson                 Material.cs:31-56
+ * ndof_reduction [n_dof]      -1 = fixed, else #fixed DOFs below           Solver.cs:121-132
+ * All pointers are HOST memory, owned by the caller for the duration of the call. */
+int stan_hip_assemble_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz,
+                           const int32_t *node_dof, int64_t n_elem, const int32_t *conn,
+                           const int32_t *elem_mat, const uint8_t *elem_type, int32_t n_mat,
+                           const double *mat_E_nu, int64_t n_dof,
+                           const int32_t *ndof_reduction, stan_matrix **outK);
+/* Same, but every array pointer (except mat_E_nu, host) is DEVICE memory already resident
+ * in HBM on the context's GPU.  This is the entry bench.py times. */
+int stan_hip_assemble_hex8_dev(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
+                               const int32_t *d_node_dof, int64_t n_elem, const int32_t *d_conn,
+                               const int32_t *d_elem_mat, const uint8_t *d_elem_type,
+                               int32_t n_mat, const double *mat_E_nu, int64_t n_dof,
+                               const int32_t *d_ndof_reduction, stan_matrix **outK);
+void stan_hip_matrix_free(stan_matrix *K);
+
+/* ---- solve: replaces LinearSolver_CG (SolverFunctions.cs:270-330) ------------------------ */
+/* F, U: [N] with N = n_dof - #fixed (the reduced system, as the reference passes them).
+ * eps_f / max_its = Analysis.LinSolverTolerance / LinSolverIterMax (Analysis.cs:10-11),
+ * both zero -> eps_f = 1e-6 (lincgsetcond).  termination_type: 1 converged, 5 max_its,
+ * 7 no further progress (best point returned), -5 not SPD, -4 overflow.
+ * rel_residual = ||r||/||b|| of the diagonally scaled system at exit.  Any out pointer
+ * except U may be NULL. */
+int stan_hip_cg_solve(stan_ctx *ctx, stan_matrix *K, const double *F, double eps_f,
+                      int32_t max_its, int32_t precision_mode, double *U,
+                      int32_t *termination_type, int32_t *iterations, double *rel_residual);
+/* F and U in device memory. */
+int stan_hip_cg_solve_dev(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_f,
+                          int32_t max_its, int32_t precision_mode, double *d_U,
+                          int32_t *termination_type, int32_t *iterations, double *rel_residual);
+
+/* ---- introspection / parity helpers ------------------------------------------------------- */
+typedef struct stan_matrix_info {
+    int64_t n_dof;        /* full DOF count                                      */
+    int64_t n_reduced;    /* N                                                   */
+    int64_t n_block_rows; /* global 3x3 block rows (= nodes)                     */
+    int64_t row_begin;    /* this rank's block-row range [row_begin,row_end)     */
+    int64_t row_end;
+    int64_t n_halo;       /* halo block columns on this rank                     */
+    int64_t n_blocks;     /* structural 3x3 blocks stored on this rank           */
+    int64_t n_slots;      /* allocated 64-row ELL slots (incl. padding)          */
+    int64_t bytes_matrix; /* device bytes of values + column indices             */
+    int32_t scaled;       /* 1 once the CG has applied its diagonal scaling      */
+    int32_t max_row_blocks;
+} stan_matrix_info;
+int stan_hip_matrix_info(stan_matrix *K, stan_matrix_info *out);
+
+/* K_e of one element (debug/parity; Element.cs:118-155): 24x24 row-major into out[576]. */
+int stan_hip_ke_hex8(stan_ctx *ctx, const double xyz8[24], double E, double nu, int32_t type,
+                     double out[576]);
+/* Batched form: n elements, xyz8 [n*24], type [n], out [n*576] (host pointers). */
+int stan_hip_ke_hex8_batch(stan_ctx *ctx, int64_t n, const double *xyz8, double E, double nu,
+                           const uint8_t *type, double *out);
+
+/* Export the REDUCED matrix (fixed DOFs removed, indices row - red[row]) as CRS with columns
+ * ascending -- what alglib.sparseconverttocrs holds (SolverFunctions.cs:275).
+ * upper_only=1: only col >= row (the reference's storage).  Two-call protocol: pass
+ * rowptr=col=val=NULL to get *nnz, then call again with buffers [N+1],[nnz],[nnz].
+ * Single-rank contexts only. */
+int stan_hip_matrix_to_csr(stan_ctx *ctx, stan_matrix *K, int32_t upper_only, int64_t *nnz,
+                           int64_t *rowptr, int32_t *col, double *val);
+
+/* y = K x on the reduced system (host x,y of length N); single-rank contexts only. */
+int stan_hip_spmv(stan_ctx *ctx, stan_matrix *K, const double *x, double *y);
+/* Timing helper for the roofline: `reps` back-to-back launches of the CG's SpMV kernel on
+ * the matrix' resident operands, bracketed by HIP events on the context stream.
+ * Returns average milliseconds per launch. */
+int stan_hip_spmv_bench(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode, int32_t reps,
+                        double *avg_ms);
+
+/* Per-phase device timings of the most recent assemble / solve, measured with HIP events on
+ * the context stream (profiling must be enabled first; it adds one event pair per launch). */
+typedef struct stan_profile {
+    double assemble_ms;      /* symbolic + numeric                                  */
+    double symbolic_ms;
+    double numeric_ms;
+    double cg_ms;            /* whole solve incl. scaling and result gather         */
+    double spmv_ms_total;    /* sum over SpMV launches of the last solve            */
+    int64_t spmv_launches;
+    int64_t spmv_bytes;      /* algorithmic bytes of ONE SpMV launch on this rank   */
+    int64_t cg_iteration_vector_bytes; /* vector traffic of one CG iteration        */
+    int32_t iterations;
+    int32_t termination_type;
+} stan_profile;
+int stan_hip_set_profiling(stan_ctx *ctx, int32_t enabled);
+int stan_hip_get_profile(stan_ctx *ctx, stan_profile *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,278 @@
+// api.hip -- the extern "C" surface of libstan_hip.so declared in include/stan_hip.h.
+#include <cstring>
+
+#include "internal.h"
+
+int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K);
+
+namespace {
+thread_local std::string g_err;  // errors raised before a context exists
+
+template <typename T>
+struct dbuf {  // RAII device buffer filled from host memory
+    T *p = nullptr;
+    ~dbuf() { if (p) hipFree(p); }
+    int upload(stan_ctx *ctx, const T *h, size_t n) {
+        STANCHK(stan_dmalloc(ctx, &p, n));
+        if (n) HIPCHK(ctx, hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+        return STAN_OK;
+    }
+    int alloc(stan_ctx *ctx, size_t n) { return stan_dmalloc(ctx, &p, n); }
+};
+}  // namespace
+
+extern "C" {
+
+int stan_hip_init(int device, stan_ctx **out) {
+    if (!out) return STAN_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0 || device < 0 || device >= n) {
+        g_err = std::string("stan_hip_init: no usable HIP device (") +
+                (e != hipSuccess ? hipGetErrorString(e) : "device ordinal out of range") + ")";
+        return STAN_E_HIP;
+    }
+    stan_ctx *c = new stan_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_status, 64 * sizeof(int64_t), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void **)&c->d_status, 64 * sizeof(int64_t)) != hipSuccess) {
+        g_err = "stan_hip_init: stream / status allocation failed";
+        delete c;
+        return STAN_E_HIP;
+    }
+    c->own_stream = true;
+    *out = c;
+    return STAN_OK;
+}
+
+void stan_hip_destroy(stan_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->comm && ctx->nccl.CommDestroy) ctx->nccl.CommDestroy(ctx->comm);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->h_status) hipHostFree(ctx->h_status);
+    if (ctx->d_status) hipFree(ctx->d_status);
+    delete ctx;
+}
+
+const char *stan_hip_last_error(stan_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+int64_t stan_hip_last_bad_element(stan_ctx *ctx) { return ctx ? ctx->bad_elem : -1; }
+
+int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream) {
+    if (!ctx) return STAN_E_ARG;
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    ctx->own_stream = false;
+    ctx->stream = (hipStream_t)hip_stream;
+    if (!hip_stream) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return STAN_OK;
+}
+
+int stan_hip_set_profiling(stan_ctx *ctx, int32_t enabled) {
+    if (!ctx) return STAN_E_ARG;
+    ctx->profiling = enabled != 0;
+    return STAN_OK;
+}
+int stan_hip_get_profile(stan_ctx *ctx, stan_profile *out) {
+    if (!ctx || !out) return STAN_E_ARG;
+    *out = ctx->prof;
+    return STAN_OK;
+}
+
+int stan_hip_assemble_hex8_dev(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
+                               const int32_t *d_node_dof, int64_t n_elem, const int32_t *d_conn,
+                               const int32_t *d_elem_mat, const uint8_t *d_elem_type,
+                               int32_t n_mat, const double *mat_E_nu, int64_t n_dof,
+                               const int32_t *d_red, stan_matrix **outK) {
+    if (!ctx || !outK || !d_xyz || !d_node_dof || !d_red || !mat_E_nu ||
+        (n_elem > 0 && (!d_conn || !d_elem_mat || !d_elem_type)))
+        return STAN_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return stan_assemble_device(ctx, n_nodes, d_xyz, d_node_dof, n_elem, d_conn, d_elem_mat,
+                                d_elem_type, n_mat, mat_E_nu, n_dof, d_red, outK);
+}
+
+int stan_hip_assemble_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz,
+                           const int32_t *node_dof, int64_t n_elem, const int32_t *conn,
+                           const int32_t *elem_mat, const uint8_t *elem_type, int32_t n_mat,
+                           const double *mat_E_nu, int64_t n_dof, const int32_t *red,
+                           stan_matrix **outK) {
+    if (!ctx || !outK || !xyz || !node_dof || !red || !mat_E_nu || n_nodes <= 0 || n_dof <= 0 ||
+        n_elem < 0 || (n_elem > 0 && (!conn || !elem_mat || !elem_type))) {
+        if (ctx) ctx->err = "assemble_hex8: null or empty argument";
+        return STAN_E_ARG;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (int64_t e = 0; e < n_elem; e++) {
+        if (elem_mat[e] < 0 || elem_mat[e] >= n_mat) {
+            ctx->err = "assemble_hex8: elem_mat out of range at element " + std::to_string(e);
+            return STAN_E_ARG;
+        }
+        if (elem_type[e] != STAN_HEX8_G1 && elem_type[e] != STAN_HEX8_G2) {
+            ctx->err = "assemble_hex8: unsupported element type at element " + std::to_string(e);
+            return STAN_E_UNSUPPORTED;
+        }
+    }
+    dbuf<double> dx; dbuf<int32_t> dd, dc, dm, dr; dbuf<uint8_t> dt;
+    STANCHK(dx.upload(ctx, xyz, (size_t)n_nodes * 3));
+    STANCHK(dd.upload(ctx, node_dof, (size_t)n_nodes * 3));
+    STANCHK(dc.upload(ctx, conn, (size_t)n_elem * 8));
+    STANCHK(dm.upload(ctx, elem_mat, (size_t)n_elem));
+    STANCHK(dt.upload(ctx, elem_type, (size_t)n_elem));
+    STANCHK(dr.upload(ctx, red, (size_t)n_dof));
+    return stan_assemble_device(ctx, n_nodes, dx.p, dd.p, n_elem, dc.p, dm.p, dt.p, n_mat, mat_E_nu,
+                                n_dof, dr.p, outK);
+}
+
+void stan_hip_matrix_free(stan_matrix *K) {
+    if (!K) return;
+    if (K->ctx) hipSetDevice(K->ctx->device);
+    hipFree(K->d_slot_ptr); hipFree(K->d_rowlen); hipFree(K->d_cols); hipFree(K->d_vals);
+    hipFree(K->d_vals32); hipFree(K->d_red); hipFree(K->d_fixmask); hipFree(K->d_scale);
+    hipFree(K->d_send_rows); hipFree(K->d_halo_glob); hipFree(K->d_sendbuf);
+    delete K;
+}
+
+int stan_hip_cg_solve_dev(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_f,
+                          int32_t max_its, int32_t precision_mode, double *d_U,
+                          int32_t *termination_type, int32_t *iterations, double *rel_residual) {
+    if (!ctx || !K || !d_F || !d_U || K->ctx != ctx) return STAN_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return stan_cg_device(ctx, K, d_F, eps_f, max_its, precision_mode, d_U, termination_type,
+                          iterations, rel_residual);
+}
+
+int stan_hip_cg_solve(stan_ctx *ctx, stan_matrix *K, const double *F, double eps_f,
+                      int32_t max_its, int32_t precision_mode, double *U,
+                      int32_t *termination_type, int32_t *iterations, double *rel_residual) {
+    if (!ctx || !K || !F || !U || K->ctx != ctx) return STAN_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t N = (size_t)K->n_red;
+    dbuf<double> dF, dU;
+    STANCHK(dF.upload(ctx, F, N));
+    STANCHK(dU.alloc(ctx, N));
+    HIPCHK(ctx, hipMemsetAsync(dU.p, 0, (N ? N : 1) * 8, ctx->stream));
+    STANCHK(stan_cg_device(ctx, K, dF.p, eps_f, max_its, precision_mode, dU.p, termination_type,
+                           iterations, rel_residual));
+    if (N) HIPCHK(ctx, hipMemcpyAsync(U, dU.p, N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return STAN_OK;
+}
+
+int stan_hip_matrix_info(stan_matrix *K, stan_matrix_info *o) {
+    if (!K || !o) return STAN_E_ARG;
+    o->n_dof = K->n_dof; o->n_reduced = K->n_red; o->n_block_rows = K->nb_glob;
+    o->row_begin = K->r0; o->row_end = K->r1; o->n_halo = K->nhalo; o->n_blocks = K->nblocks;
+    o->n_slots = K->nslots;
+    o->bytes_matrix = K->nslots * 64 * (9 * 8 + 4);
+    o->scaled = K->scaled ? 1 : 0;
+    o->max_row_blocks = K->max_row_blocks;
+    return STAN_OK;
+}
+
+int stan_hip_ke_hex8_batch(stan_ctx *ctx, int64_t n, const double *xyz8, double E, double nu,
+                           const uint8_t *type, double *out) {
+    if (!ctx || n < 0 || (n > 0 && (!xyz8 || !type || !out))) return STAN_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (int64_t e = 0; e < n; e++)
+        if (type[e] != STAN_HEX8_G1 && type[e] != STAN_HEX8_G2) {
+            ctx->err = "ke_hex8: unsupported element type";
+            return STAN_E_UNSUPPORTED;
+        }
+    dbuf<double> dx, dk; dbuf<uint8_t> dt;
+    STANCHK(dx.upload(ctx, xyz8, (size_t)n * 24));
+    STANCHK(dt.upload(ctx, type, (size_t)n));
+    STANCHK(dk.alloc(ctx, (size_t)n * 576));
+    STANCHK(stan_ke_batch_device(ctx, n, dx.p, E, nu, dt.p, dk.p));
+    if (n) HIPCHK(ctx, hipMemcpyAsync(out, dk.p, (size_t)n * 576 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return STAN_OK;
+}
+
+int stan_hip_ke_hex8(stan_ctx *ctx, const double xyz8[24], double E, double nu, int32_t type,
+                     double out[576]) {
+    uint8_t t = (uint8_t)type;
+    if (type != STAN_HEX8_G1 && type != STAN_HEX8_G2) {
+        if (ctx) ctx->err = "ke_hex8: unsupported element type";
+        return STAN_E_UNSUPPORTED;
+    }
+    return stan_hip_ke_hex8_batch(ctx, 1, xyz8, E, nu, &t, out);
+}
+
+int stan_hip_matrix_to_csr(stan_ctx *ctx, stan_matrix *K, int32_t upper_only, int64_t *nnz,
+                           int64_t *rowptr, int32_t *col, double *val) {
+    if (!ctx || !K || !nnz || K->ctx != ctx) return STAN_E_ARG;
+    if (ctx->nranks != 1) { ctx->err = "matrix_to_csr: single-rank contexts only"; return STAN_E_UNSUPPORTED; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    STANCHK(stan_matrix_unscale(ctx, K));  // export K itself, not S K S
+    const int64_t nloc = K->nloc;
+    std::vector<int32_t> slot_ptr((size_t)K->nslices + 1), rowlen((size_t)K->nslices * 64),
+        cols((size_t)K->nslots * 64), red((size_t)K->n_dof);
+    std::vector<double> vals((size_t)K->nslots * 9 * 64);
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(slot_ptr.data(), K->d_slot_ptr, slot_ptr.size() * 4, hipMemcpyDeviceToHost, st));
+    if (!rowlen.empty()) HIPCHK(ctx, hipMemcpyAsync(rowlen.data(), K->d_rowlen, rowlen.size() * 4, hipMemcpyDeviceToHost, st));
+    if (!cols.empty()) HIPCHK(ctx, hipMemcpyAsync(cols.data(), K->d_cols, cols.size() * 4, hipMemcpyDeviceToHost, st));
+    if (!vals.empty()) HIPCHK(ctx, hipMemcpyAsync(vals.data(), K->d_vals, vals.size() * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(red.data(), K->d_red, red.size() * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    int64_t count = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1 && (!rowptr || !col || !val)) break;
+        int64_t q = 0;
+        for (int64_t row = 0; row < nloc; row++) {
+            const int64_t sl = row >> 6;
+            const int lane = (int)(row & 63);
+            for (int m = 0; m < 3; m++) {
+                const int64_t d = 3 * row + m;
+                if (red[d] == -1) continue;
+                if (pass == 1) rowptr[d - red[d]] = q;
+                for (int k = 0; k < rowlen[row]; k++) {
+                    const int64_t slot = (int64_t)slot_ptr[sl] + k;
+                    const int32_t c = cols[slot * 64 + lane];
+                    for (int n = 0; n < 3; n++) {
+                        const int64_t dc = 3 * (int64_t)c + n;
+                        if (red[dc] == -1) continue;
+                        if (upper_only && dc < d) continue;
+                        if (pass == 1) {
+                            col[q] = (int32_t)(dc - red[dc]);
+                            val[q] = vals[(slot * 9 + 3 * m + n) * 64 + lane];
+                        }
+                        q++;
+                    }
+                }
+            }
+        }
+        if (pass == 0) count = q;
+        else rowptr[K->n_red] = q;
+    }
+    *nnz = count;
+    return STAN_OK;
+}
+
+int stan_hip_spmv(stan_ctx *ctx, stan_matrix *K, const double *x, double *y) {
+    if (!ctx || !K || !x || !y || K->ctx != ctx) return STAN_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t N = (size_t)K->n_red;
+    dbuf<double> dx, dy;
+    STANCHK(dx.upload(ctx, x, N));
+    STANCHK(dy.alloc(ctx, N));
+    STANCHK(stan_spmv_reduced(ctx, K, dx.p, dy.p));
+    if (N) HIPCHK(ctx, hipMemcpyAsync(y, dy.p, N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return STAN_OK;
+}
+
+int stan_hip_spmv_bench(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode, int32_t reps,
+                        double *avg_ms) {
+    if (!ctx || !K || !avg_ms || reps <= 0 || K->ctx != ctx) return STAN_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return stan_spmv_bench_device(ctx, K, precision_mode, reps, avg_ms);
+}
+
+}  // extern "C"

@@ -1,0 +1,722 @@
+// assembly.hip -- HEX8 stiffness assembly on gfx950: replaces
+// SolverFunctions.ParallelAssembly_K (SolverFunctions.cs:117-180) + alglib
+// sparsecreate/sparseadd/sparseconverttocrs (:123,:164,:275).
+//
+// Data layout in HBM ("BSELL-64"): the global K is stored as 3x3 node blocks in
+// sliced-ELL form.  Block row = node in reference DOF order (Node.DOF[0]/3,
+// Database.cs:140-234).  A slice is 64 consecutive block rows (one wavefront);
+// slice s owns the k-slots [slot_ptr[s], slot_ptr[s+1]); slot k of a slice holds,
+// for each of its 64 rows, the k-th block of the row (columns ascending):
+//     cols[slot][lane]            int32  local block-column index
+//     vals[slot][comp 0..8][lane] double block entry (row-major 3x3)
+// so a wavefront streaming a slice issues fully coalesced 512-B loads.
+//
+// Fixed DOFs (nDOF_reduction == -1, Solver.cs:121-132) are kept as identity
+// rows/columns instead of being squeezed out: entries in a fixed row or column
+// are zero, the fixed diagonal is 1.  With b = 0 on fixed DOFs the CG iterates on
+// the free DOFs are those of the reduced system the reference builds
+// (SolverFunctions.cs:155-165), and 3x3 blocks stay intact.
+//
+// Assembly is a row-owner GATHER, not a scatter: one wavefront owns one block row,
+// walks the (element, local node) incidences of its node in ascending element order
+// and sums the element blocks K_e[a][b] it recomputes from the nodal coordinates
+// (lane = (incidence s, local node b); the eight lanes of an incidence share the
+// element's J^-1 at the 8 Gauss points through LDS).  Every value of K is written
+// exactly once, in full 128-B lines, with no atomics and a fixed summation order
+// (bit-reproducible, unlike the reference's lock(K) scatter, SolverFunctions.cs:162).
+#include <algorithm>
+
+#include "internal.h"
+#include "hex8_device.h"
+
+namespace {
+
+constexpr int ERR_DOF_LAYOUT = 1, ERR_CONN_RANGE = 2, ERR_VALENCE = 4, ERR_ROWLEN = 8;
+
+// ---- step 0: node permutation + fixed-DOF masks ------------------------------------------
+__global__ void k_perm(int64_t n_nodes, int64_t nb_glob, const int32_t *node_dof,
+                       const int32_t *red, int32_t *perm, uint8_t *fixmask, int64_t *status) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const int32_t d0 = node_dof[3 * i], d1 = node_dof[3 * i + 1], d2 = node_dof[3 * i + 2];
+    // Node.cs:218-223 SetDOF: DOF = {3*index, 3*index+1, 3*index+2}
+    if (d0 < 0 || d0 % 3 != 0 || d1 != d0 + 1 || d2 != d0 + 2 || d0 / 3 >= nb_glob) {
+        atomicOr((unsigned long long *)&status[0], (unsigned long long)ERR_DOF_LAYOUT);
+        perm[i] = 0;
+        return;
+    }
+    const int32_t r = d0 / 3;
+    perm[i] = r;
+    uint8_t m = 0;
+    if (red[d0] == -1) m |= 1;
+    if (red[d1] == -1) m |= 2;
+    if (red[d2] == -1) m |= 4;
+    fixmask[r] = m;
+}
+
+// ---- step 1: node -> (element, local node) incidence lists for owned rows -----------------
+__global__ void k_count_incident(int64_t n_elem, int64_t n_nodes, const int32_t *conn,
+                                 const int32_t *perm, int64_t r0, int64_t r1, int32_t *cnt,
+                                 int64_t *status) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_elem * 8) return;
+    const int32_t nd = conn[t];
+    if (nd < 0 || nd >= n_nodes) {
+        atomicOr((unsigned long long *)&status[0], (unsigned long long)ERR_CONN_RANGE);
+        return;
+    }
+    const int64_t row = perm[nd];
+    if (row >= r0 && row < r1) atomicAdd(&cnt[row - r0], 1);
+}
+
+__global__ void k_fill_incident(int64_t n_elem, int64_t n_nodes, const int32_t *conn,
+                                const int32_t *perm, int64_t r0, int64_t r1,
+                                const int64_t *ptr, int32_t *cursor, int32_t *list) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_elem * 8) return;
+    const int32_t nd = conn[t];
+    if (nd < 0 || nd >= n_nodes) return;
+    const int64_t row = perm[nd];
+    if (row >= r0 && row < r1) {
+        const int32_t pos = atomicAdd(&cursor[row - r0], 1);
+        list[ptr[row - r0] + pos] = (int32_t)t;  // t = e*8 + a
+    }
+}
+
+// ---- bitonic sort of P (power of two >= 64) ints in LDS by one 64-lane workgroup -----------
+__device__ inline void lds_bitonic_sort(int32_t *a, int P) {
+    const int lane = threadIdx.x;
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < P; i += 64) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const int32_t x = a[i], y = a[l];
+                    const bool up = (i & k) == 0;
+                    if (up ? (x > y) : (x < y)) {
+                        a[i] = y;
+                        a[l] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- step 2: symbolic.  One 64-lane workgroup per owned block row. --------------------------
+// FILL=false: sort the row's incidence list in place, count distinct neighbour block rows,
+//             flag referenced non-owned block rows (halo discovery).
+// FILL=true : write the sorted distinct columns (local numbering) into the ELL slots.
+template <bool FILL>
+__global__ void __launch_bounds__(64)
+k_symbolic(int64_t nloc, int64_t r0, int64_t r1, const int64_t *ptr, int32_t *list,
+           const int32_t *conn, const int32_t *perm, int32_t *rowlen, int32_t *refflag,
+           const int64_t *halo_rank, const int32_t *slot_ptr, int32_t *cols, int64_t *status) {
+    __shared__ int32_t ent[64];
+    __shared__ int32_t cand[8 * STAN_MAX_INCIDENT];
+    const int lane = threadIdx.x;
+    const int64_t row = blockIdx.x;  // local row; rows >= nloc are slice padding
+    const int slice_lane = (int)(row & 63);
+    const int64_t slice = row >> 6;
+    if (row >= nloc) {
+        if (FILL) {
+            // padding row of the last slice: every slot points at local column 0 with zero values
+            const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
+            for (int k = k0 + lane; k < k1; k += 64) cols[(int64_t)k * 64 + slice_lane] = 0;
+        } else if (lane == 0)
+            rowlen[row] = 0;
+        return;
+    }
+    const int64_t p0 = ptr[row];
+    int deg = (int)(ptr[row + 1] - p0);
+    if (deg > STAN_MAX_INCIDENT) {
+        if (lane == 0) atomicOr((unsigned long long *)&status[0], (unsigned long long)ERR_VALENCE);
+        deg = STAN_MAX_INCIDENT;
+    }
+    // incidence entries ascending (= ascending element index, then local node)
+    ent[lane] = lane < deg ? list[p0 + lane] : 0x7fffffff;
+    __syncthreads();
+    if (!FILL) {
+        lds_bitonic_sort(ent, 64);
+        if (lane < deg) list[p0 + lane] = ent[lane];
+    }
+    const int ncand = deg * 8;
+    int P = 64;
+    while (P < ncand) P <<= 1;
+    for (int i = lane; i < P; i += 64) {
+        int32_t c = 0x7fffffff;
+        if (i < ncand) {
+            const int32_t e = ent[i >> 3] >> 3;
+            c = perm[conn[(int64_t)e * 8 + (i & 7)]];
+        }
+        cand[i] = c;
+    }
+    __syncthreads();
+    lds_bitonic_sort(cand, P);
+    // distinct values, in ascending (global) order
+    int32_t base = 0;
+    for (int i0 = 0; i0 < P; i0 += 64) {
+        const int i = i0 + lane;
+        const int32_t c = cand[i];
+        const bool isnew = c != 0x7fffffff && (i == 0 || cand[i - 1] != c);
+        const unsigned long long m = __ballot(isnew);
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (isnew) {
+            if (FILL) {
+                const int64_t g = c;
+                const int32_t lc = (g >= r0 && g < r1) ? (int32_t)(g - r0)
+                                                       : (int32_t)(nloc + halo_rank[g]);
+                cols[((int64_t)slot_ptr[slice] + pos) * 64 + slice_lane] = lc;
+            } else if (c < r0 || c >= r1)
+                refflag[c] = 1;
+        }
+        base += __popcll(m);
+    }
+    if (FILL) {
+        // pad the row up to the slice width with its own (diagonal) column and zero values
+        const int32_t k1 = slot_ptr[slice + 1] - slot_ptr[slice];
+        for (int k = base + lane; k < k1; k += 64)
+            cols[((int64_t)slot_ptr[slice] + k) * 64 + slice_lane] = (int32_t)row;
+    } else if (lane == 0) {
+        rowlen[row] = base;
+        if (base > STAN_MAX_ROW_BLOCKS)
+            atomicOr((unsigned long long *)&status[0], (unsigned long long)ERR_ROWLEN);
+    }
+}
+
+// slice width = longest row of the slice; also accumulates block count and max width
+__global__ void __launch_bounds__(64)
+k_slice_width(const int32_t *rowlen, int32_t *width, unsigned long long *nblocks, int32_t *maxw) {
+    const int lane = threadIdx.x;
+    int v = rowlen[(int64_t)blockIdx.x * 64 + lane];
+    int s = v;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        v = max(v, __shfl_xor(v, d, 64));
+        s += __shfl_xor(s, d, 64);
+    }
+    if (lane == 0) {
+        width[blockIdx.x] = v;
+        atomicAdd(nblocks, (unsigned long long)s);
+        atomicMax(maxw, v);
+    }
+}
+
+__global__ void k_count_fixed(int64_t n, const int32_t *red, unsigned long long *count) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && red[i] == -1) atomicAdd(count, 1ull);
+}
+
+__global__ void k_i64_to_i32(const int64_t *in, int32_t *out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)in[i];
+}
+
+// halo_glob[rank] = g for every flagged g
+__global__ void k_compact_flags(const int32_t *flag, const int64_t *rank, int32_t *out,
+                                int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) out[rank[i]] = (int32_t)i;
+}
+
+// ---- step 3: numeric.  256 threads = 4 wavefronts assemble 16 consecutive block rows --------
+struct numeric_args {
+    int64_t nloc, r0, r1, nhalo;
+    const int64_t *ptr;
+    const int32_t *list;
+    const int32_t *conn;
+    const int32_t *perm;
+    const double *xyz;
+    const int32_t *elem_mat;
+    const uint8_t *elem_type;
+    const double *mat_lamG;  // [n_mat*2] lambda, G
+    const uint8_t *fixmask;  // by global block row
+    const int32_t *halo_glob;
+    const int64_t *halo_rank;
+    const int32_t *rowlen;
+    const int32_t *slot_ptr;
+    const int32_t *cols;
+    double *vals;
+    long long *bad_elem;  // min element index with det J == 0, else LLONG_MAX
+    int32_t wmax;         // LDS accumulators are sized for this slice width
+};
+
+__global__ void __launch_bounds__(256) k_numeric(numeric_args A) {
+    extern __shared__ double lds[];
+    // carve-up (all 8-byte aligned):
+    //   acc   [16][wmax][9]   double
+    //   xs    [4 waves][8 inc][8 nodes][3] double
+    //   gps   [4 waves][8 gp][8 inc][10]   double
+    //   colsl [16][wmax] int32, cfix [16][wmax] uint8 (stored as int32 for simplicity)
+    const int W = A.wmax;
+    double *acc = lds;
+    double *xs = acc + 16 * W * 9;
+    double *gps = xs + 4 * 8 * 8 * 3;
+    int32_t *colsl = (int32_t *)(gps + 4 * 8 * 8 * 10);
+    int32_t *cfix = colsl + 16 * W;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t slice = blockIdx.x >> 2;
+    const int q = blockIdx.x & 3;
+    const int64_t row_base = slice * 64 + q * 16;
+    const int32_t k0 = A.slot_ptr[slice];
+    const int sw = A.slot_ptr[slice + 1] - k0;  // this slice's width (<= wmax)
+
+    for (int i = tid; i < 16 * W * 9; i += 256) acc[i] = 0.0;
+    for (int i = tid; i < 16 * sw; i += 256) {
+        const int r16 = i & 15, k = i >> 4;
+        const int32_t lc = A.cols[((int64_t)k0 + k) * 64 + q * 16 + r16];
+        colsl[r16 * W + k] = lc;
+        const int64_t g = lc < A.nloc ? A.r0 + lc : (int64_t)A.halo_glob[lc - A.nloc];
+        cfix[r16 * W + k] = A.fixmask[g];
+    }
+    __syncthreads();
+
+    double *xsw = xs + w * (8 * 8 * 3);
+    double *gpw = gps + w * (8 * 8 * 10);
+    const int s = lane >> 3, b = lane & 7;
+
+    for (int i = 0; i < 4; i++) {
+        const int r16 = w * 4 + i;
+        const int64_t row = row_base + r16;
+        if (row >= A.nloc) continue;  // wave-uniform
+        const int64_t p0 = A.ptr[row];
+        const int deg = (int)(A.ptr[row + 1] - p0);
+        const int rl = A.rowlen[row];
+        for (int c0 = 0; c0 < deg; c0 += 8) {
+            const bool valid = c0 + s < deg;
+            int32_t e = 0, a = 0, type = STAN_HEX8_G2, colg = 0;
+            double lam = 0, G = 0;
+            if (valid) {
+                const int32_t en = A.list[p0 + c0 + s];
+                e = en >> 3;
+                a = en & 7;
+                const int32_t nb = A.conn[(int64_t)e * 8 + b];
+                colg = A.perm[nb];
+                type = A.elem_type[e];
+                const int32_t m = A.elem_mat[e];
+                lam = A.mat_lamG[2 * m];
+                G = A.mat_lamG[2 * m + 1];
+                xsw[(s * 8 + b) * 3 + 0] = A.xyz[3 * (int64_t)nb + 0];
+                xsw[(s * 8 + b) * 3 + 1] = A.xyz[3 * (int64_t)nb + 1];
+                xsw[(s * 8 + b) * 3 + 2] = A.xyz[3 * (int64_t)nb + 2];
+            }
+            // (all LDS traffic below is private to this wavefront: program order suffices,
+            //  the fences only stop the compiler from reordering across the hand-off)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (valid) {
+                // phase A: this lane = Gauss point b of incidence s
+                double o[10];
+                const double det = hex8_gp_setup(xsw + s * 24, type, b, o);
+                if (det == 0.0 && hex8_gauss_weight(type, b) != 0.0)
+                    atomicMin(A.bad_elem, (long long)e);
+#pragma unroll
+                for (int j = 0; j < 10; j++) gpw[(b * 8 + s) * 10 + j] = o[j];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double kb[9];
+            int pos = -1;
+            if (valid) {
+                // phase B: block (a, b) of element e
+                hex8_block_ab(gpw + s * 10, 8 * 10, type, a, b, lam, G, kb);
+                // phase C: slot of column colg in this row (columns ascending)
+                const int32_t lc = (colg >= A.r0 && colg < A.r1)
+                                       ? (int32_t)(colg - A.r0)
+                                       : (int32_t)(A.nloc + A.halo_rank[colg]);
+                const int32_t *cl = colsl + r16 * W;
+                // columns ascend in GLOBAL index; halo columns below r0 sort first globally
+                // but last locally, so the local list is not monotone: search linearly
+                // (rows are ~27 long).
+                for (int k = 0; k < rl; k++)
+                    if (cl[k] == lc) { pos = k; break; }
+            }
+            // phase D: ordered accumulation, incidence by incidence (ascending element index)
+            int isdup = 0;
+            {
+#pragma unroll
+                for (int j = 0; j < 7; j++) {
+                    const int pj = __shfl(pos, (lane & ~7) | j, 64);
+                    if (j < b && pj == pos && pos >= 0) isdup = 1;
+                }
+            }
+            const bool anydup = __ballot(isdup) != 0ull;
+            volatile double *ar = acc + r16 * W * 9;
+            for (int s2 = 0; s2 < 8; s2++) {
+                if (s == s2 && pos >= 0 && !isdup) {
+#pragma unroll
+                    for (int j = 0; j < 9; j++) ar[pos * 9 + j] = ar[pos * 9 + j] + kb[j];
+                }
+                if (anydup) {  // degenerate element listing one node twice: serialise
+                    for (int b2 = 1; b2 < 8; b2++) {
+                        if (s == s2 && b == b2 && pos >= 0 && isdup) {
+#pragma unroll
+                            for (int j = 0; j < 9; j++) ar[pos * 9 + j] = ar[pos * 9 + j] + kb[j];
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    __syncthreads();
+
+    // write-out with the essential BCs applied: 16 consecutive lanes = one full 128-B line
+    for (int t = tid; t < 16 * sw * 9; t += 256) {
+        const int r16 = t & 15, kc = t >> 4;
+        const int comp = kc % 9, k = kc / 9;
+        const int64_t row = row_base + r16;
+        double v = 0.0;
+        if (row < A.nloc) {
+            v = acc[(r16 * W + k) * 9 + comp];
+            const int m = comp / 3, n = comp - 3 * m;
+            const int rfix = A.fixmask[A.r0 + row];
+            const int cf = cfix[r16 * W + k];
+            const bool fixed = ((rfix >> m) & 1) || ((cf >> n) & 1);
+            if (k >= A.rowlen[row])
+                v = 0.0;
+            else if (fixed)
+                v = (colsl[r16 * W + k] == (int32_t)row && m == n) ? 1.0 : 0.0;
+        }
+        A.vals[(((int64_t)k0 + k) * 9 + comp) * 64 + q * 16 + r16] = v;
+    }
+}
+
+// ---- per-row rank mask (which ranks need this owned row's x) --------------------------------
+__global__ void k_row_rankflag(int64_t nloc, const int32_t *rowlen, const int32_t *slot_ptr,
+                               const int32_t *cols, const int32_t *halo_glob, int64_t q0,
+                               int64_t q1, int32_t *flag) {
+    int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= nloc) return;
+    const int64_t slice = row >> 6;
+    const int lane = (int)(row & 63);
+    const int32_t k0 = slot_ptr[slice];
+    int f = 0;
+    for (int k = 0; k < rowlen[row]; k++) {
+        const int32_t lc = cols[((int64_t)k0 + k) * 64 + lane];
+        if (lc >= nloc) {
+            const int64_t g = halo_glob[lc - nloc];
+            if (g >= q0 && g < q1) f = 1;
+        }
+    }
+    flag[row] = f;
+}
+
+// ---- debug / parity: K_e of whole elements, one wavefront per element -------------------------
+__global__ void __launch_bounds__(64)
+k_ke_batch(int64_t n, const double *xyz8, double lam, double G, const uint8_t *type,
+           double *out, long long *bad_elem) {
+    __shared__ double xs[24];
+    __shared__ double gp[8 * 10];
+    __shared__ double ke[576];  // the 24x24 K_e staged in LDS, then stored as whole lines
+    const int lane = threadIdx.x;
+    const int64_t e = blockIdx.x;
+    if (e >= n) return;
+    const int t = type[e];
+    if (lane < 24) xs[lane] = xyz8[e * 24 + lane];
+    __syncthreads();
+    if (lane < 8) {
+        double o[10];
+        const double det = hex8_gp_setup(xs, t, lane, o);
+        if (det == 0.0 && hex8_gauss_weight(t, lane) != 0.0) atomicMin(bad_elem, (long long)e);
+        for (int j = 0; j < 10; j++) gp[lane * 10 + j] = o[j];
+    }
+    __syncthreads();
+    const int a = lane >> 3, b = lane & 7;
+    double kb[9];
+    hex8_block_ab(gp, 10, t, a, b, lam, G, kb);
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int nn = 0; nn < 3; nn++) ke[(3 * a + m) * 24 + 3 * b + nn] = kb[3 * m + nn];
+    __syncthreads();
+    for (int i = lane; i < 576; i += 64) out[e * 576 + i] = ke[i];
+}
+
+inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
+
+struct tmp_free {  // frees device temporaries on every exit path
+    std::vector<void *> p;
+    ~tmp_free() {
+        for (void *q : p)
+            if (q) hipFree(q);
+    }
+    template <typename T>
+    void own(T *q) { p.push_back((void *)q); }
+};
+
+}  // namespace
+
+int stan_ke_batch_device(stan_ctx *ctx, int64_t n, const double *d_xyz8, double E, double nu,
+                         const uint8_t *d_type, double *d_out) {
+    double lam, G;
+    stan_lame(E, nu, &lam, &G);
+    long long init = 0x7fffffffffffffffLL;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_status + 8, &init, 8, hipMemcpyHostToDevice, ctx->stream));
+    if (n > 0)
+        hipLaunchKernelGGL(k_ke_batch, dim3((unsigned)n), dim3(64), 0, ctx->stream, n, d_xyz8, lam,
+                           G, d_type, d_out, (long long *)(ctx->d_status + 8));
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 8, ctx->d_status + 8, 8, hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_status[8] != init) {
+        ctx->bad_elem = ctx->h_status[8];
+        ctx->err = "det J == 0 in element " + std::to_string(ctx->bad_elem) +
+                   " (MatrixST.Inverse would throw)";
+        return STAN_E_DETJ;
+    }
+    return STAN_OK;
+}
+
+int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
+                         const int32_t *d_node_dof, int64_t n_elem, const int32_t *d_conn,
+                         const int32_t *d_elem_mat, const uint8_t *d_elem_type, int32_t n_mat,
+                         const double *mat_E_nu, int64_t n_dof, const int32_t *d_red,
+                         stan_matrix **outK) {
+    *outK = nullptr;
+    if (n_nodes <= 0 || n_elem < 0 || n_dof != 3 * n_nodes || n_mat <= 0) {
+        ctx->err = "assemble: need n_nodes > 0, n_dof == 3*n_nodes, n_mat > 0";
+        return STAN_E_ARG;
+    }
+    if (n_elem * 8 >= (int64_t)1 << 31) {
+        ctx->err = "assemble: n_elem*8 must fit int32";
+        return STAN_E_ARG;
+    }
+    hipStream_t st = ctx->stream;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    if (ctx->profiling) {
+        hipEventCreate(&ev0); hipEventCreate(&ev1); hipEventCreate(&ev2);
+        hipEventRecord(ev0, st);
+    }
+    tmp_free tmp;
+    stan_matrix *K = new stan_matrix();
+    K->ctx = ctx;
+    struct guard {
+        stan_matrix *k; bool ok = false;
+        ~guard() { if (!ok) stan_hip_matrix_free(k); }
+    } g{K};
+    const int64_t nb = n_dof / 3;
+    K->n_dof = n_dof;
+    K->nb_glob = nb;
+    // contiguous block-row partition, cut on slice boundaries
+    K->row_starts.resize(ctx->nranks + 1);
+    {
+        const int64_t nsl = (nb + 63) / 64;
+        for (int r = 0; r <= ctx->nranks; r++) {
+            int64_t s = nsl * r / ctx->nranks * 64;
+            K->row_starts[r] = s > nb ? nb : s;
+        }
+        K->row_starts[ctx->nranks] = nb;
+    }
+    const int64_t r0 = K->r0 = K->row_starts[ctx->rank], r1 = K->r1 = K->row_starts[ctx->rank + 1];
+    const int64_t nloc = K->nloc = r1 - r0;
+    K->nslices = (int32_t)((nloc + 63) / 64);
+    const int64_t nrows_pad = (int64_t)K->nslices * 64;
+
+    int64_t *d_status = ctx->d_status;
+    HIPCHK(ctx, hipMemsetAsync(d_status, 0, 8 * 8, st));
+    {
+        long long init = 0x7fffffffffffffffLL;
+        HIPCHK(ctx, hipMemcpyAsync(d_status + 8, &init, 8, hipMemcpyHostToDevice, st));
+    }
+
+    // materials -> (lambda, G)
+    std::vector<double> lamG(2 * (size_t)n_mat);
+    for (int m = 0; m < n_mat; m++) stan_lame(mat_E_nu[2 * m], mat_E_nu[2 * m + 1], &lamG[2 * m], &lamG[2 * m + 1]);
+    double *d_lamG; STANCHK(stan_dmalloc(ctx, &d_lamG, lamG.size())); tmp.own(d_lamG);
+    HIPCHK(ctx, hipMemcpyAsync(d_lamG, lamG.data(), lamG.size() * 8, hipMemcpyHostToDevice, st));
+
+    int32_t *d_perm; STANCHK(stan_dmalloc(ctx, &d_perm, (size_t)n_nodes)); tmp.own(d_perm);
+    STANCHK(stan_dmalloc(ctx, &K->d_fixmask, (size_t)nb));
+    STANCHK(stan_dmalloc(ctx, &K->d_red, (size_t)n_dof));
+    HIPCHK(ctx, hipMemsetAsync(K->d_fixmask, 0, (size_t)nb, st));
+    HIPCHK(ctx, hipMemcpyAsync(K->d_red, d_red, (size_t)n_dof * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_perm, dim3(nblk(n_nodes, 256)), dim3(256), 0, st, n_nodes, nb, d_node_dof,
+                       d_red, d_perm, K->d_fixmask, d_status);
+
+    // incidence lists of owned rows
+    int32_t *d_cnt; STANCHK(stan_dmalloc(ctx, &d_cnt, (size_t)nrows_pad + 1)); tmp.own(d_cnt);
+    int64_t *d_ptr; STANCHK(stan_dmalloc(ctx, &d_ptr, (size_t)nrows_pad + 2)); tmp.own(d_ptr);
+    HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, ((size_t)nrows_pad + 1) * 4, st));
+    if (n_elem > 0)
+        hipLaunchKernelGGL(k_count_incident, dim3(nblk(n_elem * 8, 256)), dim3(256), 0, st, n_elem,
+                           n_nodes, d_conn, d_perm, r0, r1, d_cnt, d_status);
+    STANCHK(stan_scan_exclusive(ctx, d_cnt, d_ptr, nrows_pad));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status, d_status, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 1, d_ptr + nrows_pad, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (ctx->h_status[0] & ERR_DOF_LAYOUT) {
+        ctx->err = "assemble: Node.DOF is not {3i,3i+1,3i+2} with 3i < n_dof (Node.cs:218-223)";
+        return STAN_E_DOF_LAYOUT;
+    }
+    if (ctx->h_status[0] & ERR_CONN_RANGE) {
+        ctx->err = "assemble: connectivity references a node index outside [0,n_nodes)";
+        return STAN_E_ARG;
+    }
+    const int64_t n_inc = ctx->h_status[1];
+    int32_t *d_list; STANCHK(stan_dmalloc(ctx, &d_list, (size_t)n_inc)); tmp.own(d_list);
+    HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, ((size_t)nrows_pad + 1) * 4, st));
+    if (n_elem > 0)
+        hipLaunchKernelGGL(k_fill_incident, dim3(nblk(n_elem * 8, 256)), dim3(256), 0, st, n_elem,
+                           n_nodes, d_conn, d_perm, r0, r1, d_ptr, d_cnt, d_list);
+
+    // symbolic count
+    STANCHK(stan_dmalloc(ctx, &K->d_rowlen, (size_t)nrows_pad));
+    int32_t *d_refflag = nullptr; int64_t *d_halo_rank = nullptr;
+    if (ctx->nranks > 1) {
+        STANCHK(stan_dmalloc(ctx, &d_refflag, (size_t)nb)); tmp.own(d_refflag);
+        STANCHK(stan_dmalloc(ctx, &d_halo_rank, (size_t)nb + 1)); tmp.own(d_halo_rank);
+        HIPCHK(ctx, hipMemsetAsync(d_refflag, 0, (size_t)nb * 4, st));
+    }
+    if (nrows_pad > 0)
+        hipLaunchKernelGGL(k_symbolic<false>, dim3((unsigned)nrows_pad), dim3(64), 0, st, nloc, r0,
+                           r1, d_ptr, d_list, d_conn, d_perm, K->d_rowlen, d_refflag,
+                           (const int64_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr,
+                           d_status);
+    // halo numbering
+    K->nhalo = 0;
+    if (ctx->nranks > 1) {
+        STANCHK(stan_scan_exclusive(ctx, d_refflag, d_halo_rank, nb));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 2, d_halo_rank + nb, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        K->nhalo = ctx->h_status[2];
+        STANCHK(stan_dmalloc(ctx, &K->d_halo_glob, (size_t)K->nhalo));
+        hipLaunchKernelGGL(k_compact_flags, dim3(nblk(nb, 256)), dim3(256), 0, st, d_refflag,
+                           d_halo_rank, K->d_halo_glob, nb);
+    }
+    // slice widths -> slot pointers
+    int32_t *d_width; STANCHK(stan_dmalloc(ctx, &d_width, (size_t)K->nslices + 1)); tmp.own(d_width);
+    int64_t *d_sp64; STANCHK(stan_dmalloc(ctx, &d_sp64, (size_t)K->nslices + 2)); tmp.own(d_sp64);
+    HIPCHK(ctx, hipMemsetAsync(d_status + 16, 0, 16, st));
+    if (K->nslices > 0)
+        hipLaunchKernelGGL(k_slice_width, dim3((unsigned)K->nslices), dim3(64), 0, st, K->d_rowlen,
+                           d_width, (unsigned long long *)(d_status + 16), (int32_t *)(d_status + 17));
+    STANCHK(stan_scan_exclusive(ctx, d_width, d_sp64, K->nslices));
+    STANCHK(stan_dmalloc(ctx, &K->d_slot_ptr, (size_t)K->nslices + 1));
+    hipLaunchKernelGGL(k_i64_to_i32, dim3(nblk(K->nslices + 1, 256)), dim3(256), 0, st, d_sp64,
+                       K->d_slot_ptr, (int64_t)K->nslices + 1);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status, d_status, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 3, d_sp64 + K->nslices, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 4, d_status + 16, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (ctx->h_status[0] & (ERR_VALENCE | ERR_ROWLEN)) {
+        ctx->err = "assemble: a node is shared by more than 64 (element, local node) pairs or "
+                   "couples to more than " + std::to_string(STAN_MAX_ROW_BLOCKS) + " nodes";
+        return STAN_E_VALENCE;
+    }
+    K->nslots = ctx->h_status[3];
+    K->nblocks = ctx->h_status[4];
+    K->max_row_blocks = (int32_t)(ctx->h_status[5] & 0xffffffff);
+    if (K->nslots * 64 >= (int64_t)1 << 31) {
+        // cols index fits, but keep slot arithmetic in int32 honest
+        ctx->err = "assemble: more than 2^31 ELL entries on one rank";
+        return STAN_E_ARG;
+    }
+    STANCHK(stan_dmalloc(ctx, &K->d_cols, (size_t)K->nslots * 64));
+    STANCHK(stan_dmalloc(ctx, &K->d_vals, (size_t)K->nslots * 9 * 64));
+    if (nrows_pad > 0)
+        hipLaunchKernelGGL(k_symbolic<true>, dim3((unsigned)nrows_pad), dim3(64), 0, st, nloc, r0, r1,
+                           d_ptr, d_list, d_conn, d_perm, K->d_rowlen, (int32_t *)nullptr,
+                           (const int64_t *)d_halo_rank, (const int32_t *)K->d_slot_ptr, K->d_cols,
+                           d_status);
+    if (ctx->profiling) hipEventRecord(ev1, st);
+
+    // numeric
+    {
+        numeric_args A;
+        A.nloc = nloc; A.r0 = r0; A.r1 = r1; A.nhalo = K->nhalo;
+        A.ptr = d_ptr; A.list = d_list; A.conn = d_conn; A.perm = d_perm; A.xyz = d_xyz;
+        A.elem_mat = d_elem_mat; A.elem_type = d_elem_type; A.mat_lamG = d_lamG;
+        A.fixmask = K->d_fixmask; A.halo_glob = K->d_halo_glob; A.halo_rank = d_halo_rank;
+        A.rowlen = K->d_rowlen; A.slot_ptr = K->d_slot_ptr; A.cols = K->d_cols; A.vals = K->d_vals;
+        A.bad_elem = (long long *)(d_status + 8);
+        A.wmax = K->max_row_blocks > 0 ? K->max_row_blocks : 1;
+        const size_t lds = (size_t)16 * A.wmax * 9 * 8 + (size_t)4 * 8 * 8 * 3 * 8 +
+                           (size_t)4 * 8 * 8 * 10 * 8 + (size_t)2 * 16 * A.wmax * 4;
+        if (lds > 64 * 1024)
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)k_numeric,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (K->nslices > 0)
+            hipLaunchKernelGGL(k_numeric, dim3((unsigned)K->nslices * 4), dim3(256), lds, st, A);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemsetAsync(d_status + 9, 0, 8, st));
+    hipLaunchKernelGGL(k_count_fixed, dim3(nblk(n_dof, 256)), dim3(256), 0, st, n_dof, d_red,
+                       (unsigned long long *)(d_status + 9));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 8, d_status + 8, 16, hipMemcpyDeviceToHost, st));
+
+    // halo exchange plan
+    if (ctx->nranks > 1) {
+        std::vector<int32_t> hg((size_t)K->nhalo);
+        HIPCHK(ctx, hipMemcpyAsync(hg.data(), K->d_halo_glob, hg.size() * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        int32_t *d_flag; STANCHK(stan_dmalloc(ctx, &d_flag, (size_t)nloc + 1)); tmp.own(d_flag);
+        int64_t *d_rk; STANCHK(stan_dmalloc(ctx, &d_rk, (size_t)nloc + 2)); tmp.own(d_rk);
+        std::vector<int32_t *> lists;
+        std::vector<int64_t> counts;
+        K->recv_off.push_back(0);
+        K->send_off.push_back(0);
+        for (int q = 0; q < ctx->nranks; q++) {
+            if (q == ctx->rank) continue;
+            const int64_t q0 = K->row_starts[q], q1 = K->row_starts[q + 1];
+            // halo columns owned by q: contiguous in the (ascending) halo list
+            int64_t lo = std::lower_bound(hg.begin(), hg.end(), (int32_t)q0) - hg.begin();
+            int64_t hi = std::lower_bound(hg.begin(), hg.end(), (int32_t)q1) - hg.begin();
+            if (q1 > 0x7fffffff) hi = (int64_t)hg.size();
+            if (hi == lo) continue;  // structural symmetry: no recv <=> no send
+            hipLaunchKernelGGL(k_row_rankflag, dim3(nblk(nloc, 256)), dim3(256), 0, st, nloc,
+                               K->d_rowlen, K->d_slot_ptr, K->d_cols, K->d_halo_glob, q0, q1, d_flag);
+            STANCHK(stan_scan_exclusive(ctx, d_flag, d_rk, nloc));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 6, d_rk + nloc, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            const int64_t ns = ctx->h_status[6];
+            int32_t *d_l; STANCHK(stan_dmalloc(ctx, &d_l, (size_t)ns)); tmp.own(d_l);
+            hipLaunchKernelGGL(k_compact_flags, dim3(nblk(nloc, 256)), dim3(256), 0, st, d_flag, d_rk,
+                               d_l, nloc);
+            lists.push_back(d_l);
+            counts.push_back(ns);
+            K->nbr.push_back(q);
+            K->recv_off.push_back(hi);
+            K->send_off.push_back(K->send_off.back() + ns);
+            // recv segment of q starts at lo: halo list is grouped by owner in rank order
+            if ((int64_t)K->recv_off[K->recv_off.size() - 2] != lo) {
+                ctx->err = "assemble: internal halo plan inconsistency";
+                return STAN_E_COMM;
+            }
+        }
+        const int64_t stot = K->send_off.back();
+        STANCHK(stan_dmalloc(ctx, &K->d_send_rows, (size_t)stot));
+        STANCHK(stan_dmalloc(ctx, &K->d_sendbuf, (size_t)stot * 3));
+        for (size_t i = 0; i < lists.size(); i++)
+            HIPCHK(ctx, hipMemcpyAsync(K->d_send_rows + K->send_off[i], lists[i], (size_t)counts[i] * 4,
+                                       hipMemcpyDeviceToDevice, st));
+    }
+    if (ctx->profiling) hipEventRecord(ev2, st);
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (ctx->h_status[8] != 0x7fffffffffffffffLL) {
+        ctx->bad_elem = ctx->h_status[8];
+        ctx->err = "det J == 0 in element " + std::to_string(ctx->bad_elem) +
+                   " (MatrixST.Inverse would throw, MatrixST.cs:315-318)";
+        return STAN_E_DETJ;
+    }
+    K->n_red = n_dof - ctx->h_status[9];
+    if (ctx->profiling) {
+        float a = 0, b = 0;
+        hipEventElapsedTime(&a, ev0, ev1);
+        hipEventElapsedTime(&b, ev1, ev2);
+        ctx->prof.symbolic_ms = a;
+        ctx->prof.numeric_ms = b;
+        ctx->prof.assemble_ms = a + b;
+        hipEventDestroy(ev0); hipEventDestroy(ev1); hipEventDestroy(ev2);
+    }
+    g.ok = true;
+    *outK = K;
+    return STAN_OK;
+}

@@ -1,0 +1,684 @@
+// cg.hip -- Conjugate Gradient on gfx950: replaces SolverFunctions.LinearSolver_CG
+// (SolverFunctions.cs:270-330), i.e. alglib.lincgcreate / lincgsetcond /
+// lincgsolvesparse / lincgresults of alglib.net 3.16.0 (not vendored in the
+// reference; its published algorithm is restated here):
+//   * diagonal preconditioner applied as a symmetric scaling  A^ = S K S,
+//     s_i = 1/sqrt(K_ii) (1 when K_ii <= 0), b^ = S b, result U = S x^;
+//   * x0 = 0; stop when ||r^|| <= EpsF ||b^|| (type 1), after MaxIts > 0 iterations
+//     (type 5), when the merit function x'Ax - 2b'x stops decreasing (type 7, previous
+//     point returned), p'Ap <= 0 (type -5) or non-finite numbers (type -4);
+//   * every 10th iteration the residual is recomputed as b^ - A^ x^ (extra SpMV).
+//
+// All kernels here are HBM-bound streaming kernels.  The scaling is folded into the
+// matrix once per matrix, so an iteration is
+//   SpMV (+ fused p.Ap)                      reads the matrix once
+//   step  : x' = x + a p, r -= a v, r.r, merit   (one pass, 5 reads 2 writes)
+//   update: p = r + b p                          (one pass, 2 reads 1 write)
+// plus two 1-block reductions of per-block partial sums (fixed order => the whole solve is
+// bit-reproducible).  alpha, beta and every stopping decision live in device memory; the
+// host only enqueues iterations and polls a status word every CHUNK iterations, so
+// there is no host synchronisation inside an iteration.
+#include <cmath>
+
+#include "internal.h"
+
+namespace {
+
+constexpr int VEC_BLOCKS = 2048;  // grid of the streaming vector kernels (8 blocks per CU)
+constexpr int VEC_T = 256;
+constexpr int CHUNK = 32;         // iterations enqueued between two status polls
+constexpr int ITS_BEFORE_RUPDATE = 10;
+
+// device scalar slots (double)
+enum { S_BNORM = 0, S_VMV = 1, S_R2NEW = 2, S_MERIT = 3, S_RHO0 = 4, S_RHO1 = 5, S_PMF0 = 6,
+       S_PMF1 = 7, S_R2OUT = 8, S_NSCAL = 16 };
+// device status slots (int64)
+enum { T_ITER_A = 0, T_ITER_B = 1, T_TYPE = 2, T_ITERS = 3, T_XSEL = 4, T_NSTAT = 8 };
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+// block sum (256 threads), valid in thread 0; fixed combination order
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__device__ __forceinline__ bool stopped(const int64_t *st, int64_t k) {
+    return st[T_ITER_A] < k || st[T_ITER_B] < k;
+}
+
+// ---- setup kernels ---------------------------------------------------------------------------
+// s_i = 1/sqrt(K_ii) if K_ii > 0 else 1 (lincgsolvesparse); one lane per block row
+__global__ void k_diag_scale(int64_t nloc, const int32_t *rowlen, const int32_t *slot_ptr,
+                             const int32_t *cols, const double *vals, double *s) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= nloc) return;
+    const int64_t slice = row >> 6;
+    const int lane = (int)(row & 63);
+    const int32_t k0 = slot_ptr[slice];
+    double d0 = 0, d1 = 0, d2 = 0;
+    for (int k = 0; k < rowlen[row]; k++)
+        if (cols[((int64_t)k0 + k) * 64 + lane] == (int32_t)row) {
+            const double *v = vals + ((int64_t)k0 + k) * 9 * 64 + lane;
+            d0 = v[0 * 64]; d1 = v[4 * 64]; d2 = v[8 * 64];
+            break;
+        }
+    s[3 * row + 0] = d0 > 0 ? 1.0 / sqrt(d0) : 1.0;
+    s[3 * row + 1] = d1 > 0 ? 1.0 / sqrt(d1) : 1.0;
+    s[3 * row + 2] = d2 > 0 ? 1.0 / sqrt(d2) : 1.0;
+}
+
+// vals[slot][3m+n][lane] *= s[3 row + m] * s[3 col + n]   (inverse=1: divide)
+__global__ void __launch_bounds__(256)
+k_scale_matrix(int32_t nslices, const int32_t *slot_ptr, const int32_t *cols, double *vals,
+               const double *s, int inverse) {
+    const int lane = threadIdx.x & 63;
+    const int64_t slice = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slice >= nslices) return;
+    const int64_t row = slice * 64 + lane;
+    double sr[3] = {s[3 * row], s[3 * row + 1], s[3 * row + 2]};  // s is padded to slices
+    if (inverse) { sr[0] = 1.0 / sr[0]; sr[1] = 1.0 / sr[1]; sr[2] = 1.0 / sr[2]; }
+    for (int32_t k = slot_ptr[slice]; k < slot_ptr[slice + 1]; k++) {
+        const int32_t c = cols[(int64_t)k * 64 + lane];
+        double sc[3] = {s[3 * (int64_t)c], s[3 * (int64_t)c + 1], s[3 * (int64_t)c + 2]};
+        if (inverse) { sc[0] = 1.0 / sc[0]; sc[1] = 1.0 / sc[1]; sc[2] = 1.0 / sc[2]; }
+        double *v = vals + (int64_t)k * 9 * 64 + lane;
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+#pragma unroll
+            for (int n = 0; n < 3; n++) v[(3 * m + n) * 64] *= sr[m] * sc[n];
+    }
+}
+
+__global__ void k_to_fp32(const double *in, float *out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = (float)in[i];
+}
+
+// b^[i] = s_i * F[d - red[d]] on free DOFs, 0 on fixed ones; also x0 = 0, r = p = b^ and
+// partial sums of b^.b^ (x0 = 0 => r0 = b^, merit0 = 0).
+__global__ void __launch_bounds__(VEC_T)
+k_init(int64_t n3, int64_t dof0, const int32_t *red, const double *F, const double *s,
+       double *bh, double *x0, double *r, double *p, double *partial) {
+    __shared__ double sh[4];
+    double acc = 0;
+    const int64_t stride = (int64_t)gridDim.x * VEC_T;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_T + threadIdx.x; i < n3; i += stride) {
+        const int32_t rd = red[dof0 + i];
+        const double b = rd == -1 ? 0.0 : s[i] * F[dof0 + i - rd];
+        bh[i] = b;
+        x0[i] = 0.0;
+        r[i] = b;
+        p[i] = b;
+        acc += b * b;
+    }
+    const double t = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// out[j] = sum_i partial[i*nv + j], one block, fixed order
+__global__ void __launch_bounds__(256)
+k_reduce(const double *partial, int np, int nv, double *out) {
+    __shared__ double sh[4];
+    for (int j = 0; j < nv; j++) {
+        double a = 0;
+        for (int i = threadIdx.x; i < np; i += 256) a += partial[(int64_t)i * nv + j];
+        const double t = block_sum(a, sh);
+        if (threadIdx.x == 0) out[j] = t;
+        __syncthreads();
+    }
+}
+
+// after the b^.b^ reduction: bnorm, first residual test, rho, prevmf
+__global__ void k_init_scalars(double *sc, int64_t *st, double epsf) {
+    const double r2 = sc[S_VMV];  // k_reduce wrote b^.b^ here
+    sc[S_BNORM] = sqrt(r2);
+    sc[S_RHO0] = r2; sc[S_RHO1] = r2;  // iteration 1 reads slot 1
+    sc[S_PMF0] = 0.0; sc[S_PMF1] = 0.0;
+    sc[S_R2OUT] = r2;
+    st[T_ITER_A] = 0x7fffffffffffffffLL;
+    st[T_ITER_B] = 0x7fffffffffffffffLL;
+    st[T_TYPE] = 0; st[T_ITERS] = 0; st[T_XSEL] = 0;
+    if (!isfinite(r2)) { st[T_TYPE] = -4; st[T_ITER_A] = 0; }
+    else if (sqrt(r2) <= epsf * sqrt(r2)) { st[T_TYPE] = 1; st[T_ITER_A] = 0; }
+}
+
+// ---- SpMV --------------------------------------------------------------------------------------
+// y = A x over BSELL-64.  One wavefront per slice, one lane per block row: every load of
+// the value stream is a contiguous 512-B (fp64) / 256-B (fp32) wave access; x is gathered
+// (24 B per block, L2 / Infinity-Cache resident: neighbouring rows share columns).
+// DOT: also the per-block partial of x_own . y  (p.Ap of the CG).
+template <typename VT, bool DOT>
+__global__ void __launch_bounds__(256)
+k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
+       const int32_t *__restrict__ cols, const VT *__restrict__ vals,
+       const double *__restrict__ x, double *__restrict__ y, double *partial,
+       const int64_t *st, int64_t kiter) {
+    __shared__ double sh[4];
+    if (stopped(st, kiter)) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t slice = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    double y0 = 0, y1 = 0, y2 = 0;
+    const int64_t row = slice * 64 + lane;
+    if (slice < nslices) {
+        const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
+        const int32_t *cp = cols + (int64_t)k0 * 64 + lane;
+        const VT *vp = vals + (int64_t)k0 * 9 * 64 + lane;
+#pragma unroll 2
+        for (int32_t k = k0; k < k1; k++) {
+            const int64_t c = *cp;
+            const double a0 = (double)vp[0 * 64], a1 = (double)vp[1 * 64], a2 = (double)vp[2 * 64],
+                         a3 = (double)vp[3 * 64], a4 = (double)vp[4 * 64], a5 = (double)vp[5 * 64],
+                         a6 = (double)vp[6 * 64], a7 = (double)vp[7 * 64], a8 = (double)vp[8 * 64];
+            const double x0 = x[3 * c], x1 = x[3 * c + 1], x2 = x[3 * c + 2];
+            y0 += a0 * x0 + a1 * x1 + a2 * x2;
+            y1 += a3 * x0 + a4 * x1 + a5 * x2;
+            y2 += a6 * x0 + a7 * x1 + a8 * x2;
+            cp += 64;
+            vp += 9 * 64;
+        }
+        if (row < nloc) {
+            y[3 * row] = y0; y[3 * row + 1] = y1; y[3 * row + 2] = y2;
+        }
+    }
+    if (DOT) {
+        double d = 0;
+        if (slice < nslices && row < nloc) d = y0 * x[3 * row] + y1 * x[3 * row + 1] + y2 * x[3 * row + 2];
+        const double t = block_sum(d, sh);
+        if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    }
+}
+
+// ---- CG step kernels ----------------------------------------------------------------------------
+struct step_args {
+    int64_t n3;           // 3 * owned block rows
+    int64_t k;            // iteration number (1-based)
+    double *sc;           // scalars
+    int64_t *st;          // status
+    const double *xcur;   // rx
+    double *xnext;        // cx
+    double *r;            // r (in), cr (out)
+    const double *p;
+    const double *v;      // A^ p
+    const double *bh;
+    double *partial;      // [blocks][2]: r2, merit
+    int refresh;          // 1: only cx is formed here (residual recomputed from A^ cx)
+};
+
+__global__ void __launch_bounds__(VEC_T) k_step(step_args a) {
+    __shared__ double sh[4];
+    if (stopped(a.st, a.k)) return;
+    const double vmv = a.sc[S_VMV];
+    const double rho = a.sc[S_RHO0 + (a.k & 1)];
+    int bad = 0;
+    if (!isfinite(vmv) || vmv <= 0) bad = isfinite(vmv) ? -5 : -4;
+    const double alpha = rho / vmv;
+    if (!bad && !isfinite(alpha)) bad = -4;
+    if (bad) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            a.st[T_TYPE] = bad;
+            a.st[T_ITERS] = a.k;
+            a.st[T_XSEL] = (a.k - 1) & 1;  // rx of the previous iteration
+            a.st[T_ITER_B] = a.k;
+        }
+        return;
+    }
+    double s_r2 = 0, s_mf = 0;
+    const int64_t stride = (int64_t)gridDim.x * VEC_T;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_T + threadIdx.x; i < a.n3; i += stride) {
+        const double pi = a.p[i];
+        const double cx = a.xcur[i] + alpha * pi;
+        a.xnext[i] = cx;
+        if (!a.refresh) {
+            const double cr = a.r[i] - alpha * a.v[i];
+            a.r[i] = cr;
+            s_r2 += cr * cr;
+            s_mf -= (cr + a.bh[i]) * cx;
+        }
+    }
+    if (!a.refresh) {
+        const double t0 = block_sum(s_r2, sh);
+        const double t1 = block_sum(s_mf, sh);
+        if (threadIdx.x == 0) {
+            a.partial[2 * blockIdx.x] = t0;
+            a.partial[2 * blockIdx.x + 1] = t1;
+        }
+    }
+}
+
+// refresh iterations: r = b^ - A^ cx, merit = sum (mv - 2 b^) cx
+__global__ void __launch_bounds__(VEC_T)
+k_refresh(int64_t n3, int64_t k, const int64_t *st, const double *bh, const double *mv,
+          const double *cx, double *r, double *partial) {
+    __shared__ double sh[4];
+    if (st[T_ITER_A] < k || st[T_ITER_B] <= k) return;
+    double s_r2 = 0, s_mf = 0;
+    const int64_t stride = (int64_t)gridDim.x * VEC_T;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_T + threadIdx.x; i < n3; i += stride) {
+        const double b = bh[i], m = mv[i];
+        const double cr = b - m;
+        r[i] = cr;
+        s_r2 += cr * cr;
+        s_mf += (m - 2 * b) * cx[i];
+    }
+    const double t0 = block_sum(s_r2, sh);
+    const double t1 = block_sum(s_mf, sh);
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = t0;
+        partial[2 * blockIdx.x + 1] = t1;
+    }
+}
+
+// decisions of the iteration + p = r + beta p
+__global__ void __launch_bounds__(VEC_T)
+k_update(int64_t n3, int64_t k, double *sc, int64_t *st, double epsf, int64_t maxits,
+         int64_t its_before_restart, const double *r, double *p) {
+    if (st[T_ITER_A] < k || st[T_ITER_B] <= k) return;
+    const double r2 = sc[S_R2NEW], merit = sc[S_MERIT];
+    const double rho = sc[S_RHO0 + (k & 1)], prevmf = sc[S_PMF0 + (k & 1)];
+    const double bnorm = sc[S_BNORM];
+    int type = 0;
+    int64_t xsel = k & 1;  // cx lives in buffer k&1
+    if (sqrt(r2) <= epsf * bnorm) type = 1;
+    else if (k >= maxits && maxits > 0) type = 5;
+    else if (merit >= prevmf) { type = 7; xsel = (k - 1) & 1; }
+    double beta = 0;
+    const bool restart = (k % its_before_restart) == 0;
+    if (!type && !restart) {
+        beta = r2 / rho;
+        if (!isfinite(beta)) { type = -4; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc[S_R2OUT] = r2;
+        if (type) {
+            st[T_TYPE] = type;
+            st[T_ITERS] = k;
+            st[T_XSEL] = xsel;
+            st[T_ITER_A] = k;
+        } else {
+            sc[S_RHO0 + ((k + 1) & 1)] = r2;
+            sc[S_PMF0 + ((k + 1) & 1)] = merit;
+        }
+    }
+    if (type) return;
+    const int64_t stride = (int64_t)gridDim.x * VEC_T;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_T + threadIdx.x; i < n3; i += stride)
+        p[i] = r[i] + beta * p[i];
+}
+
+// U[d - red[d]] = s_d * x^_d on free DOFs (SolverFunctions.cs:305 lincgresults + un-scaling)
+__global__ void k_result(int64_t n3, int64_t dof0, const int32_t *red, const double *s,
+                         const double *x, double *U) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += stride) {
+        const int32_t rd = red[dof0 + i];
+        if (rd != -1) U[dof0 + i - rd] = s[i] * x[i];
+    }
+}
+// multi-rank: scaled solution into the global block vector, compressed after the all-gather
+__global__ void k_result_full(int64_t n3, const double *s, const double *x, double *full) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += stride)
+        full[i] = s[i] * x[i];
+}
+__global__ void k_compress(int64_t n_dof, const int32_t *red, const double *full, double *U) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_dof; i += stride) {
+        const int32_t rd = red[i];
+        if (rd != -1) U[i - rd] = full[i];
+    }
+}
+// reduced host-order vector <-> full local vector (for stan_hip_spmv)
+__global__ void k_expand(int64_t n3, int64_t dof0, const int32_t *red, const double *in,
+                         const double *div, double *out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += stride) {
+        const int32_t rd = red[dof0 + i];
+        double v = rd == -1 ? 0.0 : in[dof0 + i - rd];
+        if (div) v /= div[i];
+        out[i] = v;
+    }
+}
+__global__ void k_compress_div(int64_t n3, const int32_t *red, const double *s, const double *y,
+                               double *out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += stride) {
+        const int32_t rd = red[i];
+        if (rd != -1) out[i - rd] = s ? y[i] / s[i] : y[i];
+    }
+}
+__global__ void k_fill(double *p, int64_t n, double v) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
+inline unsigned vec_grid(int64_t n) {
+    int64_t b = (n + VEC_T - 1) / VEC_T;
+    if (b < 1) b = 1;
+    return (unsigned)(b > VEC_BLOCKS ? VEC_BLOCKS : b);
+}
+
+struct dev_bufs {
+    std::vector<void *> p;
+    ~dev_bufs() {
+        for (void *q : p)
+            if (q) hipFree(q);
+    }
+};
+template <typename T>
+int alloc(stan_ctx *ctx, dev_bufs &b, T **p, size_t n) {
+    int rc = stan_dmalloc(ctx, p, n);
+    if (rc == STAN_OK) b.p.push_back((void *)*p);
+    return rc;
+}
+
+template <typename VT, bool DOT>
+void launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double *x, double *y,
+                 double *partial, const int64_t *st, int64_t k) {
+    const unsigned grid = nblk(K->nslices, 4);
+    if (grid == 0) return;
+    hipLaunchKernelGGL((k_spmv<VT, DOT>), dim3(grid), dim3(256), 0, ctx->stream, K->nslices,
+                       K->nloc, K->d_slot_ptr, K->d_cols, vals, x, y, partial, st, k);
+}
+
+}  // namespace
+
+// Diagonal scaling of the matrix (once per matrix): A^ = S K S.
+static int ensure_scaled(stan_ctx *ctx, stan_matrix *K) {
+    if (K->scaled) return STAN_OK;
+    const int64_t npad = (int64_t)K->nslices * 64;
+    const int64_t ns = 3 * (npad + K->nhalo);
+    if (!K->d_scale) STANCHK(stan_dmalloc(ctx, &K->d_scale, (size_t)ns));
+    hipLaunchKernelGGL(k_fill, dim3(vec_grid(ns)), dim3(VEC_T), 0, ctx->stream, K->d_scale, ns, 1.0);
+    if (K->nloc > 0)
+        hipLaunchKernelGGL(k_diag_scale, dim3(nblk(K->nloc, 256)), dim3(256), 0, ctx->stream, K->nloc,
+                           K->d_rowlen, K->d_slot_ptr, K->d_cols, K->d_vals, K->d_scale);
+    if (ctx->nranks > 1) STANCHK(stan_comm_halo_exchange(ctx, K, K->d_scale));
+    if (K->nslices > 0)
+        hipLaunchKernelGGL(k_scale_matrix, dim3(nblk(K->nslices, 4)), dim3(256), 0, ctx->stream,
+                           K->nslices, K->d_slot_ptr, K->d_cols, K->d_vals, K->d_scale, 0);
+    HIPCHK(ctx, hipGetLastError());
+    K->scaled = true;
+    return STAN_OK;
+}
+
+int stan_matrix_make_fp32(stan_ctx *ctx, stan_matrix *K) {
+    if (K->d_vals32) return STAN_OK;
+    const int64_t n = K->nslots * 9 * 64;
+    STANCHK(stan_dmalloc(ctx, &K->d_vals32, (size_t)n));
+    hipLaunchKernelGGL(k_to_fp32, dim3(vec_grid(n) * 4), dim3(VEC_T), 0, ctx->stream, K->d_vals,
+                       K->d_vals32, n);
+    HIPCHK(ctx, hipGetLastError());
+    return STAN_OK;
+}
+
+// NOTE on the halo layout: vectors that are gathered by the SpMV (p, x) hold the owned
+// block rows first, padded to whole slices, then the halo block columns:
+//   [ 3*nslices*64 owned+pad | 3*nhalo ]
+// Local column indices >= nloc written by the symbolic phase are relative to nloc, so
+// the halo region must start at 3*nloc: the pad only exists for nranks == 1 tails, where
+// nhalo == 0.  For nranks > 1 every rank's row count is a multiple of 64 except the last
+// rank's; the gather vectors are therefore sized 3*(max(nloc, pad) + nhalo) and the halo
+// always sits at 3*nloc.
+int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_f,
+                   int32_t max_its, int32_t precision_mode, double *d_U, int32_t *term_out,
+                   int32_t *iters_out, double *rel_res_out) {
+    if (precision_mode != STAN_PREC_FP64 && precision_mode != STAN_PREC_MIXED) {
+        ctx->err = "cg_solve: unknown precision_mode";
+        return STAN_E_UNSUPPORTED;
+    }
+    if (eps_f < 0 || max_its < 0) {
+        ctx->err = "cg_solve: eps_f and max_its must be >= 0";
+        return STAN_E_ARG;
+    }
+    if (eps_f == 0 && max_its == 0) eps_f = 1.0e-6;  // lincgsetcond
+    hipStream_t st_ = ctx->stream;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (ctx->profiling) {
+        hipEventCreate(&ev0); hipEventCreate(&ev1);
+        hipEventRecord(ev0, st_);
+    }
+    STANCHK(ensure_scaled(ctx, K));
+    const bool mixed = precision_mode == STAN_PREC_MIXED;
+    if (mixed) STANCHK(stan_matrix_make_fp32(ctx, K));
+
+    const int64_t n3 = 3 * K->nloc;
+    const int64_t npad = (int64_t)K->nslices * 64;
+    const int64_t ng = 3 * ((npad > K->nloc + K->nhalo ? npad : K->nloc + K->nhalo));
+    const int64_t dof0 = 3 * K->r0;
+    dev_bufs bufs;
+    double *xb[2], *p, *r, *v, *bh, *partial, *sc;
+    int64_t *stt;
+    STANCHK(alloc(ctx, bufs, &xb[0], (size_t)ng));
+    STANCHK(alloc(ctx, bufs, &xb[1], (size_t)ng));
+    STANCHK(alloc(ctx, bufs, &p, (size_t)ng));
+    STANCHK(alloc(ctx, bufs, &r, (size_t)n3));
+    STANCHK(alloc(ctx, bufs, &v, (size_t)n3));
+    STANCHK(alloc(ctx, bufs, &bh, (size_t)n3));
+    const unsigned spmv_blocks = nblk(K->nslices, 4);
+    const size_t npart = 2 * (size_t)(spmv_blocks > VEC_BLOCKS ? spmv_blocks : VEC_BLOCKS);
+    STANCHK(alloc(ctx, bufs, &partial, npart));
+    STANCHK(alloc(ctx, bufs, &sc, (size_t)S_NSCAL));
+    STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
+    HIPCHK(ctx, hipMemsetAsync(sc, 0, S_NSCAL * 8, st_));
+    HIPCHK(ctx, hipMemsetAsync(xb[0], 0, (size_t)ng * 8, st_));
+    HIPCHK(ctx, hipMemsetAsync(xb[1], 0, (size_t)ng * 8, st_));
+    HIPCHK(ctx, hipMemsetAsync(p, 0, (size_t)ng * 8, st_));
+
+    const unsigned vg = vec_grid(n3);
+    hipLaunchKernelGGL(k_init, dim3(vg), dim3(VEC_T), 0, st_, n3, dof0, K->d_red, d_F, K->d_scale,
+                       bh, xb[0], r, p, partial);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st_, partial, (int)vg, 1, sc + S_VMV);
+    if (ctx->nranks > 1) STANCHK(stan_comm_allreduce_sum_f64(ctx, sc + S_VMV, 1));
+    hipLaunchKernelGGL(k_init_scalars, dim3(1), dim3(1), 0, st_, sc, stt, eps_f);
+    HIPCHK(ctx, hipGetLastError());
+
+    // lincgcreate: ItsBeforeRestart = N (global reduced size)
+    int64_t its_before_restart = K->n_red > 0 ? K->n_red : 1;
+    const int64_t hard_cap = 0x7fffffff;  // iteration counter is int32 in the report
+
+    std::vector<hipEvent_t> spmv_ev;
+    auto spmv = [&](const double *x, double *y, bool dot, int64_t k) {
+        if (ctx->profiling) {
+            hipEvent_t a, b;
+            hipEventCreate(&a); hipEventCreate(&b);
+            hipEventRecord(a, st_);
+            spmv_ev.push_back(a); spmv_ev.push_back(b);
+        }
+        if (mixed) {
+            if (dot) launch_spmv<float, true>(ctx, K, K->d_vals32, x, y, partial, stt, k);
+            else launch_spmv<float, false>(ctx, K, K->d_vals32, x, y, partial, stt, k);
+        } else {
+            if (dot) launch_spmv<double, true>(ctx, K, K->d_vals, x, y, partial, stt, k);
+            else launch_spmv<double, false>(ctx, K, K->d_vals, x, y, partial, stt, k);
+        }
+        if (ctx->profiling) hipEventRecord(spmv_ev.back(), st_);
+    };
+
+    int64_t *h_st = ctx->h_status + 16;  // pinned
+    hipEvent_t poll[2];
+    hipEventCreateWithFlags(&poll[0], hipEventDisableTiming);
+    hipEventCreateWithFlags(&poll[1], hipEventDisableTiming);
+    int64_t k = 1;
+    int chunk_id = 0;
+    bool done = false;
+    int rc = STAN_OK;
+    // status of "iteration 0" (initial residual test)
+    HIPCHK(ctx, hipMemcpyAsync(h_st, stt, T_NSTAT * 8, hipMemcpyDeviceToHost, st_));
+    HIPCHK(ctx, hipStreamSynchronize(st_));
+    if (h_st[T_ITER_A] == 0) done = true;
+    while (!done && rc == STAN_OK) {
+        // enqueue one chunk of iterations
+        for (int c = 0; c < CHUNK && k < hard_cap; c++, k++) {
+            if (ctx->nranks > 1) { rc = stan_comm_halo_exchange(ctx, K, p); if (rc) break; }
+            spmv(p, v, true, k);
+            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st_, partial, (int)spmv_blocks, 1,
+                               sc + S_VMV);
+            if (ctx->nranks > 1) { rc = stan_comm_allreduce_sum_f64(ctx, sc + S_VMV, 1); if (rc) break; }
+            step_args a;
+            a.n3 = n3; a.k = k; a.sc = sc; a.st = stt;
+            a.xcur = xb[(k - 1) & 1]; a.xnext = xb[k & 1];
+            a.r = r; a.p = p; a.v = v; a.bh = bh; a.partial = partial;
+            a.refresh = (k % ITS_BEFORE_RUPDATE) == 0;
+            hipLaunchKernelGGL(k_step, dim3(vg), dim3(VEC_T), 0, st_, a);
+            if (a.refresh) {
+                if (ctx->nranks > 1) { rc = stan_comm_halo_exchange(ctx, K, xb[k & 1]); if (rc) break; }
+                // a -5/-4 stop of this iteration is caught by k_refresh/k_update (ITER_B <= k)
+                spmv(xb[k & 1], v, false, k);
+                hipLaunchKernelGGL(k_refresh, dim3(vg), dim3(VEC_T), 0, st_, n3, k,
+                                   (const int64_t *)stt, bh, v, xb[k & 1], r, partial);
+            }
+            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st_, partial, (int)vg, 2, sc + S_R2NEW);
+            if (ctx->nranks > 1) { rc = stan_comm_allreduce_sum_f64(ctx, sc + S_R2NEW, 2); if (rc) break; }
+            hipLaunchKernelGGL(k_update, dim3(vg), dim3(VEC_T), 0, st_, n3, k, sc, stt, eps_f,
+                               (int64_t)max_its, its_before_restart, r, p);
+        }
+        if (rc) break;
+        // poll: read the status of the PREVIOUS chunk while this one runs
+        int64_t *slot = h_st + 8 * (chunk_id & 1);
+        HIPCHK(ctx, hipMemcpyAsync(slot, stt, T_NSTAT * 8, hipMemcpyDeviceToHost, st_));
+        HIPCHK(ctx, hipEventRecord(poll[chunk_id & 1], st_));
+        if (chunk_id > 0) {
+            HIPCHK(ctx, hipEventSynchronize(poll[(chunk_id - 1) & 1]));
+            int64_t *prev = h_st + 8 * ((chunk_id - 1) & 1);
+            if (prev[T_TYPE] != 0) done = true;
+        }
+        if (k >= hard_cap) done = true;
+        chunk_id++;
+    }
+    hipError_t e = hipStreamSynchronize(st_);
+    hipEventDestroy(poll[0]); hipEventDestroy(poll[1]);
+    if (rc) return rc;
+    if (e != hipSuccess) { ctx->err = std::string("cg: ") + hipGetErrorString(e); return STAN_E_HIP; }
+    HIPCHK(ctx, hipMemcpyAsync(h_st, stt, T_NSTAT * 8, hipMemcpyDeviceToHost, st_));
+    double *h_sc = (double *)(ctx->h_status + 40);
+    HIPCHK(ctx, hipMemcpyAsync(h_sc, sc, S_NSCAL * 8, hipMemcpyDeviceToHost, st_));
+    HIPCHK(ctx, hipStreamSynchronize(st_));
+    int type = (int)h_st[T_TYPE];
+    int64_t its = h_st[T_ITERS];
+    if (type == 0) { type = 5; its = k - 1; h_st[T_XSEL] = (k - 1) & 1; }  // hard cap
+    const double *xfin = xb[h_st[T_XSEL] & 1];
+
+    // U = S x^ on the free DOFs
+    if (ctx->nranks == 1) {
+        hipLaunchKernelGGL(k_result, dim3(vg), dim3(VEC_T), 0, st_, n3, dof0, K->d_red, K->d_scale,
+                           xfin, d_U);
+    } else {
+        double *full;
+        STANCHK(alloc(ctx, bufs, &full, (size_t)K->n_dof));
+        hipLaunchKernelGGL(k_result_full, dim3(vg), dim3(VEC_T), 0, st_, n3, K->d_scale, xfin,
+                           full + dof0);
+        STANCHK(stan_comm_allgather_rows(ctx, K, full));
+        hipLaunchKernelGGL(k_compress, dim3(vec_grid(K->n_dof)), dim3(VEC_T), 0, st_, K->n_dof,
+                           K->d_red, full, d_U);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    if (ctx->profiling) hipEventRecord(ev1, st_);
+    HIPCHK(ctx, hipStreamSynchronize(st_));
+
+    if (term_out) *term_out = type;
+    if (iters_out) *iters_out = (int32_t)its;
+    if (rel_res_out) *rel_res_out = h_sc[S_BNORM] > 0 ? std::sqrt(h_sc[S_R2OUT]) / h_sc[S_BNORM] : 0.0;
+    if (ctx->profiling) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, ev0, ev1);
+        ctx->prof.cg_ms = ms;
+        double tot = 0;
+        for (size_t i = 0; i + 1 < spmv_ev.size(); i += 2) {
+            float t = 0;
+            hipEventElapsedTime(&t, spmv_ev[i], spmv_ev[i + 1]);
+            tot += t;
+        }
+        ctx->prof.spmv_ms_total = tot;
+        ctx->prof.spmv_launches = (int64_t)(spmv_ev.size() / 2);
+        for (hipEvent_t ev : spmv_ev) hipEventDestroy(ev);
+        hipEventDestroy(ev0); hipEventDestroy(ev1);
+        ctx->prof.iterations = (int32_t)its;
+        ctx->prof.termination_type = type;
+        const int64_t vb = mixed ? 4 : 8;
+        ctx->prof.spmv_bytes = K->nblocks * (9 * vb + 4) + 3 * K->nloc * 16 + K->nloc * 4;
+        ctx->prof.cg_iteration_vector_bytes = 3 * K->nloc * 8 * 10;
+    }
+    return STAN_OK;
+}
+
+// y = K x on the reduced system (test helper; single rank)
+int stan_spmv_reduced(stan_ctx *ctx, stan_matrix *K, const double *d_x, double *d_y) {
+    if (ctx->nranks != 1) { ctx->err = "spmv: single-rank contexts only"; return STAN_E_UNSUPPORTED; }
+    hipStream_t st_ = ctx->stream;
+    const int64_t n3 = 3 * K->nloc, npad3 = 3 * (int64_t)K->nslices * 64;
+    dev_bufs bufs;
+    double *xf, *yf; int64_t *stt;
+    STANCHK(alloc(ctx, bufs, &xf, (size_t)npad3));
+    STANCHK(alloc(ctx, bufs, &yf, (size_t)npad3));
+    STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
+    int64_t init[T_NSTAT] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0, 0, 0, 0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(stt, init, sizeof(init), hipMemcpyHostToDevice, st_));
+    HIPCHK(ctx, hipMemsetAsync(xf, 0, (size_t)npad3 * 8, st_));
+    const double *sdiv = K->scaled ? K->d_scale : nullptr;
+    // K x = S^-1 (A^ (S^-1 x)) when the matrix already carries its scaling
+    hipLaunchKernelGGL(k_expand, dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, n3, (int64_t)0, K->d_red,
+                       d_x, sdiv, xf);
+    launch_spmv<double, false>(ctx, K, K->d_vals, xf, yf, nullptr, stt, 1);
+    // compress (and undo the row scaling)
+    hipLaunchKernelGGL(k_compress_div, dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, n3, K->d_red, sdiv, yf, d_y);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(st_));
+    return STAN_OK;
+}
+
+int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode, int32_t reps,
+                           double *avg_ms) {
+    hipStream_t st_ = ctx->stream;
+    const bool mixed = precision_mode == STAN_PREC_MIXED;
+    if (mixed) STANCHK(stan_matrix_make_fp32(ctx, K));
+    const int64_t npad = (int64_t)K->nslices * 64;
+    const int64_t ng = 3 * ((npad > K->nloc + K->nhalo ? npad : K->nloc + K->nhalo));
+    dev_bufs bufs;
+    double *x, *y, *partial; int64_t *stt;
+    STANCHK(alloc(ctx, bufs, &x, (size_t)ng));
+    STANCHK(alloc(ctx, bufs, &y, (size_t)ng));
+    STANCHK(alloc(ctx, bufs, &partial, (size_t)nblk(K->nslices, 4) + 1));
+    STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
+    int64_t init[T_NSTAT] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0, 0, 0, 0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(stt, init, sizeof(init), hipMemcpyHostToDevice, st_));
+    hipLaunchKernelGGL(k_fill, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, x, ng, 1.0);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    auto one = [&]() {
+        if (mixed) launch_spmv<float, true>(ctx, K, K->d_vals32, x, y, partial, stt, 1);
+        else launch_spmv<double, true>(ctx, K, K->d_vals, x, y, partial, stt, 1);
+    };
+    for (int i = 0; i < 3; i++) one();
+    hipEventRecord(a, st_);
+    for (int i = 0; i < reps; i++) one();
+    hipEventRecord(b, st_);
+    HIPCHK(ctx, hipEventSynchronize(b));
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    hipEventDestroy(a); hipEventDestroy(b);
+    *avg_ms = reps > 0 ? ms / reps : 0;
+    HIPCHK(ctx, hipGetLastError());
+    return STAN_OK;
+}
+
+// un-scale on export
+int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K) {
+    if (!K->scaled) return STAN_OK;
+    if (K->nslices > 0)
+        hipLaunchKernelGGL(k_scale_matrix, dim3(nblk(K->nslices, 4)), dim3(256), 0, ctx->stream,
+                           K->nslices, K->d_slot_ptr, K->d_cols, K->d_vals, K->d_scale, 1);
+    HIPCHK(ctx, hipGetLastError());
+    K->scaled = false;
+    if (K->d_vals32) { hipFree(K->d_vals32); K->d_vals32 = nullptr; }
+    return STAN_OK;
+}

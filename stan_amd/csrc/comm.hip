@@ -1,0 +1,156 @@
+// comm.hip -- RCCL plumbing of the sharded CG (one process per GPU, xGMI underneath).
+//
+// The reference has no distributed path (a single process with TPL
+// threads); this is new design.  Rows of K are sharded by contiguous block-row ranges
+// in reference DOF order.  Per CG iteration the only exchanges are
+//   * one halo exchange of p (grouped ncclSend/ncclRecv with the few neighbour ranks whose
+//     rows couple to ours; a BFS-level ordering keeps that to rank+-1 on connected meshes),
+//   * two all-reduces of 1-2 doubles (p.Ap; r.r with the merit function piggy-backed).
+// The payloads are latency-bound, not bandwidth-bound, so nothing is bucketed or ringed.
+//
+// RCCL is resolved with dlopen at comm_init: libstan_hip.so has no link-time dependency
+// on it and loads on hosts without RCCL (and next to torch's bundled librccl.so.1).
+#include <dlfcn.h>
+
+#include <cstring>
+
+#include "internal.h"
+
+namespace {
+
+struct nccl_uid { char internal[128]; };
+constexpr int NCCL_SUM = 0, NCCL_INT64 = 4, NCCL_F64 = 8;
+
+typedef int (*fn_commInitRank)(void **, int, nccl_uid, int);
+
+int load_rccl(stan_ctx *ctx) {
+    rccl_api &n = ctx->nccl;
+    if (n.handle) return STAN_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names) {
+        n.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (n.handle) break;
+    }
+    if (!n.handle) {
+        ctx->err = std::string("dlopen(librccl): ") + dlerror();
+        return STAN_E_COMM;
+    }
+#define SYM(field, name)                                              \
+    *(void **)(&n.field) = dlsym(n.handle, name);                     \
+    if (!n.field) {                                                   \
+        ctx->err = std::string("dlsym(") + name + ") failed";         \
+        return STAN_E_COMM;                                           \
+    }
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(AllReduce, "ncclAllReduce");
+    SYM(Broadcast, "ncclBroadcast");
+    SYM(Send, "ncclSend");
+    SYM(Recv, "ncclRecv");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    return STAN_OK;
+}
+
+#define NCCLCHK(ctx, call)                                                                 \
+    do {                                                                                   \
+        int r_ = (call);                                                                   \
+        if (r_ != 0) {                                                                     \
+            (ctx)->err = std::string(#call) + ": " + (ctx)->nccl.GetErrorString(r_);       \
+            return STAN_E_COMM;                                                            \
+        }                                                                                  \
+    } while (0)
+
+// sendbuf[3*i + c] = vec[3*rows[i] + c]
+__global__ void k_pack(int64_t n, const int32_t *rows, const double *vec, double *buf) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < 3 * n; t += stride) {
+        const int64_t i = t / 3;
+        const int c = (int)(t - 3 * i);
+        buf[t] = vec[3 * (int64_t)rows[i] + c];
+    }
+}
+
+}  // namespace
+
+extern "C" int stan_hip_comm_unique_id(char id[128]) {
+    stan_ctx tmp;
+    int rc = load_rccl(&tmp);
+    if (rc) return rc;
+    return tmp.nccl.GetUniqueId((void *)id) == 0 ? STAN_OK : STAN_E_COMM;
+}
+
+extern "C" int stan_hip_comm_init(stan_ctx *ctx, int rank, int nranks, const char id[128]) {
+    if (!ctx || nranks < 1 || rank < 0 || rank >= nranks) return STAN_E_ARG;
+    if (ctx->comm) {
+        ctx->err = "comm_init: communicator already initialised";
+        return STAN_E_ARG;
+    }
+    ctx->rank = rank;
+    ctx->nranks = nranks;
+    if (nranks == 1) return STAN_OK;
+    if (nranks > 64) {
+        ctx->err = "comm_init: at most 64 ranks";
+        return STAN_E_ARG;
+    }
+    STANCHK(load_rccl(ctx));
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    nccl_uid uid;
+    memcpy(uid.internal, id, 128);
+    NCCLCHK(ctx, ((fn_commInitRank)ctx->nccl.CommInitRank)(&ctx->comm, nranks, uid, rank));
+    return STAN_OK;
+}
+
+int stan_comm_allreduce_sum_f64(stan_ctx *ctx, double *d_buf, size_t count) {
+    if (ctx->nranks == 1) return STAN_OK;
+    NCCLCHK(ctx, ctx->nccl.AllReduce(d_buf, d_buf, count, NCCL_F64, NCCL_SUM, ctx->comm, ctx->stream));
+    return STAN_OK;
+}
+
+int stan_comm_allreduce_sum_i64(stan_ctx *ctx, int64_t *d_buf, size_t count) {
+    if (ctx->nranks == 1) return STAN_OK;
+    NCCLCHK(ctx, ctx->nccl.AllReduce(d_buf, d_buf, count, NCCL_INT64, NCCL_SUM, ctx->comm, ctx->stream));
+    return STAN_OK;
+}
+
+int stan_comm_halo_exchange(stan_ctx *ctx, stan_matrix *K, double *d_vec) {
+    if (ctx->nranks == 1 || K->nbr.empty()) return STAN_OK;
+    const int64_t stot = K->send_off.back();
+    if (stot > 0) {
+        int64_t b = (3 * stot + 255) / 256;
+        if (b > 1024) b = 1024;
+        hipLaunchKernelGGL(k_pack, dim3((unsigned)b), dim3(256), 0, ctx->stream, stot, K->d_send_rows,
+                           d_vec, K->d_sendbuf);
+    }
+    double *halo = d_vec + 3 * K->nloc;
+    NCCLCHK(ctx, ctx->nccl.GroupStart());
+    for (size_t i = 0; i < K->nbr.size(); i++) {
+        const int64_t ns = K->send_off[i + 1] - K->send_off[i];
+        const int64_t nr = K->recv_off[i + 1] - K->recv_off[i];
+        if (ns > 0)
+            NCCLCHK(ctx, ctx->nccl.Send(K->d_sendbuf + 3 * K->send_off[i], (size_t)(3 * ns), NCCL_F64,
+                                        K->nbr[i], ctx->comm, ctx->stream));
+        if (nr > 0)
+            NCCLCHK(ctx, ctx->nccl.Recv(halo + 3 * K->recv_off[i], (size_t)(3 * nr), NCCL_F64,
+                                        K->nbr[i], ctx->comm, ctx->stream));
+    }
+    NCCLCHK(ctx, ctx->nccl.GroupEnd());
+    return STAN_OK;
+}
+
+// every rank contributes its owned rows of a global block vector (3 doubles per block row)
+int stan_comm_allgather_rows(stan_ctx *ctx, stan_matrix *K, double *d_full) {
+    if (ctx->nranks == 1) return STAN_OK;
+    NCCLCHK(ctx, ctx->nccl.GroupStart());
+    for (int r = 0; r < ctx->nranks; r++) {
+        const int64_t a = K->row_starts[r], b = K->row_starts[r + 1];
+        if (b > a)
+            NCCLCHK(ctx, ctx->nccl.Broadcast(d_full + 3 * a, d_full + 3 * a, (size_t)(3 * (b - a)),
+                                             NCCL_F64, r, ctx->comm, ctx->stream));
+    }
+    NCCLCHK(ctx, ctx->nccl.GroupEnd());
+    return STAN_OK;
+}

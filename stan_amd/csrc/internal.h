@@ -1,0 +1,138 @@
+// internal.h -- shared declarations of libstan_hip.so (not part of the C-ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/stan_hip.h"
+
+#define STAN_SLICE 64      // block rows per ELL slice == wavefront width
+#define STAN_MAX_INCIDENT 64  // (element,local node) pairs per node the symbolic kernels accept
+#define STAN_MAX_ROW_BLOCKS 96
+
+// HIP call guard: records the error on the context and returns STAN_E_HIP.
+#define HIPCHK(ctx, call)                                                              \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);            \
+            return (e_ == hipErrorOutOfMemory) ? STAN_E_ALLOC : STAN_E_HIP;            \
+        }                                                                              \
+    } while (0)
+
+#define STANCHK(call)                 \
+    do {                              \
+        int rc_ = (call);             \
+        if (rc_ != STAN_OK) return rc_; \
+    } while (0)
+
+// RCCL entry points, resolved with dlopen at comm_init (no link-time dependency so the
+// library loads on a host without RCCL / without a GPU).
+struct rccl_api {
+    void *handle = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, const void *, int) = nullptr;  // ncclUniqueId by value
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+struct stan_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    int64_t bad_elem = -1;
+    // communicator
+    int rank = 0, nranks = 1;
+    void *comm = nullptr;
+    rccl_api nccl;
+    // profiling
+    bool profiling = false;
+    stan_profile prof{};
+    // small pinned host + device scratch for status words
+    int64_t *h_status = nullptr;  // pinned, 64 words
+    int64_t *d_status = nullptr;  // device, 64 words
+};
+
+struct stan_matrix {
+    stan_ctx *ctx = nullptr;
+    int64_t n_dof = 0, n_red = 0;
+    int64_t nb_glob = 0;  // global block rows
+    int64_t r0 = 0, r1 = 0;  // owned block rows
+    int64_t nloc = 0, nhalo = 0;
+    int32_t nslices = 0;
+    int64_t nslots = 0;      // total k-slots (each = 64 rows x one block)
+    int64_t nblocks = 0;     // structural blocks on this rank
+    int32_t max_row_blocks = 0;
+    int32_t *d_slot_ptr = nullptr;  // [nslices+1]
+    int32_t *d_rowlen = nullptr;    // [nslices*64] blocks per row
+    int32_t *d_cols = nullptr;      // [nslots][64] local block-column index
+    double *d_vals = nullptr;       // [nslots][9][64]
+    float *d_vals32 = nullptr;      // same layout, fp32 copy (mixed precision)
+    int32_t *d_red = nullptr;       // [n_dof] nDOF_reduction
+    uint8_t *d_fixmask = nullptr;   // [nb_glob] bit m = DOF m of the node fixed
+    double *d_scale = nullptr;      // [3*(nloc+nhalo)] s_i = 1/sqrt(K_ii)
+    bool scaled = false;
+    // halo plan (all index lists on device, counts on host)
+    std::vector<int> nbr;             // neighbour ranks
+    std::vector<int64_t> send_off;    // [nbr+1] offsets into d_send_rows
+    std::vector<int64_t> recv_off;    // [nbr+1] offsets into the halo region (block cols)
+    int32_t *d_send_rows = nullptr;   // local block rows to pack, grouped by neighbour
+    int32_t *d_halo_glob = nullptr;   // [nhalo] global block index of each halo column
+    double *d_sendbuf = nullptr;      // [3*send_total]
+    std::vector<int64_t> row_starts;  // [nranks+1] partition
+};
+
+// ---- scan.hip -------------------------------------------------------------------------------
+// out[i] = sum_{j<i} in[j] (int32 in, int64 out), out has n+1 entries (out[n] = total).
+int stan_scan_exclusive(stan_ctx *ctx, const int32_t *d_in, int64_t *d_out, int64_t n);
+
+// ---- assembly.hip ---------------------------------------------------------------------------
+int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
+                         const int32_t *d_node_dof, int64_t n_elem, const int32_t *d_conn,
+                         const int32_t *d_elem_mat, const uint8_t *d_elem_type, int32_t n_mat,
+                         const double *mat_E_nu, int64_t n_dof, const int32_t *d_red,
+                         stan_matrix **outK);
+int stan_ke_batch_device(stan_ctx *ctx, int64_t n, const double *d_xyz8, double E, double nu,
+                         const uint8_t *d_type, double *d_out);
+
+// ---- cg.hip ---------------------------------------------------------------------------------
+int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_f,
+                   int32_t max_its, int32_t precision_mode, double *d_U, int32_t *term,
+                   int32_t *iters, double *rel_res);
+int stan_spmv_reduced(stan_ctx *ctx, stan_matrix *K, const double *d_x, double *d_y);
+int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode, int32_t reps,
+                           double *avg_ms);
+int stan_matrix_make_fp32(stan_ctx *ctx, stan_matrix *K);
+int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K);
+
+// ---- comm.cpp -------------------------------------------------------------------------------
+int stan_comm_allreduce_sum_f64(stan_ctx *ctx, double *d_buf, size_t count);
+int stan_comm_allreduce_sum_i64(stan_ctx *ctx, int64_t *d_buf, size_t count);
+// exchange: pack rows listed in K->d_send_rows from d_vec (3 doubles per block row) and
+// receive into d_vec + 3*nloc (halo region).
+int stan_comm_halo_exchange(stan_ctx *ctx, stan_matrix *K, double *d_vec);
+int stan_comm_allgather_rows(stan_ctx *ctx, stan_matrix *K, double *d_full_blockvec);
+
+// device memory helpers
+template <typename T>
+static inline int stan_dmalloc(stan_ctx *ctx, T **p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+    if (e != hipSuccess) {
+        ctx->err = std::string("hipMalloc(") + std::to_string(count * sizeof(T)) +
+                   " B): " + hipGetErrorString(e);
+        return STAN_E_ALLOC;
+    }
+    return STAN_OK;
+}

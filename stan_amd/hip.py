@@ -1,0 +1,256 @@
+"""ctypes binding of libstan_hip.so (include/stan_hip.h).
+
+This is plumbing for tests, bench.py and __graft_entry__: the product is the
+shared library.  There is NO CPU fallback: loading fails loudly if the library
+has not been built, and stan_hip_init fails if no GPU is present.
+
+Import torch BEFORE this module in any process that also uses torch, so that
+both share one HIP runtime (torch bundles its own libamdhip64.so.7).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libstan_hip.so")
+
+HEX8_G1, HEX8_G2 = 1, 2
+PREC_FP64, PREC_MIXED = 0, 1
+E_HIP, E_ARG, E_ALLOC, E_DETJ, E_DOF_LAYOUT, E_VALENCE, E_COMM, E_UNSUPPORTED = (
+    -1, -2, -3, -4, -5, -6, -7, -8)
+
+EXPORTS = [
+    "stan_hip_init", "stan_hip_destroy", "stan_hip_last_error", "stan_hip_last_bad_element",
+    "stan_hip_set_stream", "stan_hip_comm_unique_id", "stan_hip_comm_init",
+    "stan_hip_assemble_hex8", "stan_hip_assemble_hex8_dev", "stan_hip_matrix_free",
+    "stan_hip_cg_solve", "stan_hip_cg_solve_dev", "stan_hip_matrix_info", "stan_hip_ke_hex8",
+    "stan_hip_ke_hex8_batch", "stan_hip_matrix_to_csr", "stan_hip_spmv", "stan_hip_spmv_bench",
+    "stan_hip_set_profiling", "stan_hip_get_profile",
+]
+
+
+class MatrixInfo(C.Structure):
+    _fields_ = [("n_dof", C.c_int64), ("n_reduced", C.c_int64), ("n_block_rows", C.c_int64),
+                ("row_begin", C.c_int64), ("row_end", C.c_int64), ("n_halo", C.c_int64),
+                ("n_blocks", C.c_int64), ("n_slots", C.c_int64), ("bytes_matrix", C.c_int64),
+                ("scaled", C.c_int32), ("max_row_blocks", C.c_int32)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("assemble_ms", C.c_double), ("symbolic_ms", C.c_double),
+                ("numeric_ms", C.c_double), ("cg_ms", C.c_double), ("spmv_ms_total", C.c_double),
+                ("spmv_launches", C.c_int64), ("spmv_bytes", C.c_int64),
+                ("cg_iteration_vector_bytes", C.c_int64), ("iterations", C.c_int32),
+                ("termination_type", C.c_int32)]
+
+
+class StanHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libstan_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library (works without a GPU; compute calls do not)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.stan_hip_last_error.restype = C.c_char_p
+        _lib.stan_hip_last_bad_element.restype = C.c_int64
+        _lib.stan_hip_destroy.restype = None
+        _lib.stan_hip_matrix_free.restype = None
+    return _lib
+
+
+def _ptr(a, t):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _dev(p, t):
+    """device pointer given as int (torch tensor.data_ptr())"""
+    return C.cast(C.c_void_p(int(p)), C.POINTER(t))
+
+
+class Context:
+    def __init__(self, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.stan_hip_init(C.c_int(device), C.byref(h))
+        if rc != 0:
+            self.lib.stan_hip_last_error.argtypes = [C.c_void_p]
+            msg = self.lib.stan_hip_last_error(None)
+            raise StanHipError(rc, msg.decode() if msg else "stan_hip_init failed")
+        self.h = h
+        self.lib.stan_hip_last_error.argtypes = [C.c_void_p]
+        self.lib.stan_hip_last_bad_element.argtypes = [C.c_void_p]
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.stan_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise StanHipError(rc, self.lib.stan_hip_last_error(self.h).decode())
+
+    def last_bad_element(self):
+        return int(self.lib.stan_hip_last_bad_element(self.h))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.lib.stan_hip_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def set_profiling(self, on=True):
+        self._chk(self.lib.stan_hip_set_profiling(self.h, C.c_int32(1 if on else 0)))
+
+    def profile(self):
+        p = Profile()
+        self._chk(self.lib.stan_hip_get_profile(self.h, C.byref(p)))
+        return {k: getattr(p, k) for k, _ in Profile._fields_}
+
+    # -- multi-GPU -----------------------------------------------------------------
+    def unique_id(self):
+        buf = C.create_string_buffer(128)
+        rc = self.lib.stan_hip_comm_unique_id(buf)
+        if rc != 0:
+            raise StanHipError(rc, "ncclGetUniqueId failed")
+        return bytes(buf.raw)
+
+    def comm_init(self, rank, nranks, uid):
+        buf = C.create_string_buffer(bytes(uid), 128)
+        self._chk(self.lib.stan_hip_comm_init(self.h, C.c_int(rank), C.c_int(nranks), buf))
+
+    # -- K_e (debug / parity) ---------------------------------------------------------
+    def ke_hex8(self, xyz8, E, nu, etype):
+        xyz8 = np.ascontiguousarray(xyz8, dtype=np.float64).reshape(24)
+        out = np.zeros(576)
+        self._chk(self.lib.stan_hip_ke_hex8(self.h, _ptr(xyz8, C.c_double), C.c_double(E),
+                                            C.c_double(nu), C.c_int32(etype),
+                                            _ptr(out, C.c_double)))
+        return out.reshape(24, 24)
+
+    def ke_hex8_batch(self, xyz8, E, nu, etypes):
+        xyz8 = np.ascontiguousarray(xyz8, dtype=np.float64).reshape(-1, 24)
+        n = xyz8.shape[0]
+        etypes = np.ascontiguousarray(etypes, dtype=np.uint8)
+        out = np.zeros((n, 576))
+        self._chk(self.lib.stan_hip_ke_hex8_batch(self.h, C.c_int64(n), _ptr(xyz8, C.c_double),
+                                                  C.c_double(E), C.c_double(nu),
+                                                  _ptr(etypes, C.c_uint8), _ptr(out, C.c_double)))
+        return out.reshape(n, 24, 24)
+
+    # -- assembly ------------------------------------------------------------------------
+    def assemble_hex8(self, xyz, node_dof, conn, elem_mat, elem_type, mat_E_nu, red):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+        node_dof = np.ascontiguousarray(node_dof, dtype=np.int32)
+        conn = np.ascontiguousarray(conn, dtype=np.int32).reshape(-1, 8)
+        elem_mat = np.ascontiguousarray(elem_mat, dtype=np.int32)
+        elem_type = np.ascontiguousarray(elem_type, dtype=np.uint8)
+        mat_E_nu = np.ascontiguousarray(mat_E_nu, dtype=np.float64).reshape(-1, 2)
+        red = np.ascontiguousarray(red, dtype=np.int32)
+        k = C.c_void_p()
+        self._chk(self.lib.stan_hip_assemble_hex8(
+            self.h, C.c_int64(xyz.shape[0]), _ptr(xyz, C.c_double), _ptr(node_dof, C.c_int32),
+            C.c_int64(conn.shape[0]), _ptr(conn, C.c_int32), _ptr(elem_mat, C.c_int32),
+            _ptr(elem_type, C.c_uint8), C.c_int32(mat_E_nu.shape[0]), _ptr(mat_E_nu, C.c_double),
+            C.c_int64(red.shape[0]), _ptr(red, C.c_int32), C.byref(k)))
+        return Matrix(self, k)
+
+    def assemble_hex8_dev(self, n_nodes, d_xyz, d_node_dof, n_elem, d_conn, d_elem_mat,
+                          d_elem_type, mat_E_nu, n_dof, d_red):
+        """All d_* are device pointers (ints), e.g. torch tensor.data_ptr()."""
+        mat_E_nu = np.ascontiguousarray(mat_E_nu, dtype=np.float64).reshape(-1, 2)
+        k = C.c_void_p()
+        self._chk(self.lib.stan_hip_assemble_hex8_dev(
+            self.h, C.c_int64(n_nodes), _dev(d_xyz, C.c_double), _dev(d_node_dof, C.c_int32),
+            C.c_int64(n_elem), _dev(d_conn, C.c_int32), _dev(d_elem_mat, C.c_int32),
+            _dev(d_elem_type, C.c_uint8), C.c_int32(mat_E_nu.shape[0]), _ptr(mat_E_nu, C.c_double),
+            C.c_int64(n_dof), _dev(d_red, C.c_int32), C.byref(k)))
+        return Matrix(self, k)
+
+
+class Matrix:
+    """Opaque device-resident K (stan_matrix*)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.k = handle
+
+    def free(self):
+        if getattr(self, "k", None):
+            self.ctx.lib.stan_hip_matrix_free(self.k)
+            self.k = None
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.free()
+        except Exception:
+            pass
+
+    def info(self):
+        i = MatrixInfo()
+        self.ctx._chk(self.ctx.lib.stan_hip_matrix_info(self.k, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in MatrixInfo._fields_}
+
+    def cg_solve(self, F, eps_f, max_its=0, precision_mode=PREC_FP64):
+        F = np.ascontiguousarray(F, dtype=np.float64)
+        U = np.zeros_like(F)
+        term, its, rel = C.c_int32(0), C.c_int32(0), C.c_double(0)
+        self.ctx._chk(self.ctx.lib.stan_hip_cg_solve(
+            self.ctx.h, self.k, _ptr(F, C.c_double), C.c_double(eps_f), C.c_int32(max_its),
+            C.c_int32(precision_mode), _ptr(U, C.c_double), C.byref(term), C.byref(its),
+            C.byref(rel)))
+        return U, dict(terminationtype=term.value, iterations=its.value, rel_residual=rel.value)
+
+    def cg_solve_dev(self, d_F, d_U, eps_f, max_its=0, precision_mode=PREC_FP64):
+        term, its, rel = C.c_int32(0), C.c_int32(0), C.c_double(0)
+        self.ctx._chk(self.ctx.lib.stan_hip_cg_solve_dev(
+            self.ctx.h, self.k, _dev(d_F, C.c_double), C.c_double(eps_f), C.c_int32(max_its),
+            C.c_int32(precision_mode), _dev(d_U, C.c_double), C.byref(term), C.byref(its),
+            C.byref(rel)))
+        return dict(terminationtype=term.value, iterations=its.value, rel_residual=rel.value)
+
+    def to_csr(self, upper_only=True):
+        nnz = C.c_int64(0)
+        lib, h = self.ctx.lib, self.ctx.h
+        self.ctx._chk(lib.stan_hip_matrix_to_csr(h, self.k, C.c_int32(int(upper_only)),
+                                                 C.byref(nnz), None, None, None))
+        N = self.info()["n_reduced"]
+        rowptr = np.zeros(N + 1, dtype=np.int64)
+        col = np.zeros(max(nnz.value, 1), dtype=np.int32)
+        val = np.zeros(max(nnz.value, 1), dtype=np.float64)
+        self.ctx._chk(lib.stan_hip_matrix_to_csr(h, self.k, C.c_int32(int(upper_only)),
+                                                 C.byref(nnz), _ptr(rowptr, C.c_int64),
+                                                 _ptr(col, C.c_int32), _ptr(val, C.c_double)))
+        return rowptr, col[:nnz.value], val[:nnz.value]
+
+    def spmv(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros_like(x)
+        self.ctx._chk(self.ctx.lib.stan_hip_spmv(self.ctx.h, self.k, _ptr(x, C.c_double),
+                                                 _ptr(y, C.c_double)))
+        return y
+
+    def spmv_bench(self, reps=20, precision_mode=PREC_FP64):
+        ms = C.c_double(0)
+        self.ctx._chk(self.ctx.lib.stan_hip_spmv_bench(self.ctx.h, self.k,
+                                                       C.c_int32(precision_mode), C.c_int32(reps),
+                                                       C.byref(ms)))
+        return ms.value

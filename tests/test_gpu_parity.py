@@ -1,0 +1,251 @@
+"""GPU parity tests: libstan_hip.so (through the C-ABI) against the CPU oracle on the same
+seeded inputs, plus size-independent properties at larger sizes.
+
+Bars: DOF / CSR indexing bit-exact; K values <= 1e-13 relative to max|K| (fp64, different
+summation order than MatrixST); displacements <= 1e-6 relative (BASELINE.json north_star)."""
+import os
+
+import numpy as np
+import pytest
+
+from stan_amd import problem
+from tests.util import UNIT, random_hexes
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "hot_path_golden.npz"))
+K_TOL = 1e-13
+U_TOL = 1e-6
+
+
+def _assemble_both(ctx, oracle, job):
+    K = ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type,
+                          job.mat_E_nu, job.red)
+    rc, A = oracle.assemble(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type,
+                            job.mat_E_nu, job.red)
+    assert rc == 0
+    return K, A
+
+
+@pytest.mark.parametrize("etype", [1, 2])
+def test_ke_parity(gpu_ctx, oracle, etype):
+    xs = random_hexes(64, seed=21)
+    Kg = gpu_ctx.ke_hex8_batch(xs, 70000.0, 0.33, np.full(64, etype, np.uint8))
+    for x, kg in zip(xs, Kg):
+        rc, ko = oracle.ke_hex8(x, 70000.0, 0.33, etype)
+        assert rc == 0
+        assert np.abs(kg - ko).max() <= K_TOL * np.abs(ko).max()
+    k1 = gpu_ctx.ke_hex8(UNIT, 210000.0, 0.3, etype)
+    assert np.abs(k1 - GOLD["ke_unit_g%d" % etype]).max() <= K_TOL * np.abs(k1).max()
+
+
+def test_ke_singular_jacobian_is_an_error(gpu_ctx):
+    from stan_amd import hip
+    x = UNIT.copy(); x[:, 2] = 0.0
+    with pytest.raises(hip.StanHipError) as ei:
+        gpu_ctx.ke_hex8(x, 1.0, 0.3, 2)
+    assert ei.value.code == hip.E_DETJ and gpu_ctx.last_bad_element() == 0
+
+
+@pytest.mark.parametrize("n,etype,jit", [(1, 2, 0.0), (2, 2, 0.0), (3, 2, 0.1), (5, 1, 0.1),
+                                         (8, 2, 0.1), (13, 2, 0.05)])
+def test_assembly_csr_parity(gpu_ctx, oracle, n, etype, jit):
+    job = problem.cube_job(n, etype=etype, jitter=jit)
+    K, A = _assemble_both(gpu_ctx, oracle, job)
+    info = K.info()
+    assert info["n_dof"] == job.n_dof and info["n_reduced"] == job.n_red
+    rowptr, col, val = K.to_csr(upper_only=True)
+    assert np.array_equal(rowptr, A.ridx)           # bit-exact indexing
+    assert np.array_equal(col, A.idx)
+    assert np.abs(val - A.vals).max() <= K_TOL * np.abs(A.vals).max()
+    # full (symmetric) export is the mirror of the upper one
+    rp, cf, vf = K.to_csr(upper_only=False)
+    assert rp[-1] == 2 * A.nnz - A.n
+    K.free()
+
+
+def test_assembly_is_bit_reproducible(gpu_ctx):
+    job = problem.cube_job(6, jitter=0.1)
+    vals = []
+    for _ in range(2):
+        K = gpu_ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type,
+                                  job.mat_E_nu, job.red)
+        vals.append(K.to_csr()[2])
+        K.free()
+    assert np.array_equal(vals[0], vals[1])
+
+
+def test_assembly_mixed_types_materials_partial_spc(gpu_ctx, oracle):
+    rng = np.random.default_rng(3)
+    job = problem.cube_job(5, jitter=0.1)
+    job.elem_type = rng.integers(1, 3, job.conn.shape[0]).astype(np.uint8)
+    job.elem_mat = rng.integers(0, 3, job.conn.shape[0]).astype(np.int32)
+    job.mat_E_nu = np.array([[210000.0, 0.3], [70000.0, 0.33], [1000.0, 0.45]])
+    # partially fixed nodes: (1,0,1) on a few nodes
+    from stan_amd import host
+    from stan_amd.cube import cube_bcs
+    spc, ld, f = cube_bcs(5)
+    vals = np.ones((spc.shape[0], 3)); vals[::3, 1] = 0
+    job.red, job.n_fixed = host.dof_reduction(job.n_dof, job.node_dof, spc, vals)
+    K, A = _assemble_both(gpu_ctx, oracle, job)
+    rowptr, col, val = K.to_csr()
+    assert np.array_equal(rowptr, A.ridx) and np.array_equal(col, A.idx)
+    assert np.abs(val - A.vals).max() <= K_TOL * np.abs(A.vals).max()
+    K.free()
+
+
+def test_assembly_shuffled_wire_order(gpu_ctx, oracle):
+    """Node and element wire order is arbitrary in an STdb (Dictionary order)."""
+    from stan_amd.cube import cube_bcs, cube_mesh
+    rng = np.random.default_rng(9)
+    n = 4
+    xyz, conn = cube_mesh(n, jitter=0.1)
+    perm = rng.permutation(xyz.shape[0])
+    xyz2 = np.empty_like(xyz); xyz2[perm] = xyz
+    conn2 = perm[conn][rng.permutation(conn.shape[0])].astype(np.int32)
+    spc, ld, f = cube_bcs(n)
+    job = problem.make_job(xyz2, conn2, perm[spc], np.ones((spc.shape[0], 3)), perm[ld],
+                           np.tile(f, (ld.shape[0], 1)))
+    K, A = _assemble_both(gpu_ctx, oracle, job)
+    rowptr, col, val = K.to_csr()
+    assert np.array_equal(rowptr, A.ridx) and np.array_equal(col, A.idx)
+    assert np.abs(val - A.vals).max() <= K_TOL * np.abs(A.vals).max()
+    U, rep = K.cg_solve(job.F, 1e-12)
+    Uo, _ = oracle.cg(A, job.F, 1e-12)
+    assert np.abs(U - Uo).max() <= U_TOL * np.abs(Uo).max()
+    K.free()
+
+
+def test_assembly_errors(gpu_ctx):
+    from stan_amd import hip
+    job = problem.cube_job(3)
+    xyz = job.xyz.copy()
+    xyz[job.conn[5]] = xyz[job.conn[5]] * [1, 1, 0]       # flatten one element: det J == 0
+    with pytest.raises(hip.StanHipError) as ei:
+        gpu_ctx.assemble_hex8(xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type,
+                              job.mat_E_nu, job.red)
+    assert ei.value.code == hip.E_DETJ
+    bad_dof = job.node_dof.copy(); bad_dof[4, 1] += 7
+    with pytest.raises(hip.StanHipError) as ei:
+        gpu_ctx.assemble_hex8(job.xyz, bad_dof, job.conn, job.elem_mat, job.elem_type,
+                              job.mat_E_nu, job.red)
+    assert ei.value.code == hip.E_DOF_LAYOUT
+    bad_t = job.elem_type.copy(); bad_t[0] = 9
+    with pytest.raises(hip.StanHipError) as ei:
+        gpu_ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, bad_t,
+                              job.mat_E_nu, job.red)
+    assert ei.value.code == hip.E_UNSUPPORTED
+
+
+def test_spmv_parity(gpu_ctx, oracle):
+    job = problem.cube_job(7, jitter=0.1)
+    K, A = _assemble_both(gpu_ctx, oracle, job)
+    x = np.random.default_rng(0).standard_normal(job.n_red)
+    y = K.spmv(x)
+    yo = oracle.smv_upper(A, x)
+    assert np.abs(y - yo).max() <= 1e-12 * np.abs(yo).max()
+    K.free()
+
+
+@pytest.mark.parametrize("tag,n,etype,jit", [("cube2_g2_j0", 2, 2, 0.0), ("cube4_g2_j1", 4, 2, 0.1),
+                                              ("cube6_g2_j0", 6, 2, 0.0), ("cube5_g1_j1", 5, 1, 0.1)])
+def test_cg_vs_golden_direct_solve(gpu_ctx, tag, n, etype, jit):
+    job = problem.cube_job(n, etype=etype, jitter=jit)
+    K = gpu_ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type,
+                              job.mat_E_nu, job.red)
+    U, rep = K.cg_solve(job.F, 1e-12)
+    assert rep["terminationtype"] in (1, 7)
+    Ud = GOLD[tag + "_U"]
+    assert np.abs(U - Ud).max() <= U_TOL * np.abs(Ud).max()
+    K.free()
+
+
+@pytest.mark.parametrize("n,etype", [(10, 2), (16, 2), (12, 1)])
+def test_cg_parity_with_oracle(gpu_ctx, oracle, n, etype):
+    job = problem.cube_job(n, etype=etype, jitter=0.05)
+    K, A = _assemble_both(gpu_ctx, oracle, job)
+    for eps in (1e-12, 1e-8):
+        U, rep = K.cg_solve(job.F, eps)
+        Uo, repo = oracle.cg(A, job.F, eps)
+        assert rep["terminationtype"] == repo["terminationtype"]
+        tol = U_TOL if eps == 1e-12 else 1e-3   # at loose eps both stop O(kappa*eps) from the solution
+        assert np.abs(U - Uo).max() <= tol * np.abs(Uo).max()
+        # same algorithm => iteration counts agree up to rounding-induced drift
+        assert abs(rep["iterations"] - repo["iterations"]) <= max(3, repo["iterations"] // 50)
+    K.free()
+
+
+def test_cg_termination_codes(gpu_ctx, oracle):
+    job = problem.cube_job(4)
+    K, A = _assemble_both(gpu_ctx, oracle, job)
+    U, rep = K.cg_solve(job.F, 1e-30, max_its=5)
+    Uo, repo = oracle.cg(A, job.F, 1e-30, maxits=5)
+    assert rep["terminationtype"] == 5 and rep["iterations"] == 5
+    assert np.abs(U - Uo).max() <= 1e-9 * np.abs(Uo).max()
+    U, rep = K.cg_solve(job.F, 0.0, max_its=0)       # both zero -> eps_f = 1e-6
+    assert rep["terminationtype"] == 1 and rep["rel_residual"] <= 1e-6
+    U, rep = K.cg_solve(job.F, 1e-30)                 # unreachable: type 7, best point
+    assert rep["terminationtype"] == 7
+    Uo, _ = oracle.cg(A, job.F, 1e-12)
+    assert np.abs(U - Uo).max() <= U_TOL * np.abs(Uo).max()
+    U, rep = K.cg_solve(np.zeros_like(job.F), 1e-8)
+    assert rep["terminationtype"] == 1 and rep["iterations"] == 0 and not U.any()
+    K.free()
+
+
+def test_cg_not_spd_is_reported_not_raised(gpu_ctx):
+    # E < 0 makes K negative definite: ALGLIB reports -5 and STAN still returns U
+    job = problem.cube_job(3, E=-210000.0)
+    K = gpu_ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type,
+                              job.mat_E_nu, job.red)
+    U, rep = K.cg_solve(job.F, 1e-8)
+    assert rep["terminationtype"] == -5
+    K.free()
+
+
+def test_cg_mixed_precision(gpu_ctx, oracle):
+    from stan_amd import hip
+    job = problem.cube_job(10, jitter=0.05)
+    K, A = _assemble_both(gpu_ctx, oracle, job)
+    U, rep = K.cg_solve(job.F, 1e-8, precision_mode=hip.PREC_MIXED)
+    Uo, _ = oracle.cg(A, job.F, 1e-12)
+    # fp32 matrix entries: solution of a 6e-8-perturbed system
+    assert rep["terminationtype"] in (1, 7)
+    assert np.abs(U - Uo).max() <= 1e-4 * np.abs(Uo).max()
+    K.free()
+
+
+def test_cg_is_bit_reproducible(gpu_ctx):
+    job = problem.cube_job(8, jitter=0.1)
+    res = []
+    for _ in range(2):
+        K = gpu_ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type,
+                                  job.mat_E_nu, job.red)
+        res.append(K.cg_solve(job.F, 1e-10))
+        K.free()
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+
+
+def test_medium_cube_properties(gpu_ctx):
+    """40^3 (~207k DOF): too slow to cross-check entry by entry; size-independent properties."""
+    n = 40
+    job = problem.cube_job(n)
+    K = gpu_ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type,
+                              job.mat_E_nu, job.red)
+    info = K.info()
+    # SURVEY.md section 8 formula on the UNREDUCED block matrix: (3n+1)^3-ish blocks
+    assert info["n_block_rows"] == (n + 1) ** 3
+    assert info["n_blocks"] == (3 * n + 1) ** 3
+    rng = np.random.default_rng(1)
+    x, y = rng.standard_normal(job.n_red), rng.standard_normal(job.n_red)
+    Kx, Ky = K.spmv(x), K.spmv(y)
+    assert abs(y @ Kx - x @ Ky) <= 1e-10 * abs(y @ Kx)              # symmetry
+    assert np.abs(K.spmv(2 * x - 3 * y) - (2 * Kx - 3 * Ky)).max() <= 1e-10 * np.abs(Kx).max()
+    assert x @ Kx > 0                                                # positive definite
+    U, rep = K.cg_solve(job.F, 1e-10)
+    assert rep["terminationtype"] == 1
+    r = job.F - K.spmv(U)                                            # independent residual
+    assert np.linalg.norm(r) <= 1e-7 * np.linalg.norm(job.F)
+    # total reaction balances the applied load: sum of F_z = 50 * (n+1)^2
+    assert np.isclose(job.F.sum(), 50.0 * (n + 1) ** 2)
+    K.free()

@@ -1,0 +1,88 @@
+"""CPU tests of libstan_host.so (host steps around the hot path) against the oracle."""
+import numpy as np
+import pytest
+
+from stan_amd import host, problem
+from stan_amd.cube import cube_bcs, cube_mesh
+
+
+@pytest.mark.parametrize("n,jit", [(1, 0.0), (2, 0.0), (3, 0.1), (7, 0.0), (12, 0.1)])
+def test_assign_dof_matches_literal_restatement(oracle, built_libs, n, jit):
+    xyz, conn = cube_mesh(n, jitter=jit)
+    idx, dof = host.assign_dof(xyz.shape[0], conn)
+    rc, ref = oracle.assign_dof(xyz.shape[0], conn)
+    assert rc == 0 and np.array_equal(idx, ref)          # bit-exact (int)
+    assert sorted(idx.tolist()) == list(range(xyz.shape[0]))
+    assert np.array_equal(dof, np.stack([3 * idx, 3 * idx + 1, 3 * idx + 2], 1))
+
+
+def test_assign_dof_shuffled_elements_and_nodes(oracle, built_libs):
+    # wire order drives the numbering (Dictionary iteration order): shuffle both
+    rng = np.random.default_rng(5)
+    xyz, conn = cube_mesh(5)
+    perm = rng.permutation(xyz.shape[0])            # new position of each node
+    inv = np.argsort(perm)
+    conn2 = perm[conn][rng.permutation(conn.shape[0])].astype(np.int32)
+    idx, _ = host.assign_dof(xyz.shape[0], conn2)
+    rc, ref = oracle.assign_dof(xyz.shape[0], conn2)
+    assert rc == 0 and np.array_equal(idx, ref)
+    assert inv.shape == perm.shape
+
+
+def test_assign_dof_degenerate_and_errors(oracle, built_libs):
+    xyz, conn = cube_mesh(2)
+    conn = conn.copy()
+    conn[3, 7] = conn[3, 6]                           # an element listing a node twice
+    idx, _ = host.assign_dof(xyz.shape[0], conn)
+    rc, ref = oracle.assign_dof(xyz.shape[0], conn)
+    assert rc == 0 and np.array_equal(idx, ref)
+    with pytest.raises(host.StanHostError) as ei:      # two components
+        host.assign_dof(54, np.concatenate([cube_mesh(2)[1], cube_mesh(2)[1] + 27]))
+    assert ei.value.code == -21
+    with pytest.raises(host.StanHostError) as ei:      # no start node
+        host.assign_dof(4, np.zeros((0, 8), np.int32))
+    assert ei.value.code == -20
+    with pytest.raises(host.StanHostError) as ei:      # index out of range
+        host.assign_dof(8, np.full((1, 8), 9, np.int32))
+    assert ei.value.code == -2
+
+
+def test_reduction_and_load_vector(oracle, built_libs):
+    n = 3
+    xyz, conn = cube_mesh(n)
+    idx, dof = host.assign_dof(xyz.shape[0], conn)
+    spc, ld, f = cube_bcs(n)
+    vals = np.ones((spc.shape[0], 3))
+    vals[0] = [1, 0, 1]          # partially fixed node
+    vals[1] = [0.5, 2, 1]        # only exact 1 fixes (Solver.cs:110-112)
+    spc2 = np.concatenate([spc, spc[:3]])            # duplicates are Distinct()-ed
+    vals2 = np.concatenate([vals, vals[:3]])
+    red, nfix = host.dof_reduction(3 * xyz.shape[0], dof, spc2, vals2)
+    fixed = np.zeros(3 * xyz.shape[0], np.uint8)
+    for s, v in zip(spc, vals):
+        for d in range(3):
+            if v[d] == 1:
+                fixed[dof[s, d]] = 1
+    nfix_ref, red_ref = oracle.dof_reduction(fixed)
+    assert nfix == nfix_ref and np.array_equal(red, red_ref)
+    # loads: duplicates accumulate, loads on fixed DOFs are dropped (Solver.cs:144)
+    ln = np.concatenate([ld, ld[:2], spc[2:3]])
+    lv = np.tile(f, (ln.shape[0], 1))
+    F = host.load_vector(3 * xyz.shape[0], dof, red, nfix, ln, lv)
+    Fref = np.zeros(3 * xyz.shape[0] - nfix)
+    for nd, v in zip(ln, lv):
+        for d in range(3):
+            g = dof[nd, d]
+            if red[g] != -1:
+                Fref[g - red[g]] += v[d]
+    assert np.array_equal(F, Fref)
+    U = np.arange(F.shape[0], dtype=float) + 1
+    disp = host.nodal_displacements(dof, red, U)
+    assert np.array_equal(disp.ravel(), oracle.include_bc(red, U)[dof.ravel()])
+
+
+def test_cube_job_sizes(built_libs):
+    # SURVEY.md section 8 size table: N = nDOF - 3 (n+1)^2
+    for n in (4, 10):
+        j = problem.cube_job(n)
+        assert j.n_dof == 3 * (n + 1) ** 3 and j.n_fixed == 3 * (n + 1) ** 2
