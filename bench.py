@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path (HEX8 assembly + Jacobi-scaled CG to 1e-8) on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W           (N=1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one synthetic structured HEX8 cube:
+  stan_hip_assemble_hex8_dev (symbolic + numeric assembly of K)  +
+  stan_hip_cg_solve_dev      (diagonal scaling + CG until ||r|| <= 1e-8 ||b||)
+with the mesh arrays, DOF table and load vector already resident in HBM.  Workload:
+BASELINE.json's headline, the ~10 M-DOF cube (n = 148 -> 9 923 847 DOF).  N > 1 shards
+the block rows of the SAME cube over the ranks (strong scaling; halo exchange + all-reduce
+over RCCL inside the CG).
+
+Prints ONE JSON line (rank 0): metric DOF/s = nDOF * K / t, plus
+  roofline     achieved HBM GB/s of the dominant kernel (the BSELL-64 SpMV), from HIP events
+               around every SpMV launch of the timed solves, against 8 TB/s;
+  cpu_baseline the CPU oracle (a port of the reference algorithm) on a bounded sample.
+The merit-function stop of ALGLIB's lincg (termination type 7) is switched OFF here and in
+the CPU baseline: with it the reference algorithm gives up near 1e-7 on cubes of this size
+and would never reach the 1e-8 the metric names.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(n, eps):
+    """Oracle = port of the reference algorithm (parallel K_e, serial locked scatter into a
+    hash table, serial symmetric-upper CG), timed on this host's cores."""
+    from oracle import pyoracle as O
+    from stan_amd import problem
+    job = problem.cube_job(n)
+    threads = min(8, os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    rc, A = O.assemble(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type,
+                       job.mat_E_nu, job.red, n_threads=threads)
+    t1 = time.perf_counter()
+    U, rep = O.cg(A, job.F, eps, merit_stop=False)
+    t2 = time.perf_counter()
+    return {"value": job.n_dof / (t2 - t0), "unit": "DOF/s", "cores": threads, "kind": "port",
+            "sample": "%d^3 HEX8_G2 cube, %d DOF: assembly %.2f s (K_e on %d threads, serial "
+                      "scatter) + CG to %.0e %.2f s (%d its, serial)" %
+                      (n, job.n_dof, t1 - t0, threads, eps, t2 - t1, rep["iterations"])}, U, job
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=148, help="cube edge in elements (148 -> ~10 M DOF)")
+    ap.add_argument("--eps", type=float, default=1e-8)
+    ap.add_argument("--mixed", action="store_true", help="fp32 matrix / fp64 vectors")
+    ap.add_argument("--etype", type=int, default=2, help="2 = HEX8_G2, 1 = HEX8_G1")
+    ap.add_argument("--cpu-n", type=int, default=40, help="cube edge of the CPU-baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from stan_amd import hip, problem
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- synthetic job (host: mesh, Database.AssignDOF, BC tables; outside the timed region)
+    job = problem.cube_job(args.n, etype=args.etype)
+    ctx = hip.Context(local_rank)
+    if world > 1:
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid = torch.tensor(list(ctx.unique_id()), dtype=torch.uint8, device=dev)
+        dist.broadcast(uid, 0)
+        ctx.comm_init(rank, world, bytes(uid.cpu().tolist()))
+    ctx.set_option(hip.OPT_CG_MERIT_STOP, 0)
+    ctx.set_profiling(True)
+
+    # inputs resident in HBM before the timed region
+    d_xyz = torch.from_numpy(job.xyz).to(dev)
+    d_dof = torch.from_numpy(job.node_dof).to(dev)
+    d_conn = torch.from_numpy(job.conn).to(dev)
+    d_mat = torch.from_numpy(job.elem_mat).to(dev)
+    d_typ = torch.from_numpy(job.elem_type).to(dev)
+    d_red = torch.from_numpy(job.red).to(dev)
+    d_F = torch.from_numpy(job.F).to(dev)
+    d_U = torch.zeros(job.n_red, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    prec = hip.PREC_MIXED if args.mixed else hip.PREC_FP64
+
+    def step():
+        K = ctx.assemble_hex8_dev(job.xyz.shape[0], d_xyz.data_ptr(), d_dof.data_ptr(),
+                                  job.conn.shape[0], d_conn.data_ptr(), d_mat.data_ptr(),
+                                  d_typ.data_ptr(), job.mat_E_nu, job.n_dof, d_red.data_ptr())
+        rep = K.cg_solve_dev(d_F.data_ptr(), d_U.data_ptr(), args.eps, 0, prec)
+        prof = ctx.profile()
+        info = K.info()
+        K.free()
+        return rep, prof, info
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    spmv_ms = spmv_n = 0.0
+    asm_ms = cg_ms = 0.0
+    for _ in range(args.steps):
+        rep, prof, info = step()
+        spmv_ms += prof["spmv_ms_total"]
+        spmv_n += prof["spmv_launches"]
+        asm_ms += prof["assemble_ms"]
+        cg_ms += prof["cg_ms"]
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # sanity of the timed work (rank 0): converged to eps, true residual through an
+    # independent product is checked in tests; here the solver's own report
+    ok = rep["terminationtype"] == 1 and rep["rel_residual"] <= args.eps
+    out = None
+    if rank == 0:
+        avg_ms = spmv_ms / max(spmv_n, 1)
+        achieved = prof["spmv_bytes"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "DOF/s (assembly+CG to 1e-8) on 10M-DOF HEX8 cube; SpMV GB/s vs HBM peak",
+            "value": job.n_dof * args.steps / dt,
+            "unit": "DOF/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64" if not args.mixed else "f32 matrix / f64 vectors",
+            "data": "synthetic",
+            "config": {"workload": "%d^3 HEX8_G%d cube, %d DOF, clamp x=0, PointLoad (0,0,50) on "
+                                   "x=n; fp64 Jacobi-scaled CG to %.0e" %
+                                   (args.n, args.etype, job.n_dof, args.eps),
+                       "n_dof": job.n_dof, "n_reduced": job.n_red,
+                       "blocks_3x3_rank0": info["n_blocks"], "cg_iterations": rep["iterations"],
+                       "termination_type": rep["terminationtype"],
+                       "rel_residual": rep["rel_residual"], "converged": bool(ok),
+                       "assemble_ms": asm_ms / args.steps, "cg_ms": cg_ms / args.steps,
+                       "matrix_format": "BSELL-64 3x3 blocks (fp%s values + int32 block cols)" %
+                                        ("32" if args.mixed else "64"),
+                       "parallelism": "rows sharded x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_spmv (BSELL-64 SpMV + fused p.Ap)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": prof["spmv_bytes"], "avg_launch_ms": avg_ms,
+                         "launches": int(spmv_n)},
+        }
+        if not args.no_cpu and world == 1:
+            base, _, _ = cpu_baseline(args.cpu_n, args.eps)
+            out["cpu_baseline"] = base
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -68,6 +68,16 @@ int64_t stan_hip_last_bad_element(stan_ctx *ctx);
 /* Use an existing hipStream_t (e.g. torch's current stream) for all work; NULL = own stream. */
 int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
 
+/* Solver options (defaults reproduce alglib.lincg as the reference uses it).
+ *   STAN_OPT_CG_MERIT_STOP  1 (default): stop with type 7 when the merit function x'Ax-2b'x
+ *                           no longer decreases (rounding floor, ~1e-7 relative residual on
+ *                           large meshes); 0: iterate until eps_f / max_its only.
+ *   STAN_OPT_CG_RUPDATE     residual is recomputed as b-Ax every this many iterations
+ *                           (default 10 = ALGLIB's ItsBeforeRUpdate; 0 = never). */
+#define STAN_OPT_CG_MERIT_STOP 1
+#define STAN_OPT_CG_RUPDATE 2
+int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value);
+
 /* ---- multi-GPU (RCCL over xGMI) -------------------------------------------------------- */
 /* Rank 0 creates the 128-byte id, the host distributes it (torch.distributed broadcast,
  * MPI, a file ...), every rank calls comm_init. */

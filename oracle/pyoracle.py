@@ -148,14 +148,15 @@ def smv_upper(crs, x):
     return y
 
 
-def cg(crs, b, epsf, maxits=0):
+def cg(crs, b, epsf, maxits=0, merit_stop=True, rupdate=10):
     b = np.ascontiguousarray(b, dtype=np.float64)
     x = np.zeros(crs.n)
     term, its, nmv = C.c_int32(0), C.c_int32(0), C.c_int32(0)
     rel = C.c_double(0)
-    lib().stan_oracle_cg(C.byref(crs._raw), _p(b, C.c_double), C.c_double(epsf),
-                         C.c_int32(maxits), _p(x, C.c_double), C.byref(term), C.byref(its),
-                         C.byref(nmv), C.byref(rel))
+    lib().stan_oracle_cg_opt(C.byref(crs._raw), _p(b, C.c_double), C.c_double(epsf),
+                             C.c_int32(maxits), C.c_int(1 if merit_stop else 0), C.c_int(rupdate),
+                             _p(x, C.c_double), C.byref(term), C.byref(its), C.byref(nmv),
+                             C.byref(rel))
     return x, dict(terminationtype=term.value, iterations=its.value, nmv=nmv.value,
                    rel_residual=rel.value)
 

@@ -597,9 +597,18 @@ void stan_oracle_smv_upper(const stan_oracle_crs *A, const double *x, double *y)
 int stan_oracle_cg(const stan_oracle_crs *A, const double *b_in, double epsf, int32_t maxits,
                    double *x_out, int32_t *terminationtype, int32_t *iterations, int32_t *nmv_out,
                    double *rel_res) {
+    return stan_oracle_cg_opt(A, b_in, epsf, maxits, 1, 10, x_out, terminationtype, iterations,
+                              nmv_out, rel_res);
+}
+
+/* merit_stop = 0 / itsbeforerupdate != 10 are NOT ALGLIB defaults: they mirror the
+ * STAN_OPT_* switches of libstan_hip.so so that both sides can run the same variant. */
+int stan_oracle_cg_opt(const stan_oracle_crs *A, const double *b_in, double epsf, int32_t maxits,
+                       int merit_stop, int itsbeforerupdate, double *x_out,
+                       int32_t *terminationtype, int32_t *iterations, int32_t *nmv_out,
+                       double *rel_res) {
     int64_t n = A->n;
     const int itsbeforerestart = (int)(n > 0x7fffffff ? 0x7fffffff : n); /* lincgcreate */
-    const int itsbeforerupdate = 10;
     if (epsf == 0 && maxits == 0) epsf = 1.0e-6; /* lincgsetcond */
     size_t sz = sizeof(double) * (size_t)(n ? n : 1);
     double *s = malloc(sz), *b = malloc(sz), *rx = malloc(sz), *cx = malloc(sz), *r = malloc(sz),
@@ -689,7 +698,7 @@ int stan_oracle_cg(const stan_oracle_crs *A, const double *b_in, double epsf, in
             term = 5;
             break;
         }
-        if (merit >= prevmf) { /* no further progress: keep the previous (best) point */
+        if (merit_stop && merit >= prevmf) { /* no further progress: keep the previous (best) point */
             term = 7;
             for (int64_t i = 0; i < n; i++)
                 if (!isfinite(rx[i])) term = -4;

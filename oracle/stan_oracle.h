@@ -86,6 +86,12 @@ int stan_oracle_cg(const stan_oracle_crs *A, const double *b, double epsf, int32
                    double *x, int32_t *terminationtype, int32_t *iterations, int32_t *nmv,
                    double *rel_residual_scaled);
 
+/* Same with the two switches libstan_hip.so exposes as STAN_OPT_CG_MERIT_STOP / _RUPDATE
+ * (merit_stop=1, itsbeforerupdate=10 is ALGLIB's behaviour). */
+int stan_oracle_cg_opt(const stan_oracle_crs *A, const double *b, double epsf, int32_t maxits,
+                       int merit_stop, int itsbeforerupdate, double *x, int32_t *terminationtype,
+                       int32_t *iterations, int32_t *nmv, double *rel_residual_scaled);
+
 /* SolverFunctions.cs:520-538 Include_BC_DOF */
 void stan_oracle_include_bc(int64_t n_dof, const int32_t *red, const double *U, double *U_full);
 

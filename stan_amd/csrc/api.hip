@@ -73,6 +73,14 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream) {
     return STAN_OK;
 }
 
+int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
+    if (!ctx) return STAN_E_ARG;
+    if (option == STAN_OPT_CG_MERIT_STOP) ctx->cg_merit_stop = value != 0;
+    else if (option == STAN_OPT_CG_RUPDATE && value >= 0 && value < (1 << 30)) ctx->cg_rupdate = (int)value;
+    else { ctx->err = "set_option: unknown option or bad value"; return STAN_E_ARG; }
+    return STAN_OK;
+}
+
 int stan_hip_set_profiling(stan_ctx *ctx, int32_t enabled) {
     if (!ctx) return STAN_E_ARG;
     ctx->profiling = enabled != 0;

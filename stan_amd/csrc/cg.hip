@@ -27,7 +27,6 @@ namespace {
 constexpr int VEC_BLOCKS = 2048;  // grid of the streaming vector kernels (8 blocks per CU)
 constexpr int VEC_T = 256;
 constexpr int CHUNK = 32;         // iterations enqueued between two status polls
-constexpr int ITS_BEFORE_RUPDATE = 10;
 
 // device scalar slots (double)
 enum { S_BNORM = 0, S_VMV = 1, S_R2NEW = 2, S_MERIT = 3, S_RHO0 = 4, S_RHO1 = 5, S_PMF0 = 6,
@@ -280,7 +279,7 @@ k_refresh(int64_t n3, int64_t k, const int64_t *st, const double *bh, const doub
 // decisions of the iteration + p = r + beta p
 __global__ void __launch_bounds__(VEC_T)
 k_update(int64_t n3, int64_t k, double *sc, int64_t *st, double epsf, int64_t maxits,
-         int64_t its_before_restart, const double *r, double *p) {
+         int64_t its_before_restart, int merit_stop, const double *r, double *p) {
     if (st[T_ITER_A] < k || st[T_ITER_B] <= k) return;
     const double r2 = sc[S_R2NEW], merit = sc[S_MERIT];
     const double rho = sc[S_RHO0 + (k & 1)], prevmf = sc[S_PMF0 + (k & 1)];
@@ -289,7 +288,7 @@ k_update(int64_t n3, int64_t k, double *sc, int64_t *st, double epsf, int64_t ma
     int64_t xsel = k & 1;  // cx lives in buffer k&1
     if (sqrt(r2) <= epsf * bnorm) type = 1;
     else if (k >= maxits && maxits > 0) type = 5;
-    else if (merit >= prevmf) { type = 7; xsel = (k - 1) & 1; }
+    else if (merit_stop && merit >= prevmf) { type = 7; xsel = (k - 1) & 1; }
     double beta = 0;
     const bool restart = (k % its_before_restart) == 0;
     if (!type && !restart) {
@@ -528,7 +527,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             a.n3 = n3; a.k = k; a.sc = sc; a.st = stt;
             a.xcur = xb[(k - 1) & 1]; a.xnext = xb[k & 1];
             a.r = r; a.p = p; a.v = v; a.bh = bh; a.partial = partial;
-            a.refresh = (k % ITS_BEFORE_RUPDATE) == 0;
+            a.refresh = ctx->cg_rupdate > 0 && (k % ctx->cg_rupdate) == 0;
             hipLaunchKernelGGL(k_step, dim3(vg), dim3(VEC_T), 0, st_, a);
             if (a.refresh) {
                 if (ctx->nranks > 1) { rc = stan_comm_halo_exchange(ctx, K, xb[k & 1]); if (rc) break; }
@@ -540,7 +539,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st_, partial, (int)vg, 2, sc + S_R2NEW);
             if (ctx->nranks > 1) { rc = stan_comm_allreduce_sum_f64(ctx, sc + S_R2NEW, 2); if (rc) break; }
             hipLaunchKernelGGL(k_update, dim3(vg), dim3(VEC_T), 0, st_, n3, k, sc, stt, eps_f,
-                               (int64_t)max_its, its_before_restart, r, p);
+                               (int64_t)max_its, its_before_restart, ctx->cg_merit_stop ? 1 : 0, r, p);
         }
         if (rc) break;
         // poll: read the status of the PREVIOUS chunk while this one runs

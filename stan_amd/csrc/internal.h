@@ -55,6 +55,9 @@ struct stan_ctx {
     int rank = 0, nranks = 1;
     void *comm = nullptr;
     rccl_api nccl;
+    // solver options (include/stan_hip.h STAN_OPT_*)
+    bool cg_merit_stop = true;
+    int cg_rupdate = 10;
     // profiling
     bool profiling = false;
     stan_profile prof{};

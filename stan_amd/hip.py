@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libstan_hip.so")
 
 HEX8_G1, HEX8_G2 = 1, 2
 PREC_FP64, PREC_MIXED = 0, 1
+OPT_CG_MERIT_STOP, OPT_CG_RUPDATE = 1, 2
 E_HIP, E_ARG, E_ALLOC, E_DETJ, E_DOF_LAYOUT, E_VALENCE, E_COMM, E_UNSUPPORTED = (
     -1, -2, -3, -4, -5, -6, -7, -8)
 
@@ -26,7 +27,7 @@ EXPORTS = [
     "stan_hip_assemble_hex8", "stan_hip_assemble_hex8_dev", "stan_hip_matrix_free",
     "stan_hip_cg_solve", "stan_hip_cg_solve_dev", "stan_hip_matrix_info", "stan_hip_ke_hex8",
     "stan_hip_ke_hex8_batch", "stan_hip_matrix_to_csr", "stan_hip_spmv", "stan_hip_spmv_bench",
-    "stan_hip_set_profiling", "stan_hip_get_profile",
+    "stan_hip_set_profiling", "stan_hip_get_profile", "stan_hip_set_option",
 ]
 
 
@@ -115,6 +116,9 @@ class Context:
 
     def set_stream(self, stream_ptr):
         self._chk(self.lib.stan_hip_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def set_option(self, option, value):
+        self._chk(self.lib.stan_hip_set_option(self.h, C.c_int32(option), C.c_int64(value)))
 
     def set_profiling(self, on=True):
         self._chk(self.lib.stan_hip_set_profiling(self.h, C.c_int32(1 if on else 0)))
