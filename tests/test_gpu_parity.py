@@ -171,7 +171,7 @@ def test_cg_parity_with_oracle(gpu_ctx, oracle, n, etype):
         tol = U_TOL if eps == 1e-12 else 1e-3   # at loose eps both stop O(kappa*eps) from the solution
         assert np.abs(U - Uo).max() <= tol * np.abs(Uo).max()
         # same algorithm => iteration counts agree up to rounding-induced drift
-        assert abs(rep["iterations"] - repo["iterations"]) <= max(3, repo["iterations"] // 50)
+        assert abs(rep["iterations"] - repo["iterations"]) <= max(5, repo["iterations"] // 20)
     K.free()
 
 
