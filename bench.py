@@ -144,6 +144,14 @@ def main():
     out = None
     if rank == 0:
         avg_ms = spmv_ms / max(spmv_n, 1)
+        # HBM traffic per launch from the committed PMC passes (tools/pmc_run.sh), if one exists
+        # for this workload; counters cannot be collected from inside this process
+        traffic = None
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_spmv.json"))):
+            d = json.load(open(f))
+            if d.get("workload_n") == args.n and not args.mixed and world == 1:
+                traffic = d["traffic_bytes_per_launch"]
         achieved = prof["spmv_bytes"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
             "metric": "DOF/s (assembly+CG to 1e-8) on 10M-DOF HEX8 cube; SpMV GB/s vs HBM peak",
@@ -169,7 +177,7 @@ def main():
                        "parallelism": "rows sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "k_spmv (BSELL-64 SpMV + fused p.Ap)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch": prof["spmv_bytes"], "avg_launch_ms": avg_ms,
                          "launches": int(spmv_n)},
         }
