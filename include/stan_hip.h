@@ -123,6 +123,21 @@ int stan_hip_cg_solve_dev(stan_ctx *ctx, stan_matrix *K, const double *d_F, doub
                           int32_t max_its, int32_t precision_mode, double *d_U,
                           int32_t *termination_type, int32_t *iterations, double *rel_residual);
 
+/* ---- stress recovery: replaces Element.Recovery_Stress + Update_StrainStress ------------ */
+/* (Element.cs:211-246, 257-267, called from Solver.cs:184-210).  disp [n_nodes*3] = the
+ * nodal dU_buffer in NodeLib order (Solver.cs:171-178).  strain/stress [n_elem*48]: per
+ * element 8 nodes x {xx,yy,zz,xy,yz,xz} = the 8x6 MatrixST stored in Element.Strain[1] /
+ * Stress[1].  A HEX8_G1 element is STAN_E_UNSUPPORTED (the reference throws there). */
+int stan_hip_recover_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz, const double *disp,
+                          int64_t n_elem, const int32_t *conn, const int32_t *elem_mat,
+                          const uint8_t *elem_type, int32_t n_mat, const double *mat_E_nu,
+                          double *strain, double *stress);
+int stan_hip_recover_hex8_dev(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
+                              const double *d_disp, int64_t n_elem, const int32_t *d_conn,
+                              const int32_t *d_elem_mat, const uint8_t *d_elem_type,
+                              int32_t n_mat, const double *mat_E_nu, double *d_strain,
+                              double *d_stress);
+
 /* ---- introspection / parity helpers ------------------------------------------------------- */
 typedef struct stan_matrix_info {
     int64_t n_dof;        /* full DOF count                                      */

@@ -49,6 +49,64 @@ int stan_host_load_vector(int64_t n_dof, const int32_t *node_dof, const int32_t 
 int stan_host_nodal_displacements(int64_t n_nodes, const int32_t *node_dof, const int32_t *red,
                                   const double *U, double *disp_out);
 
+/* ---- STAN_Database object model + STdb codec (stan_amd/host/model.h) -----------------------
+ * stan_db wraps a Database (Database.cs:10-21).  Text comes back through
+ * stan_host_db_last_error.  Strings are UTF-8, NUL-terminated. */
+typedef struct stan_db stan_db;
+int stan_host_db_new(stan_db **out);
+void stan_host_db_free(stan_db *db);
+const char *stan_host_db_last_error(stan_db *db);
+
+/* ProtoDeserialize / ProtoSerialize (SolverFunctions.cs:48-63).  packed != 0 writes repeated
+ * scalars packed; the reader accepts both. */
+int stan_host_db_read_stdb(stan_db *db, const char *path);
+int stan_host_db_parse_stdb(stan_db *db, const uint8_t *data, int64_t size);
+int stan_host_db_write_stdb(stan_db *db, const char *path, int32_t packed);
+/* two-call: buf == NULL returns the size */
+int stan_host_db_serialize(stan_db *db, int32_t packed, uint8_t *buf, int64_t cap, int64_t *size);
+
+/* Database.ReadNastranMesh (Database.cs:39-111) + Set_nDOF (:135-138), what the GUI's
+ * Import does (MainWindow.xaml.cs:181-238).  *n_import_errors = lines that failed to parse. */
+int stan_host_db_read_bdf(stan_db *db, const char *path, int64_t *n_import_errors);
+/* Bulk mesh construction from arrays (IDs, not indices); Type of every element = hex_type. */
+int stan_host_db_set_mesh(stan_db *db, int64_t n_nodes, const int32_t *node_ids, const double *xyz,
+                          int64_t n_elem, const int32_t *elem_ids, const int32_t *elem_pids,
+                          const int32_t *nlist8, const char *hex_type);
+/* new Material(id) + SetElastic / Name (Material.cs:19-56) */
+int stan_host_db_add_material(stan_db *db, int32_t id, const char *name, double E, double nu);
+/* What the GUI's part box does before saving: MatID and FE type of every element of a
+ * part (Part.cs:658-673, 767-774) and the PartInfo record (MainWindow.xaml.cs:456-462). */
+int stan_host_db_assign_part(stan_db *db, int32_t pid, int32_t mat_id, const char *hex_type);
+/* new BoundaryCondition(name, type, id) + Add per node (BoundaryCondition.cs:29-37, 87-98):
+ * type "SPC" or "PointLoad"; vals [n*3]; unknown node IDs are ignored like the reference. */
+int stan_host_db_add_bc(stan_db *db, int32_t id, const char *name, const char *type, int64_t n,
+                        const int32_t *node_ids, const double *vals);
+int stan_host_db_set_analysis(stan_db *db, const char *type, const char *lin_solver, double tol,
+                              int32_t max_iter, int32_t inc_numb);
+
+/* sizes[0..7] = nodes, elements, materials, BCs, nDOF, Result_StepNo, import errors, 0 */
+int stan_host_db_sizes(stan_db *db, int64_t sizes[8]);
+/* analysis settings: type/lin_solver copied into caller buffers of cap bytes */
+int stan_host_db_get_analysis(stan_db *db, char *type, char *lin_solver, int32_t cap, double *tol,
+                              int32_t *max_iter, int32_t *result_step);
+int stan_host_db_assign_dof(stan_db *db); /* Database.AssignDOF, Solver.cs:46 */
+/* Flat arrays for stan_hip_assemble_hex8 (any pointer may be NULL to skip it):
+ * xyz[n*3], node_ids[n], node_dof[n*3], conn[e*8] (indices), elem_ids[e], elem_mat[e],
+ * elem_type[e], mat_E_nu[cap_mat*2]; *n_mat = materials used. */
+int stan_host_db_get_flat(stan_db *db, double *xyz, int32_t *node_ids, int32_t *node_dof,
+                          int32_t *conn, int32_t *elem_ids, int32_t *elem_mat,
+                          uint8_t *elem_type, double *mat_E_nu, int32_t cap_mat, int32_t *n_mat);
+/* Solver.cs:104-152 from the BCLib: red[nDOF], *n_fixed, F[nDOF - n_fixed] (F may be NULL
+ * on a first call that only asks for n_fixed). */
+int stan_host_db_get_reduction(stan_db *db, int32_t *red, int64_t *n_fixed, double *F);
+/* Result write-back of SolverLinearStatics (Solver.cs:81-90, 171-178, 203-210, Main :56):
+ * re-initialises step 0/1, stores disp[n*3] into Node.DispX/Y/Z[1] and strain/stress
+ * [e*48] (may be NULL) into Element.Strain[1]/Stress[1], sets Result_StepNo = 1. */
+int stan_host_db_set_results(stan_db *db, const double *disp, const double *strain,
+                             const double *stress);
+int stan_host_db_get_results(stan_db *db, int32_t inc, double *disp, double *strain,
+                             double *stress);
+
 #ifdef __cplusplus
 }
 #endif

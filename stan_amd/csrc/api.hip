@@ -172,6 +172,50 @@ int stan_hip_cg_solve(stan_ctx *ctx, stan_matrix *K, const double *F, double eps
     return STAN_OK;
 }
 
+int stan_hip_recover_hex8_dev(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
+                              const double *d_disp, int64_t n_elem, const int32_t *d_conn,
+                              const int32_t *d_elem_mat, const uint8_t *d_elem_type,
+                              int32_t n_mat, const double *mat_E_nu, double *d_strain,
+                              double *d_stress) {
+    if (!ctx || !d_xyz || !d_disp || !mat_E_nu || n_mat <= 0 ||
+        (n_elem > 0 && (!d_conn || !d_elem_mat || !d_elem_type || !d_strain || !d_stress)))
+        return STAN_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return stan_recover_device(ctx, n_nodes, d_xyz, d_disp, n_elem, d_conn, d_elem_mat, d_elem_type,
+                               n_mat, mat_E_nu, d_strain, d_stress);
+}
+
+int stan_hip_recover_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz, const double *disp,
+                          int64_t n_elem, const int32_t *conn, const int32_t *elem_mat,
+                          const uint8_t *elem_type, int32_t n_mat, const double *mat_E_nu,
+                          double *strain, double *stress) {
+    if (!ctx || !xyz || !disp || !mat_E_nu || n_nodes <= 0 || n_mat <= 0 || n_elem < 0 ||
+        (n_elem > 0 && (!conn || !elem_mat || !elem_type || !strain || !stress)))
+        return STAN_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (int64_t e = 0; e < n_elem; e++) {
+        if (elem_mat[e] < 0 || elem_mat[e] >= n_mat) { ctx->err = "recover_hex8: elem_mat out of range"; return STAN_E_ARG; }
+        for (int a = 0; a < 8; a++)
+            if (conn[e * 8 + a] < 0 || conn[e * 8 + a] >= n_nodes) { ctx->err = "recover_hex8: node index out of range"; return STAN_E_ARG; }
+    }
+    dbuf<double> dx, du, de, ds; dbuf<int32_t> dc, dm; dbuf<uint8_t> dt;
+    STANCHK(dx.upload(ctx, xyz, (size_t)n_nodes * 3));
+    STANCHK(du.upload(ctx, disp, (size_t)n_nodes * 3));
+    STANCHK(dc.upload(ctx, conn, (size_t)n_elem * 8));
+    STANCHK(dm.upload(ctx, elem_mat, (size_t)n_elem));
+    STANCHK(dt.upload(ctx, elem_type, (size_t)n_elem));
+    STANCHK(de.alloc(ctx, (size_t)n_elem * 48));
+    STANCHK(ds.alloc(ctx, (size_t)n_elem * 48));
+    STANCHK(stan_recover_device(ctx, n_nodes, dx.p, du.p, n_elem, dc.p, dm.p, dt.p, n_mat, mat_E_nu,
+                                de.p, ds.p));
+    if (n_elem) {
+        HIPCHK(ctx, hipMemcpyAsync(strain, de.p, (size_t)n_elem * 48 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(stress, ds.p, (size_t)n_elem * 48 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return STAN_OK;
+}
+
 int stan_hip_matrix_info(stan_matrix *K, stan_matrix_info *o) {
     if (!K || !o) return STAN_E_ARG;
     o->n_dof = K->n_dof; o->n_reduced = K->n_red; o->n_block_rows = K->nb_glob;

@@ -118,6 +118,12 @@ int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode
 int stan_matrix_make_fp32(stan_ctx *ctx, stan_matrix *K);
 int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K);
 
+// ---- recovery.hip ---------------------------------------------------------------------------
+int stan_recover_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz, const double *d_disp,
+                        int64_t n_elem, const int32_t *d_conn, const int32_t *d_elem_mat,
+                        const uint8_t *d_elem_type, int32_t n_mat, const double *mat_E_nu,
+                        double *d_strain, double *d_stress);
+
 // ---- comm.cpp -------------------------------------------------------------------------------
 int stan_comm_allreduce_sum_f64(stan_ctx *ctx, double *d_buf, size_t count);
 int stan_comm_allreduce_sum_i64(stan_ctx *ctx, int64_t *d_buf, size_t count);

@@ -89,3 +89,170 @@ def nodal_displacements(node_dof, red, U):
     if rc:
         raise StanHostError(rc, "nodal_displacements")
     return out
+
+
+# ---- STAN_Database mirror + STdb codec (stan_db part of include/stan_host.h) -----------------
+EXPORTS += [
+    "stan_host_db_new", "stan_host_db_free", "stan_host_db_last_error", "stan_host_db_read_stdb",
+    "stan_host_db_parse_stdb", "stan_host_db_write_stdb", "stan_host_db_serialize",
+    "stan_host_db_read_bdf", "stan_host_db_set_mesh", "stan_host_db_add_material",
+    "stan_host_db_assign_part", "stan_host_db_add_bc", "stan_host_db_set_analysis",
+    "stan_host_db_sizes", "stan_host_db_get_analysis", "stan_host_db_assign_dof",
+    "stan_host_db_get_flat", "stan_host_db_get_reduction", "stan_host_db_set_results",
+    "stan_host_db_get_results",
+]
+
+
+class Db:
+    """A Database (Database.cs:10-21) living in libstan_host.so."""
+
+    def __init__(self):
+        self.lib = load()
+        self.lib.stan_host_db_last_error.restype = C.c_char_p
+        self.lib.stan_host_db_free.restype = None
+        self.h = C.c_void_p()
+        rc = self.lib.stan_host_db_new(C.byref(self.h))
+        if rc:
+            raise StanHostError(rc, "db_new")
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.stan_host_db_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc:
+            msg = self.lib.stan_host_db_last_error(self.h)
+            e = StanHostError(rc, what + ": " + (msg.decode() if msg else ""))
+            raise e
+
+    # -- STdb ---------------------------------------------------------------------------------
+    @classmethod
+    def read_stdb(cls, path):
+        d = cls()
+        d._chk(d.lib.stan_host_db_read_stdb(d.h, os.fsencode(path)), "read_stdb")
+        return d
+
+    @classmethod
+    def parse_stdb(cls, data):
+        d = cls()
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        d._chk(d.lib.stan_host_db_parse_stdb(d.h, buf, C.c_int64(len(data))), "parse_stdb")
+        return d
+
+    def write_stdb(self, path, packed=False):
+        self._chk(self.lib.stan_host_db_write_stdb(self.h, os.fsencode(path), C.c_int32(int(packed))),
+                  "write_stdb")
+
+    def serialize(self, packed=False):
+        n = C.c_int64(0)
+        self._chk(self.lib.stan_host_db_serialize(self.h, C.c_int32(int(packed)), None, C.c_int64(0),
+                                                  C.byref(n)), "serialize")
+        buf = (C.c_uint8 * max(n.value, 1))()
+        self._chk(self.lib.stan_host_db_serialize(self.h, C.c_int32(int(packed)), buf,
+                                                  C.c_int64(n.value), C.byref(n)), "serialize")
+        return bytes(buf[:n.value])
+
+    # -- construction (what the GUI does before it launches the solver) -------------------------
+    def read_bdf(self, path):
+        nerr = C.c_int64(0)
+        self._chk(self.lib.stan_host_db_read_bdf(self.h, os.fsencode(path), C.byref(nerr)), "read_bdf")
+        return nerr.value
+
+    def set_mesh(self, node_ids, xyz, elem_ids, elem_pids, nlist8, hex_type="HEX8_G2"):
+        node_ids = np.ascontiguousarray(node_ids, dtype=np.int32)
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+        elem_ids = np.ascontiguousarray(elem_ids, dtype=np.int32)
+        elem_pids = np.ascontiguousarray(elem_pids, dtype=np.int32)
+        nlist8 = np.ascontiguousarray(nlist8, dtype=np.int32)
+        self._chk(self.lib.stan_host_db_set_mesh(
+            self.h, C.c_int64(node_ids.shape[0]), _p(node_ids, C.c_int32), _p(xyz, C.c_double),
+            C.c_int64(elem_ids.shape[0]), _p(elem_ids, C.c_int32), _p(elem_pids, C.c_int32),
+            _p(nlist8, C.c_int32), hex_type.encode()), "set_mesh")
+
+    def add_material(self, mid, name, E, nu):
+        self._chk(self.lib.stan_host_db_add_material(self.h, C.c_int32(mid), name.encode(),
+                                                     C.c_double(E), C.c_double(nu)), "add_material")
+
+    def assign_part(self, pid, mat_id, hex_type="HEX8_G2"):
+        self._chk(self.lib.stan_host_db_assign_part(self.h, C.c_int32(pid), C.c_int32(mat_id),
+                                                    hex_type.encode()), "assign_part")
+
+    def add_bc(self, bid, name, btype, node_ids, vals):
+        node_ids = np.ascontiguousarray(node_ids, dtype=np.int32)
+        vals = np.ascontiguousarray(vals, dtype=np.float64).reshape(-1, 3)
+        self._chk(self.lib.stan_host_db_add_bc(self.h, C.c_int32(bid), name.encode(), btype.encode(),
+                                               C.c_int64(node_ids.shape[0]), _p(node_ids, C.c_int32),
+                                               _p(vals, C.c_double)), "add_bc")
+
+    def set_analysis(self, atype="Linear_Statics", lin_solver="CG", tol=1e-6, max_iter=0, inc_numb=1):
+        self._chk(self.lib.stan_host_db_set_analysis(self.h, atype.encode(), lin_solver.encode(),
+                                                     C.c_double(tol), C.c_int32(max_iter),
+                                                     C.c_int32(inc_numb)), "set_analysis")
+
+    # -- queries ------------------------------------------------------------------------------
+    def sizes(self):
+        s = (C.c_int64 * 8)()
+        self._chk(self.lib.stan_host_db_sizes(self.h, s), "sizes")
+        return dict(nodes=s[0], elements=s[1], materials=s[2], bcs=s[3], nDOF=s[4],
+                    result_step=s[5], import_errors=s[6])
+
+    def analysis(self):
+        t = C.create_string_buffer(64)
+        ls = C.create_string_buffer(64)
+        tol, mi, rs = C.c_double(0), C.c_int32(0), C.c_int32(0)
+        self._chk(self.lib.stan_host_db_get_analysis(self.h, t, ls, C.c_int32(64), C.byref(tol),
+                                                     C.byref(mi), C.byref(rs)), "get_analysis")
+        return dict(type=t.value.decode(), lin_solver=ls.value.decode(), tol=tol.value,
+                    max_iter=mi.value, result_step=rs.value)
+
+    def assign_dof(self):
+        self._chk(self.lib.stan_host_db_assign_dof(self.h), "assign_dof")
+
+    def flat(self):
+        s = self.sizes()
+        n, e, nm = s["nodes"], s["elements"], max(s["materials"], 1)
+        out = dict(xyz=np.zeros((n, 3)), node_ids=np.zeros(n, np.int32),
+                   node_dof=np.zeros((n, 3), np.int32), conn=np.zeros((e, 8), np.int32),
+                   elem_ids=np.zeros(e, np.int32), elem_mat=np.zeros(e, np.int32),
+                   elem_type=np.zeros(e, np.uint8), mat_E_nu=np.zeros((nm, 2)))
+        nmat = C.c_int32(0)
+        self._chk(self.lib.stan_host_db_get_flat(
+            self.h, _p(out["xyz"], C.c_double), _p(out["node_ids"], C.c_int32),
+            _p(out["node_dof"], C.c_int32), _p(out["conn"], C.c_int32), _p(out["elem_ids"], C.c_int32),
+            _p(out["elem_mat"], C.c_int32), _p(out["elem_type"], C.c_uint8),
+            _p(out["mat_E_nu"], C.c_double), C.c_int32(nm), C.byref(nmat)), "get_flat")
+        out["mat_E_nu"] = out["mat_E_nu"][:nmat.value]
+        return out
+
+    def reduction(self):
+        ndof = self.sizes()["nDOF"]
+        red = np.zeros(ndof, np.int32)
+        F = np.zeros(max(ndof, 1))
+        nfix = C.c_int64(0)
+        self._chk(self.lib.stan_host_db_get_reduction(self.h, _p(red, C.c_int32), C.byref(nfix),
+                                                      _p(F, C.c_double)), "get_reduction")
+        return red, int(nfix.value), F[:ndof - nfix.value].copy()
+
+    def set_results(self, disp, strain=None, stress=None):
+        disp = np.ascontiguousarray(disp, dtype=np.float64)
+        if strain is not None:
+            strain = np.ascontiguousarray(strain, dtype=np.float64)
+            stress = np.ascontiguousarray(stress, dtype=np.float64)
+        self._chk(self.lib.stan_host_db_set_results(
+            self.h, _p(disp, C.c_double), None if strain is None else _p(strain, C.c_double),
+            None if stress is None else _p(stress, C.c_double)), "set_results")
+
+    def results(self, inc=1, with_stress=True):
+        s = self.sizes()
+        disp = np.zeros((s["nodes"], 3))
+        strain = np.zeros((s["elements"], 8, 6))
+        stress = np.zeros((s["elements"], 8, 6))
+        self._chk(self.lib.stan_host_db_get_results(
+            self.h, C.c_int32(inc), _p(disp, C.c_double),
+            _p(strain, C.c_double) if with_stress else None,
+            _p(stress, C.c_double) if with_stress else None), "get_results")
+        return disp, strain, stress

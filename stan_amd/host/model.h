@@ -1,0 +1,181 @@
+// model.h -- C++ mirror of the STAN_Database object model, as far as the linear-static
+// solver path touches it.  Same class and member names as
+// the C# DTOs so that the driver (main_solver.cpp) reads like Solver.cs.
+//
+//   Database          Database.cs:10-21      NodeLib / ElemLib / MatLib / BCLib / nDOF /
+//                                            AnalysisLib / Info  ([ProtoMember] 1..7)
+//   Node              Node.cs:9-23           ID, X, Y, Z, EList, DOF, DispX/Y/Z
+//   Element           Element.cs:11-23       ID, Type, PID, MatID, NList, Strain, Stress
+//   MatrixST          MatrixST.cs:15-19      M, Rows, Cols
+//   Material          Material.cs:7-14       ID, Type, Name, E, Poisson, ColorID
+//   BoundaryCondition BoundaryCondition.cs:8-14  Type, Name, ID, NodalValues, ColorID
+//   Analysis          Analysis.cs:6-13       Type, LinSolver, LinSolverTolerance, ...
+//   Information/PartInfo  Information.cs:7-40
+//
+// Dictionaries keep INSERTION order (= STdb wire order), because .NET's
+// Dictionary<int,T> enumerates in insertion order when nothing was removed and that
+// order drives AssignDOF and the element order.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+namespace stan {
+
+template <typename T>
+class OrderedDict {  // Dictionary<int, T> with insertion-order enumeration
+  public:
+    bool Add(int key, T value) {  // false when the key exists (Dictionary.Add would throw)
+        if (index_.count(key)) return false;
+        index_[key] = items_.size();
+        items_.emplace_back(key, std::move(value));
+        return true;
+    }
+    bool ContainsKey(int key) const { return index_.count(key) != 0; }
+    T *Find(int key) {
+        auto it = index_.find(key);
+        return it == index_.end() ? nullptr : &items_[it->second].second;
+    }
+    const T *Find(int key) const {
+        auto it = index_.find(key);
+        return it == index_.end() ? nullptr : &items_[it->second].second;
+    }
+    int64_t IndexOf(int key) const {
+        auto it = index_.find(key);
+        return it == index_.end() ? -1 : (int64_t)it->second;
+    }
+    size_t Count() const { return items_.size(); }
+    std::vector<std::pair<int, T>> &Items() { return items_; }
+    const std::vector<std::pair<int, T>> &Items() const { return items_; }
+    void Clear() { items_.clear(); index_.clear(); }
+
+  private:
+    std::vector<std::pair<int, T>> items_;
+    std::unordered_map<int, size_t> index_;
+};
+
+struct MatrixST {  // MatrixST.cs:15-26
+    std::vector<double> M;
+    int Rows = 0, Cols = 0;
+    MatrixST() {}
+    MatrixST(int rows, int cols) : M((size_t)rows * cols, 0.0), Rows(rows), Cols(cols) {}
+    double Get(int r, int c) const { return M[(size_t)r * Cols + c]; }
+    void Set(int r, int c, double v) { M[(size_t)r * Cols + c] = v; }
+};
+
+struct Node {  // Node.cs:9-23
+    int ID = 0;
+    double X = 0, Y = 0, Z = 0;
+    std::vector<int> EList;
+    std::vector<int> DOF;  // int[3]
+    std::vector<double> DispX, DispY, DispZ;
+    double dU_buffer[3] = {0, 0, 0};  // not serialized
+    // Node(string input): 8-character fixed-field GRID parser, Node.cs:25-80
+    static bool FromBdfLine(const std::string &input, Node *out);
+    void Initialize_StepZero();        // Node.cs:95-103
+    void Initialize_NewDisp(int inc);  // Node.cs:109-116
+    void Update_Displacement(int inc); // Node.cs:176-181
+    void SetDOF(int index) { DOF = {3 * index, 3 * index + 1, 3 * index + 2}; }  // :218-223
+};
+
+struct Element {  // Element.cs:11-23
+    int ID = 0;
+    std::string Type;
+    int PID = 0;
+    int MatID = 0;
+    std::vector<int> NList;
+    std::vector<MatrixST> Strain, Stress;
+    bool has_type = false;
+    // Element(string input): whitespace split, Element.cs:35-73
+    static bool FromBdfLine(const std::string &input, Element *out);
+    void Initialize_StepZero();         // Element.cs:79-87
+    void Initialize_Increment(int inc); // Element.cs:92-113
+};
+
+struct Material {  // Material.cs:7-29
+    int ID = 0;
+    std::string Type, Name;
+    bool has_type = false, has_name = false;
+    double E = 0, Poisson = 0;
+    int ColorID = 0;
+    static Material Create(int id) {  // Material(int id), Material.cs:19-29
+        Material m;
+        m.ID = id; m.Type = "Elastic"; m.has_type = true; m.ColorID = id % 9;
+        m.E = -999; m.Poisson = -999;
+        return m;
+    }
+};
+
+struct BoundaryCondition {  // BoundaryCondition.cs:8-37
+    std::string Type, Name;
+    bool has_type = false, has_name = false;
+    int ID = 0;
+    OrderedDict<MatrixST> NodalValues;  // node ID -> 3x1
+    int ColorID = 0;
+};
+
+struct Analysis {  // Analysis.cs:6-25
+    std::string Type = "Linear_Statics", LinSolver = "CG";
+    double LinSolverTolerance = 1.0e-6;
+    int LinSolverIterMax = 0, IncNumb = 0, Result_StepNo = 0;
+};
+
+struct PartInfo {  // Information.cs:33-63
+    int ColorID = 0, MatID = 0;
+    std::string Name = "blank", HEX_Type = "blank", PENTA_Type = "blank", TET_Type = "blank";
+};
+struct Information {  // Information.cs:7-30
+    OrderedDict<PartInfo> InfoPart;
+    bool has_parts = false;
+};
+
+struct Database {  // Database.cs:10-37
+    OrderedDict<Node> NodeLib;
+    OrderedDict<Element> ElemLib;
+    OrderedDict<Material> MatLib;
+    OrderedDict<BoundaryCondition> BCLib;
+    int nDOF = 0;
+    Analysis AnalysisLib;
+    bool has_analysis = true;
+    Information Info;
+    bool has_info = true;
+    std::vector<std::string> Import_Error;  // not serialized (Database.cs:18)
+
+    // Database.cs:39-111 (mesh only: Part objects are GUI-side and not serialized)
+    bool ReadNastranMesh(const std::string &path, std::string *err);
+    void Set_nDOF() { nDOF = (int)NodeLib.Count() * 3; }  // Database.cs:135-138
+    int AssignDOF();                                       // Database.cs:140-234 (0 / STAN_HOST_E_*)
+    std::string Database_Summary() const;                  // Database.cs:123-133
+};
+
+// ---- STdb (protobuf-net 3.0.73 wire format) --------------------------
+// packed=false writes repeated scalars unpacked (protobuf-net default without IsPacked);
+// the reader accepts both encodings and both orders of map key/value.
+bool ReadStdb(const std::string &path, Database *db, std::string *err);
+bool ParseStdb(const uint8_t *data, size_t size, Database *db, std::string *err);
+bool WriteStdb(const Database &db, const std::string &path, bool packed, std::string *err);
+void SerializeStdb(const Database &db, bool packed, std::string *out);
+
+// ---- flat views for the C-ABI of libstan_hip.so ----------------------------------------------
+struct FlatModel {
+    std::vector<double> xyz;       // [n_nodes*3] NodeLib order
+    std::vector<int32_t> node_dof; // [n_nodes*3]
+    std::vector<int32_t> conn;     // [n_elem*8] node indices
+    std::vector<int32_t> elem_mat; // [n_elem] index into mat_E_nu
+    std::vector<uint8_t> elem_type;
+    std::vector<double> mat_E_nu;  // [n_mat*2]
+};
+// Returns 0, or a negative code with *err: unknown node ID in an NList, MatID not in
+// MatLib (the C# throws KeyNotFound, Element.cs:147), material whose Type does not contain
+// "Elastic" (ElasticMatrix stays null, Solver.cs:33-39), unsupported element Type,
+// element without 8 nodes.
+int Flatten(const Database &db, FlatModel *out, std::string *err);
+
+// Solver.cs:104-152: Fix_DOF / nDOF_reduction / F.  Returns 0 or negative.
+int BuildReductionAndLoads(const Database &db, std::vector<int32_t> *red, int64_t *n_fixed,
+                           std::vector<double> *F, std::string *err);
+
+}  // namespace stan

@@ -1,0 +1,397 @@
+// stdb.cpp -- STdb reader/writer: the protobuf wire format protobuf-net 3.0.73 produces for
+// the [ProtoContract]/[ProtoMember] attributes of STAN_Database (schema reconstructed in
+// SURVEY.md Appendix A; the root object is a bare Database message, no length prefix:
+// SolverFunctions.cs:48-63).  protobuf-net is not vendored in the reference and no sample
+// .STdb exists in the checkout, so byte-level compatibility with the Windows GUI is
+// unverified; the contract tested here is: reader accepts packed and unpacked repeated
+// scalars and either order of map key/value, unknown fields are skipped, and
+// write(read(bytes)) == bytes for files this writer produced.
+//
+// Writer rules: fields in ascending number; scalar members equal to 0 / 0.0 / null are
+// omitted (implicit zero default); list elements are always written, zeros included;
+// empty lists are omitted; repeated scalars unpacked unless `packed`.
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+#include "model.h"
+
+namespace stan {
+namespace {
+
+// ---------------------------------------------------------------- writer
+struct W {
+    std::string &o;
+    bool packed;
+    void varint(uint64_t v) {
+        while (v >= 0x80) { o.push_back((char)(v | 0x80)); v >>= 7; }
+        o.push_back((char)v);
+    }
+    void tag(int field, int wt) { varint(((uint64_t)field << 3) | (uint64_t)wt); }
+    void i32(int field, int v) {  // implicit zero default
+        if (v == 0) return;
+        tag(field, 0);
+        varint((uint64_t)(int64_t)v);  // negatives: 10-byte two's complement
+    }
+    void f64raw(double v) {
+        uint64_t b;
+        memcpy(&b, &v, 8);
+        for (int i = 0; i < 8; i++) o.push_back((char)(b >> (8 * i)));
+    }
+    void f64(int field, double v) {
+        if (!(v != 0.0)) return;
+        tag(field, 1);
+        f64raw(v);
+    }
+    void str(int field, const std::string &s, bool present) {
+        if (!present) return;
+        tag(field, 2);
+        varint(s.size());
+        o += s;
+    }
+    void bytes(int field, const std::string &s) {
+        tag(field, 2);
+        varint(s.size());
+        o += s;
+    }
+    void rep_i32(int field, const std::vector<int> &v) {
+        if (v.empty()) return;
+        if (packed) {
+            std::string t;
+            W w{t, packed};
+            for (int x : v) w.varint((uint64_t)(int64_t)x);
+            bytes(field, t);
+        } else
+            for (int x : v) { tag(field, 0); varint((uint64_t)(int64_t)x); }
+    }
+    void rep_f64(int field, const std::vector<double> &v) {
+        if (v.empty()) return;
+        if (packed) {
+            tag(field, 2);
+            varint(v.size() * 8);
+            for (double x : v) f64raw(x);
+        } else
+            for (double x : v) { tag(field, 1); f64raw(x); }
+    }
+};
+
+void enc(const MatrixST &m, bool packed, std::string &o) {
+    W w{o, packed};
+    w.rep_f64(1, m.M);
+    w.i32(2, m.Rows);
+    w.i32(3, m.Cols);
+}
+void enc(const Node &n, bool packed, std::string &o) {
+    W w{o, packed};
+    w.i32(1, n.ID); w.f64(2, n.X); w.f64(3, n.Y); w.f64(4, n.Z);
+    w.rep_i32(5, n.EList); w.rep_i32(6, n.DOF);
+    w.rep_f64(7, n.DispX); w.rep_f64(8, n.DispY); w.rep_f64(9, n.DispZ);
+}
+void enc(const Element &e, bool packed, std::string &o) {
+    W w{o, packed};
+    w.i32(1, e.ID); w.str(2, e.Type, e.has_type); w.i32(3, e.PID); w.i32(4, e.MatID);
+    w.rep_i32(5, e.NList);
+    for (const MatrixST &m : e.Strain) { std::string t; enc(m, packed, t); w.bytes(6, t); }
+    for (const MatrixST &m : e.Stress) { std::string t; enc(m, packed, t); w.bytes(7, t); }
+}
+void enc(const Material &m, bool packed, std::string &o) {
+    W w{o, packed};
+    w.i32(1, m.ID); w.str(2, m.Type, m.has_type); w.str(3, m.Name, m.has_name);
+    w.f64(4, m.E); w.f64(5, m.Poisson); w.i32(6, m.ColorID);
+}
+void enc(const PartInfo &p, bool packed, std::string &o);
+void enc(const BoundaryCondition &b, bool packed, std::string &o);
+template <typename T>
+void enc_entry(int key, const T &v, bool packed, std::string &o) {  // map entry {1:key, 2:value}
+    W w{o, packed};
+    w.i32(1, key);
+    std::string t;
+    enc(v, packed, t);
+    w.bytes(2, t);
+}
+void enc(const BoundaryCondition &b, bool packed, std::string &o) {
+    W w{o, packed};
+    w.str(1, b.Type, b.has_type); w.str(2, b.Name, b.has_name); w.i32(3, b.ID);
+    for (const auto &kv : b.NodalValues.Items()) {
+        std::string t;
+        enc_entry(kv.first, kv.second, packed, t);
+        w.bytes(4, t);
+    }
+    w.i32(5, b.ColorID);
+}
+void enc(const Analysis &a, bool packed, std::string &o) {
+    W w{o, packed};
+    w.str(1, a.Type, true); w.str(2, a.LinSolver, true); w.f64(3, a.LinSolverTolerance);
+    w.i32(4, a.LinSolverIterMax); w.i32(5, a.IncNumb); w.i32(6, a.Result_StepNo);
+}
+void enc(const PartInfo &p, bool packed, std::string &o) {
+    W w{o, packed};
+    w.i32(1, p.ColorID); w.i32(2, p.MatID); w.str(3, p.Name, true); w.str(4, p.HEX_Type, true);
+    w.str(5, p.PENTA_Type, true); w.str(6, p.TET_Type, true);
+}
+void enc(const Information &i, bool packed, std::string &o) {
+    W w{o, packed};
+    for (const auto &kv : i.InfoPart.Items()) {
+        std::string t;
+        enc_entry(kv.first, kv.second, packed, t);
+        w.bytes(1, t);
+    }
+}
+
+// ---------------------------------------------------------------- reader
+struct R {
+    const uint8_t *p, *end;
+    bool ok = true;
+    bool more() const { return ok && p < end; }
+    uint64_t varint() {
+        uint64_t v = 0;
+        for (int s = 0; s < 70; s += 7) {
+            if (p >= end) { ok = false; return 0; }
+            const uint8_t b = *p++;
+            v |= (uint64_t)(b & 0x7f) << s;
+            if (!(b & 0x80)) return v;
+        }
+        ok = false;
+        return 0;
+    }
+    double f64() {
+        if (end - p < 8) { ok = false; return 0; }
+        uint64_t b = 0;
+        for (int i = 0; i < 8; i++) b |= (uint64_t)p[i] << (8 * i);
+        p += 8;
+        double d;
+        memcpy(&d, &b, 8);
+        return d;
+    }
+    R sub() {  // length-delimited payload
+        const uint64_t n = varint();
+        if (!ok || n > (uint64_t)(end - p)) { ok = false; return R{p, p, false}; }
+        R r{p, p + n, true};
+        p += n;
+        return r;
+    }
+    void skip(int wt) {
+        switch (wt) {
+            case 0: varint(); break;
+            case 1: if (end - p < 8) ok = false; else p += 8; break;
+            case 2: sub(); break;
+            case 5: if (end - p < 4) ok = false; else p += 4; break;
+            default: ok = false;
+        }
+    }
+    std::string str() {
+        R s = sub();
+        return s.ok ? std::string((const char *)s.p, (size_t)(s.end - s.p)) : std::string();
+    }
+    void rep_i32(int wt, std::vector<int> &v) {
+        if (wt == 0) v.push_back((int)(int64_t)varint());
+        else if (wt == 2) { R s = sub(); while (s.more()) v.push_back((int)(int64_t)s.varint()); ok &= s.ok; }
+        else skip(wt);
+    }
+    void rep_f64(int wt, std::vector<double> &v) {
+        if (wt == 1) v.push_back(f64());
+        else if (wt == 2) { R s = sub(); while (s.more()) v.push_back(s.f64()); ok &= s.ok; }
+        else skip(wt);
+    }
+};
+
+#define FIELDS(r)                                 \
+    while ((r).more()) {                          \
+        const uint64_t tg_ = (r).varint();        \
+        if (!(r).ok) break;                       \
+        const int f = (int)(tg_ >> 3), wt = (int)(tg_ & 7);
+#define END_FIELDS(r) }
+
+bool dec(R r, MatrixST &m) {
+    FIELDS(r)
+        if (f == 1) r.rep_f64(wt, m.M);
+        else if (f == 2 && wt == 0) m.Rows = (int)r.varint();
+        else if (f == 3 && wt == 0) m.Cols = (int)r.varint();
+        else r.skip(wt);
+    END_FIELDS(r)
+    return r.ok;
+}
+bool dec(R r, Node &n) {
+    FIELDS(r)
+        if (f == 1 && wt == 0) n.ID = (int)r.varint();
+        else if (f == 2 && wt == 1) n.X = r.f64();
+        else if (f == 3 && wt == 1) n.Y = r.f64();
+        else if (f == 4 && wt == 1) n.Z = r.f64();
+        else if (f == 5) r.rep_i32(wt, n.EList);
+        else if (f == 6) r.rep_i32(wt, n.DOF);
+        else if (f == 7) r.rep_f64(wt, n.DispX);
+        else if (f == 8) r.rep_f64(wt, n.DispY);
+        else if (f == 9) r.rep_f64(wt, n.DispZ);
+        else r.skip(wt);
+    END_FIELDS(r)
+    return r.ok;
+}
+bool dec(R r, Element &e) {
+    FIELDS(r)
+        if (f == 1 && wt == 0) e.ID = (int)r.varint();
+        else if (f == 2 && wt == 2) { e.Type = r.str(); e.has_type = true; }
+        else if (f == 3 && wt == 0) e.PID = (int)r.varint();
+        else if (f == 4 && wt == 0) e.MatID = (int)r.varint();
+        else if (f == 5) r.rep_i32(wt, e.NList);
+        else if (f == 6 && wt == 2) { e.Strain.emplace_back(); if (!dec(r.sub(), e.Strain.back())) r.ok = false; }
+        else if (f == 7 && wt == 2) { e.Stress.emplace_back(); if (!dec(r.sub(), e.Stress.back())) r.ok = false; }
+        else r.skip(wt);
+    END_FIELDS(r)
+    return r.ok;
+}
+bool dec(R r, Material &m) {
+    FIELDS(r)
+        if (f == 1 && wt == 0) m.ID = (int)r.varint();
+        else if (f == 2 && wt == 2) { m.Type = r.str(); m.has_type = true; }
+        else if (f == 3 && wt == 2) { m.Name = r.str(); m.has_name = true; }
+        else if (f == 4 && wt == 1) m.E = r.f64();
+        else if (f == 5 && wt == 1) m.Poisson = r.f64();
+        else if (f == 6 && wt == 0) m.ColorID = (int)r.varint();
+        else r.skip(wt);
+    END_FIELDS(r)
+    return r.ok;
+}
+template <typename T>
+bool dec_entry(R r, int &key, T &val) {  // key and value in either order
+    key = 0;
+    FIELDS(r)
+        if (f == 1 && wt == 0) key = (int)(int64_t)r.varint();
+        else if (f == 2 && wt == 2) { if (!dec(r.sub(), val)) r.ok = false; }
+        else r.skip(wt);
+    END_FIELDS(r)
+    return r.ok;
+}
+bool dec(R r, BoundaryCondition &b) {
+    FIELDS(r)
+        if (f == 1 && wt == 2) { b.Type = r.str(); b.has_type = true; }
+        else if (f == 2 && wt == 2) { b.Name = r.str(); b.has_name = true; }
+        else if (f == 3 && wt == 0) b.ID = (int)r.varint();
+        else if (f == 4 && wt == 2) {
+            int k; MatrixST m;
+            if (!dec_entry(r.sub(), k, m)) r.ok = false;
+            else b.NodalValues.Add(k, std::move(m));
+        }
+        else if (f == 5 && wt == 0) b.ColorID = (int)r.varint();
+        else r.skip(wt);
+    END_FIELDS(r)
+    return r.ok;
+}
+bool dec(R r, Analysis &a) {
+    // SkipConstructor = true: absent members are null / 0, not the constructor defaults
+    a = Analysis();
+    a.Type.clear(); a.LinSolver.clear(); a.LinSolverTolerance = 0;
+    FIELDS(r)
+        if (f == 1 && wt == 2) a.Type = r.str();
+        else if (f == 2 && wt == 2) a.LinSolver = r.str();
+        else if (f == 3 && wt == 1) a.LinSolverTolerance = r.f64();
+        else if (f == 4 && wt == 0) a.LinSolverIterMax = (int)r.varint();
+        else if (f == 5 && wt == 0) a.IncNumb = (int)r.varint();
+        else if (f == 6 && wt == 0) a.Result_StepNo = (int)r.varint();
+        else r.skip(wt);
+    END_FIELDS(r)
+    return r.ok;
+}
+bool dec(R r, PartInfo &p) {
+    FIELDS(r)
+        if (f == 1 && wt == 0) p.ColorID = (int)r.varint();
+        else if (f == 2 && wt == 0) p.MatID = (int)r.varint();
+        else if (f == 3 && wt == 2) p.Name = r.str();
+        else if (f == 4 && wt == 2) p.HEX_Type = r.str();
+        else if (f == 5 && wt == 2) p.PENTA_Type = r.str();
+        else if (f == 6 && wt == 2) p.TET_Type = r.str();
+        else r.skip(wt);
+    END_FIELDS(r)
+    return r.ok;
+}
+bool dec(R r, Information &i) {
+    FIELDS(r)
+        if (f == 1 && wt == 2) {
+            int k; PartInfo p;
+            if (!dec_entry(r.sub(), k, p)) r.ok = false;
+            else { i.InfoPart.Add(k, std::move(p)); i.has_parts = true; }
+        }
+        else r.skip(wt);
+    END_FIELDS(r)
+    return r.ok;
+}
+
+template <typename T>
+bool dec_lib(R &r, OrderedDict<T> &lib) {
+    int k; T v;
+    if (!dec_entry(r.sub(), k, v)) return false;
+    lib.Add(k, std::move(v));  // a repeated key keeps the first entry
+    return true;
+}
+
+}  // namespace
+
+void SerializeStdb(const Database &db, bool packed, std::string *out) {
+    std::string &o = *out;
+    W w{o, packed};
+    for (const auto &kv : db.NodeLib.Items()) { std::string t; enc_entry(kv.first, kv.second, packed, t); w.bytes(1, t); }
+    for (const auto &kv : db.ElemLib.Items()) { std::string t; enc_entry(kv.first, kv.second, packed, t); w.bytes(2, t); }
+    for (const auto &kv : db.MatLib.Items()) { std::string t; enc_entry(kv.first, kv.second, packed, t); w.bytes(3, t); }
+    for (const auto &kv : db.BCLib.Items()) { std::string t; enc_entry(kv.first, kv.second, packed, t); w.bytes(4, t); }
+    w.i32(5, db.nDOF);
+    if (db.has_analysis) { std::string t; enc(db.AnalysisLib, packed, t); w.bytes(6, t); }
+    if (db.has_info) { std::string t; enc(db.Info, packed, t); w.bytes(7, t); }
+}
+
+bool WriteStdb(const Database &db, const std::string &path, bool packed, std::string *err) {
+    // Solver.cs:454-462 ExportOutput: FileMode.Create, overwrite.  Entries are streamed one
+    // at a time, so the writer is not bound by protobuf-net's 2 GB MemoryStream.
+    FILE *fp = fopen(path.c_str(), "wb");
+    if (!fp) { if (err) *err = "cannot open " + path + " for writing"; return false; }
+    bool ok = true;
+    auto flush = [&](std::string &b) { ok &= fwrite(b.data(), 1, b.size(), fp) == b.size(); b.clear(); };
+    std::string buf;
+    W w{buf, packed};
+    auto lib = [&](int field, const auto &dict) {
+        for (const auto &kv : dict.Items()) {
+            std::string t;
+            enc_entry(kv.first, kv.second, packed, t);
+            w.bytes(field, t);
+            if (buf.size() > (1u << 20)) flush(buf);
+        }
+    };
+    lib(1, db.NodeLib); lib(2, db.ElemLib); lib(3, db.MatLib); lib(4, db.BCLib);
+    w.i32(5, db.nDOF);
+    if (db.has_analysis) { std::string t; enc(db.AnalysisLib, packed, t); w.bytes(6, t); }
+    if (db.has_info) { std::string t; enc(db.Info, packed, t); w.bytes(7, t); }
+    flush(buf);
+    ok &= fclose(fp) == 0;
+    if (!ok && err) *err = "short write to " + path;
+    return ok;
+}
+
+bool ParseStdb(const uint8_t *data, size_t size, Database *db, std::string *err) {
+    *db = Database();
+    db->has_analysis = false;  // SkipConstructor: members absent from the wire stay null
+    db->has_info = false;
+    R r{data, data + size, true};
+    FIELDS(r)
+        if (f == 1 && wt == 2) { if (!dec_lib(r, db->NodeLib)) r.ok = false; }
+        else if (f == 2 && wt == 2) { if (!dec_lib(r, db->ElemLib)) r.ok = false; }
+        else if (f == 3 && wt == 2) { if (!dec_lib(r, db->MatLib)) r.ok = false; }
+        else if (f == 4 && wt == 2) { if (!dec_lib(r, db->BCLib)) r.ok = false; }
+        else if (f == 5 && wt == 0) db->nDOF = (int)r.varint();
+        else if (f == 6 && wt == 2) { db->has_analysis = true; if (!dec(r.sub(), db->AnalysisLib)) r.ok = false; }
+        else if (f == 7 && wt == 2) { db->has_info = true; if (!dec(r.sub(), db->Info)) r.ok = false; }
+        else r.skip(wt);
+    END_FIELDS(r)
+    if (!r.ok && err) *err = "malformed STdb (protobuf wire error near byte " +
+                             std::to_string((size_t)(r.p - data)) + ")";
+    return r.ok;
+}
+
+bool ReadStdb(const std::string &path, Database *db, std::string *err) {
+    std::ifstream in(path, std::ios::binary | std::ios::ate);  // File.ReadAllBytes, Solver.cs:26
+    if (!in) { if (err) *err = "cannot open " + path; return false; }
+    const std::streamsize n = in.tellg();
+    in.seekg(0);
+    std::string buf((size_t)n, '\0');
+    if (n > 0 && !in.read(&buf[0], n)) { if (err) *err = "cannot read " + path; return false; }
+    return ParseStdb((const uint8_t *)buf.data(), buf.size(), db, err);
+}
+
+}  // namespace stan

@@ -249,3 +249,74 @@ def test_medium_cube_properties(gpu_ctx):
     # total reaction balances the applied load: sum of F_z = 50 * (n+1)^2
     assert np.isclose(job.F.sum(), 50.0 * (n + 1) ** 2)
     K.free()
+
+
+def test_stress_recovery_parity(gpu_ctx, oracle):
+    job = problem.cube_job(5, jitter=0.1)
+    job.elem_mat = (np.arange(job.conn.shape[0]) % 2).astype(np.int32)
+    job.mat_E_nu = np.array([[210000.0, 0.3], [70000.0, 0.33]])
+    rng = np.random.default_rng(4)
+    disp = rng.standard_normal(job.xyz.shape) * 1e-3
+    strain, stress = gpu_ctx.recover_hex8(job.xyz, disp, job.conn, job.elem_mat, job.elem_type,
+                                          job.mat_E_nu)
+    for e in range(job.conn.shape[0]):
+        E, nu = job.mat_E_nu[job.elem_mat[e]]
+        rc, eo, so = oracle.recover_hex8(job.xyz[job.conn[e]], E, nu, 2, disp[job.conn[e]].ravel())
+        assert rc == 0
+        assert np.abs(strain[e] - eo).max() <= 1e-12 * np.abs(eo).max()
+        assert np.abs(stress[e] - so).max() <= 1e-12 * np.abs(so).max()
+
+
+def test_stress_recovery_g1_is_an_error_like_the_reference(gpu_ctx):
+    from stan_amd import hip
+    job = problem.cube_job(2, etype=1)
+    with pytest.raises(hip.StanHipError) as ei:
+        gpu_ctx.recover_hex8(job.xyz, np.zeros_like(job.xyz), job.conn, job.elem_mat, job.elem_type,
+                             job.mat_E_nu)
+    assert ei.value.code == hip.E_UNSUPPORTED and gpu_ctx.last_bad_element() == 0
+
+
+def test_native_console_driver_end_to_end(built_libs, oracle, tmp_path):
+    """stan_solver <model.STdb>: the Solver.Main replacement over both C-ABI libraries."""
+    import subprocess
+    from stan_amd import bdf, host
+    from stan_amd.cube import cube_bcs, cube_mesh
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "stan_amd", "bin", "stan_solver")
+    n = 6
+    xyz, conn = cube_mesh(n, jitter=0.1)
+    bdf.write_bdf(str(tmp_path / "m.bdf"), xyz, conn)
+    d = host.Db()
+    assert d.read_bdf(str(tmp_path / "m.bdf")) == 0
+    d.add_material(1, "Steel", 210000.0, 0.3)
+    d.assign_part(1, 1, "HEX8_G2")
+    spc, ld, f = cube_bcs(n)
+    d.add_bc(1, "fix", "SPC", spc + 1, np.ones((len(spc), 3)))
+    d.add_bc(2, "load", "PointLoad", ld + 1, np.tile(f, (len(ld), 1)))
+    d.set_analysis(tol=1e-12)
+    path = str(tmp_path / "model.STdb")
+    d.write_stdb(path)
+    out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "NORMAL" in out.stdout and "Stress recovery" in out.stdout
+    r = host.Db.read_stdb(path)
+    assert r.sizes()["result_step"] == 1
+    disp, strain, stress = r.results(1)
+    # oracle on the model as the driver saw it (coordinates as parsed from the bdf)
+    m = host.Db.read_stdb(path); m.assign_dof()
+    fl = m.flat(); red, nfix, F = m.reduction()
+    rc, A = oracle.assemble(fl["xyz"], fl["node_dof"], fl["conn"], fl["elem_mat"], fl["elem_type"],
+                            fl["mat_E_nu"], red)
+    Uo, _ = oracle.cg(A, F, 1e-12)
+    do = host.nodal_displacements(fl["node_dof"], red, Uo)
+    assert np.abs(disp - do).max() <= U_TOL * np.abs(do).max()
+    for e in (0, 17, n ** 3 - 1):
+        rc, eo, so = oracle.recover_hex8(fl["xyz"][fl["conn"][e]], 210000.0, 0.3, 2, do[fl["conn"][e]].ravel())
+        assert np.abs(stress[e] - so).max() <= 1e-5 * np.abs(so).max()
+    # a G1 model fails in stress recovery like the reference and leaves the input untouched
+    d.assign_part(1, 1, "HEX8_G1")
+    d.write_stdb(path)
+    before = open(path, "rb").read()
+    out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "HEX8_G1" in out.stderr
+    assert open(path, "rb").read() == before
