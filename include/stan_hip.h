@@ -82,6 +82,9 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value);
 /* Rank 0 creates the 128-byte id, the host distributes it (torch.distributed broadcast,
  * MPI, a file ...), every rank calls comm_init. */
 int stan_hip_comm_unique_id(char id[128]);
+/* id == NULL makes a DETACHED rank: partition, assembly, plan export and local products
+ * work, anything that needs a collective returns STAN_E_COMM (used by the tests to check
+ * every rank's shard on one GPU).  nranks == 1 with an id creates a real 1-rank communicator. */
 int stan_hip_comm_init(stan_ctx *ctx, int rank, int nranks, const char id[128]);
 
 /* ---- assembly: replaces ParallelAssembly_K (SolverFunctions.cs:117-180) ----------------- */
@@ -168,6 +171,16 @@ int stan_hip_ke_hex8_batch(stan_ctx *ctx, int64_t n, const double *xyz8, double 
  * Single-rank contexts only. */
 int stan_hip_matrix_to_csr(stan_ctx *ctx, stan_matrix *K, int32_t upper_only, int64_t *nnz,
                            int64_t *rowptr, int32_t *col, double *val);
+
+/* The shard's halo plan as derived on the device (compare stan_host_partition_plan):
+ * row_starts [nranks+1]; halo_glob [n_halo]; nbr [<= nranks]; send_off/recv_off [n_nbr+1];
+ * send_rows [send_off[n_nbr]] local rows.  Array pointers may be NULL (sizes only). */
+int stan_hip_matrix_plan(stan_ctx *ctx, stan_matrix *K, int64_t *row_starts, int64_t *n_halo,
+                         int32_t *halo_glob, int32_t *n_nbr, int32_t *nbr, int64_t *send_off,
+                         int32_t *send_rows, int64_t *recv_off);
+/* y_owned [3*n_owned] = K_shard x_local, x_local [3*(n_owned + n_halo)] = owned rows then halo
+ * columns in plan order (host pointers; the UNSCALED matrix, i.e. before any solve). */
+int stan_hip_spmv_local(stan_ctx *ctx, stan_matrix *K, const double *x_local, double *y_owned);
 
 /* y = K x on the reduced system (host x,y of length N); single-rank contexts only. */
 int stan_hip_spmv(stan_ctx *ctx, stan_matrix *K, const double *x, double *y);

@@ -49,6 +49,19 @@ int stan_host_load_vector(int64_t n_dof, const int32_t *node_dof, const int32_t 
 int stan_host_nodal_displacements(int64_t n_nodes, const int32_t *node_dof, const int32_t *red,
                                   const double *U, double *disp_out);
 
+/* ---- row partition + halo plan of the sharded CG (no counterpart in the reference) -----------
+ * Block rows = nodes in reference DOF order.  row_starts [nranks+1]. */
+int stan_host_partition_rows(int64_t n_block_rows, int32_t nranks, int64_t *row_starts);
+/* Plan of `rank`: halo_glob [<= n_nodes] ascending global block rows it must receive;
+ * neighbours nbr_ranks [<= nranks] ascending; send_rows [<= n_nodes] LOCAL owned rows grouped by
+ * neighbour, send_off / recv_off [n_nbr+1] offsets into send_rows / halo_glob.  Output arrays
+ * other than row_starts, n_halo, n_nbr may be NULL (sizes only). */
+int stan_host_partition_plan(int64_t n_nodes, const int32_t *node_index, int64_t n_elem,
+                             const int32_t *conn, int32_t nranks, int32_t rank, int64_t *row_starts,
+                             int64_t *n_halo, int32_t *halo_glob, int32_t *n_nbr,
+                             int32_t *nbr_ranks, int64_t *send_off, int32_t *send_rows,
+                             int64_t *recv_off);
+
 /* ---- STAN_Database object model + STdb codec (stan_amd/host/model.h) -----------------------
  * stan_db wraps a Database (Database.cs:10-21).  Text comes back through
  * stan_host_db_last_error.  Strings are UTF-8, NUL-terminated. */

@@ -320,6 +320,40 @@ int stan_hip_spmv(stan_ctx *ctx, stan_matrix *K, const double *x, double *y) {
     return STAN_OK;
 }
 
+int stan_hip_matrix_plan(stan_ctx *ctx, stan_matrix *K, int64_t *row_starts, int64_t *n_halo,
+                         int32_t *halo_glob, int32_t *n_nbr, int32_t *nbr, int64_t *send_off,
+                         int32_t *send_rows, int64_t *recv_off) {
+    if (!ctx || !K || K->ctx != ctx) return STAN_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (row_starts) for (size_t i = 0; i < K->row_starts.size(); i++) row_starts[i] = K->row_starts[i];
+    if (n_halo) *n_halo = K->nhalo;
+    if (n_nbr) *n_nbr = (int32_t)K->nbr.size();
+    if (nbr) for (size_t i = 0; i < K->nbr.size(); i++) nbr[i] = K->nbr[i];
+    if (send_off) { send_off[0] = 0; for (size_t i = 0; i < K->send_off.size(); i++) send_off[i] = K->send_off[i]; }
+    if (recv_off) { recv_off[0] = 0; for (size_t i = 0; i < K->recv_off.size(); i++) recv_off[i] = K->recv_off[i]; }
+    if (halo_glob && K->nhalo)
+        HIPCHK(ctx, hipMemcpy(halo_glob, K->d_halo_glob, (size_t)K->nhalo * 4, hipMemcpyDeviceToHost));
+    if (send_rows && !K->send_off.empty() && K->send_off.back())
+        HIPCHK(ctx, hipMemcpy(send_rows, K->d_send_rows, (size_t)K->send_off.back() * 4, hipMemcpyDeviceToHost));
+    return STAN_OK;
+}
+
+int stan_hip_spmv_local(stan_ctx *ctx, stan_matrix *K, const double *x_local, double *y_owned) {
+    if (!ctx || !K || !x_local || !y_owned || K->ctx != ctx) return STAN_E_ARG;
+    if (K->scaled) { ctx->err = "spmv_local: matrix already carries the CG scaling"; return STAN_E_UNSUPPORTED; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int64_t npad = (int64_t)K->nslices * 64;
+    const int64_t ng = 3 * (npad > K->nloc + K->nhalo ? npad : K->nloc + K->nhalo);
+    dbuf<double> dx, dy;
+    STANCHK(dx.alloc(ctx, (size_t)ng));
+    STANCHK(dy.alloc(ctx, (size_t)(3 * npad + 3)));
+    HIPCHK(ctx, hipMemsetAsync(dx.p, 0, (size_t)ng * 8, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dx.p, x_local, (size_t)(3 * (K->nloc + K->nhalo)) * 8, hipMemcpyHostToDevice, ctx->stream));
+    STANCHK(stan_spmv_local(ctx, K, dx.p, dy.p));
+    if (K->nloc) HIPCHK(ctx, hipMemcpy(y_owned, dy.p, (size_t)(3 * K->nloc) * 8, hipMemcpyDeviceToHost));
+    return STAN_OK;
+}
+
 int stan_hip_spmv_bench(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode, int32_t reps,
                         double *avg_ms) {
     if (!ctx || !K || !avg_ms || reps <= 0 || K->ctx != ctx) return STAN_E_ARG;

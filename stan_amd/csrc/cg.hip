@@ -401,7 +401,7 @@ static int ensure_scaled(stan_ctx *ctx, stan_matrix *K) {
     if (K->nloc > 0)
         hipLaunchKernelGGL(k_diag_scale, dim3(nblk(K->nloc, 256)), dim3(256), 0, ctx->stream, K->nloc,
                            K->d_rowlen, K->d_slot_ptr, K->d_cols, K->d_vals, K->d_scale);
-    if (ctx->nranks > 1) STANCHK(stan_comm_halo_exchange(ctx, K, K->d_scale));
+    if (ctx->comm || ctx->nranks > 1) STANCHK(stan_comm_halo_exchange(ctx, K, K->d_scale));
     if (K->nslices > 0)
         hipLaunchKernelGGL(k_scale_matrix, dim3(nblk(K->nslices, 4)), dim3(256), 0, ctx->stream,
                            K->nslices, K->d_slot_ptr, K->d_cols, K->d_vals, K->d_scale, 0);
@@ -449,6 +449,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     STANCHK(ensure_scaled(ctx, K));
     const bool mixed = precision_mode == STAN_PREC_MIXED;
     if (mixed) STANCHK(stan_matrix_make_fp32(ctx, K));
+    const bool dist = ctx->comm != nullptr || ctx->nranks > 1;  // collectives in the loop
 
     const int64_t n3 = 3 * K->nloc;
     const int64_t npad = (int64_t)K->nslices * 64;
@@ -477,7 +478,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     hipLaunchKernelGGL(k_init, dim3(vg), dim3(VEC_T), 0, st_, n3, dof0, K->d_red, d_F, K->d_scale,
                        bh, xb[0], r, p, partial);
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st_, partial, (int)vg, 1, sc + S_VMV);
-    if (ctx->nranks > 1) STANCHK(stan_comm_allreduce_sum_f64(ctx, sc + S_VMV, 1));
+    if (dist) STANCHK(stan_comm_allreduce_sum_f64(ctx, sc + S_VMV, 1));
     hipLaunchKernelGGL(k_init_scalars, dim3(1), dim3(1), 0, st_, sc, stt, eps_f);
     HIPCHK(ctx, hipGetLastError());
 
@@ -518,11 +519,11 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     while (!done && rc == STAN_OK) {
         // enqueue one chunk of iterations
         for (int c = 0; c < CHUNK && k < hard_cap; c++, k++) {
-            if (ctx->nranks > 1) { rc = stan_comm_halo_exchange(ctx, K, p); if (rc) break; }
+            if (dist) { rc = stan_comm_halo_exchange(ctx, K, p); if (rc) break; }
             spmv(p, v, true, k);
             hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st_, partial, (int)spmv_blocks, 1,
                                sc + S_VMV);
-            if (ctx->nranks > 1) { rc = stan_comm_allreduce_sum_f64(ctx, sc + S_VMV, 1); if (rc) break; }
+            if (dist) { rc = stan_comm_allreduce_sum_f64(ctx, sc + S_VMV, 1); if (rc) break; }
             step_args a;
             a.n3 = n3; a.k = k; a.sc = sc; a.st = stt;
             a.xcur = xb[(k - 1) & 1]; a.xnext = xb[k & 1];
@@ -530,14 +531,14 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             a.refresh = ctx->cg_rupdate > 0 && (k % ctx->cg_rupdate) == 0;
             hipLaunchKernelGGL(k_step, dim3(vg), dim3(VEC_T), 0, st_, a);
             if (a.refresh) {
-                if (ctx->nranks > 1) { rc = stan_comm_halo_exchange(ctx, K, xb[k & 1]); if (rc) break; }
+                if (dist) { rc = stan_comm_halo_exchange(ctx, K, xb[k & 1]); if (rc) break; }
                 // a -5/-4 stop of this iteration is caught by k_refresh/k_update (ITER_B <= k)
                 spmv(xb[k & 1], v, false, k);
                 hipLaunchKernelGGL(k_refresh, dim3(vg), dim3(VEC_T), 0, st_, n3, k,
                                    (const int64_t *)stt, bh, v, xb[k & 1], r, partial);
             }
             hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st_, partial, (int)vg, 2, sc + S_R2NEW);
-            if (ctx->nranks > 1) { rc = stan_comm_allreduce_sum_f64(ctx, sc + S_R2NEW, 2); if (rc) break; }
+            if (dist) { rc = stan_comm_allreduce_sum_f64(ctx, sc + S_R2NEW, 2); if (rc) break; }
             hipLaunchKernelGGL(k_update, dim3(vg), dim3(VEC_T), 0, st_, n3, k, sc, stt, eps_f,
                                (int64_t)max_its, its_before_restart, ctx->cg_merit_stop ? 1 : 0, r, p);
         }
@@ -568,7 +569,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     const double *xfin = xb[h_st[T_XSEL] & 1];
 
     // U = S x^ on the free DOFs
-    if (ctx->nranks == 1) {
+    if (!dist) {
         hipLaunchKernelGGL(k_result, dim3(vg), dim3(VEC_T), 0, st_, n3, dof0, K->d_red, K->d_scale,
                            xfin, d_U);
     } else {
@@ -632,6 +633,19 @@ int stan_spmv_reduced(stan_ctx *ctx, stan_matrix *K, const double *d_x, double *
     hipLaunchKernelGGL(k_compress_div, dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, n3, K->d_red, sdiv, yf, d_y);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(st_));
+    return STAN_OK;
+}
+
+// y_owned = A_local x_local, x_local = [owned rows | halo columns] (plan checks; any rank)
+int stan_spmv_local(stan_ctx *ctx, stan_matrix *K, const double *d_x, double *d_y) {
+    dev_bufs bufs;
+    int64_t *stt;
+    STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
+    int64_t init[T_NSTAT] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0, 0, 0, 0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(stt, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    launch_spmv<double, false>(ctx, K, K->d_vals, d_x, d_y, nullptr, stt, 1);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return STAN_OK;
 }
 

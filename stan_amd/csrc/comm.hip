@@ -74,6 +74,13 @@ __global__ void k_pack(int64_t n, const int32_t *rows, const double *vec, double
     }
 }
 
+// no communicator: fine for a single rank, an error for a detached rank of several
+int no_comm(stan_ctx *ctx) {
+    if (ctx->nranks == 1) return STAN_OK;
+    ctx->err = "this context is a detached rank (comm_init without an id): no collectives";
+    return STAN_E_COMM;
+}
+
 }  // namespace
 
 extern "C" int stan_hip_comm_unique_id(char id[128]) {
@@ -91,7 +98,7 @@ extern "C" int stan_hip_comm_init(stan_ctx *ctx, int rank, int nranks, const cha
     }
     ctx->rank = rank;
     ctx->nranks = nranks;
-    if (nranks == 1) return STAN_OK;
+    if (!id) return STAN_OK;  // detached: partition/assembly only, no collectives (tests)
     if (nranks > 64) {
         ctx->err = "comm_init: at most 64 ranks";
         return STAN_E_ARG;
@@ -105,19 +112,20 @@ extern "C" int stan_hip_comm_init(stan_ctx *ctx, int rank, int nranks, const cha
 }
 
 int stan_comm_allreduce_sum_f64(stan_ctx *ctx, double *d_buf, size_t count) {
-    if (ctx->nranks == 1) return STAN_OK;
+    if (!ctx->comm) return no_comm(ctx);
     NCCLCHK(ctx, ctx->nccl.AllReduce(d_buf, d_buf, count, NCCL_F64, NCCL_SUM, ctx->comm, ctx->stream));
     return STAN_OK;
 }
 
 int stan_comm_allreduce_sum_i64(stan_ctx *ctx, int64_t *d_buf, size_t count) {
-    if (ctx->nranks == 1) return STAN_OK;
+    if (!ctx->comm) return no_comm(ctx);
     NCCLCHK(ctx, ctx->nccl.AllReduce(d_buf, d_buf, count, NCCL_INT64, NCCL_SUM, ctx->comm, ctx->stream));
     return STAN_OK;
 }
 
 int stan_comm_halo_exchange(stan_ctx *ctx, stan_matrix *K, double *d_vec) {
-    if (ctx->nranks == 1 || K->nbr.empty()) return STAN_OK;
+    if (!ctx->comm) return no_comm(ctx);
+    if (K->nbr.empty()) return STAN_OK;
     const int64_t stot = K->send_off.back();
     if (stot > 0) {
         int64_t b = (3 * stot + 255) / 256;
@@ -143,7 +151,7 @@ int stan_comm_halo_exchange(stan_ctx *ctx, stan_matrix *K, double *d_vec) {
 
 // every rank contributes its owned rows of a global block vector (3 doubles per block row)
 int stan_comm_allgather_rows(stan_ctx *ctx, stan_matrix *K, double *d_full) {
-    if (ctx->nranks == 1) return STAN_OK;
+    if (!ctx->comm) return no_comm(ctx);
     NCCLCHK(ctx, ctx->nccl.GroupStart());
     for (int r = 0; r < ctx->nranks; r++) {
         const int64_t a = K->row_starts[r], b = K->row_starts[r + 1];

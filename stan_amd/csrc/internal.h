@@ -115,6 +115,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
 int stan_spmv_reduced(stan_ctx *ctx, stan_matrix *K, const double *d_x, double *d_y);
 int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode, int32_t reps,
                            double *avg_ms);
+int stan_spmv_local(stan_ctx *ctx, stan_matrix *K, const double *d_x, double *d_y);
 int stan_matrix_make_fp32(stan_ctx *ctx, stan_matrix *K);
 int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K);
 

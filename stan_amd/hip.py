@@ -28,6 +28,7 @@ EXPORTS = [
     "stan_hip_cg_solve", "stan_hip_cg_solve_dev", "stan_hip_matrix_info", "stan_hip_ke_hex8",
     "stan_hip_ke_hex8_batch", "stan_hip_matrix_to_csr", "stan_hip_spmv", "stan_hip_spmv_bench",
     "stan_hip_set_profiling", "stan_hip_get_profile", "stan_hip_set_option", "stan_hip_recover_hex8", "stan_hip_recover_hex8_dev",
+    "stan_hip_matrix_plan", "stan_hip_spmv_local",
 ]
 
 
@@ -137,6 +138,10 @@ class Context:
         return bytes(buf.raw)
 
     def comm_init(self, rank, nranks, uid):
+        """uid=None: detached rank (no collectives) for shard/plan checks."""
+        if uid is None:
+            self._chk(self.lib.stan_hip_comm_init(self.h, C.c_int(rank), C.c_int(nranks), None))
+            return
         buf = C.create_string_buffer(bytes(uid), 128)
         self._chk(self.lib.stan_hip_comm_init(self.h, C.c_int(rank), C.c_int(nranks), buf))
 
@@ -268,6 +273,37 @@ class Matrix:
         y = np.zeros_like(x)
         self.ctx._chk(self.ctx.lib.stan_hip_spmv(self.ctx.h, self.k, _ptr(x, C.c_double),
                                                  _ptr(y, C.c_double)))
+        return y
+
+    def plan(self):
+        lib, h = self.ctx.lib, self.ctx.h
+        i = self.info()
+        nr = 64
+        row_starts = np.zeros(nr + 1, np.int64)
+        nh, nn = C.c_int64(0), C.c_int32(0)
+        self.ctx._chk(lib.stan_hip_matrix_plan(h, self.k, None, C.byref(nh), None, C.byref(nn),
+                                               None, None, None, None))
+        halo = np.zeros(max(nh.value, 1), np.int32)
+        nbr = np.zeros(max(nn.value, 1), np.int32)
+        send_off = np.zeros(nn.value + 1, np.int64)
+        recv_off = np.zeros(nn.value + 1, np.int64)
+        self.ctx._chk(lib.stan_hip_matrix_plan(h, self.k, _ptr(row_starts, C.c_int64), C.byref(nh),
+                                               _ptr(halo, C.c_int32), C.byref(nn), _ptr(nbr, C.c_int32),
+                                               _ptr(send_off, C.c_int64), None, _ptr(recv_off, C.c_int64)))
+        send_rows = np.zeros(max(int(send_off[-1]), 1), np.int32)
+        self.ctx._chk(lib.stan_hip_matrix_plan(h, self.k, None, C.byref(nh), None, C.byref(nn), None,
+                                               None, _ptr(send_rows, C.c_int32), None))
+        return dict(halo_glob=halo[:nh.value], nbr=nbr[:nn.value], send_off=send_off,
+                    recv_off=recv_off, send_rows=send_rows[:int(send_off[-1])],
+                    row_begin=i["row_begin"], row_end=i["row_end"], row_starts=row_starts)
+
+    def spmv_local(self, x_local):
+        i = self.info()
+        x_local = np.ascontiguousarray(x_local, dtype=np.float64)
+        assert x_local.shape[0] == 3 * (i["row_end"] - i["row_begin"] + i["n_halo"])
+        y = np.zeros(3 * (i["row_end"] - i["row_begin"]))
+        self.ctx._chk(self.ctx.lib.stan_hip_spmv_local(self.ctx.h, self.k, _ptr(x_local, C.c_double),
+                                                       _ptr(y, C.c_double)))
         return y
 
     def spmv_bench(self, reps=20, precision_mode=PREC_FP64):

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstan_host.so")
 
 EXPORTS = ["stan_host_assign_dof", "stan_host_dof_reduction", "stan_host_load_vector",
-           "stan_host_nodal_displacements"]
+           "stan_host_nodal_displacements", "stan_host_partition_rows", "stan_host_partition_plan"]
 
 _lib = None
 
@@ -89,6 +89,31 @@ def nodal_displacements(node_dof, red, U):
     if rc:
         raise StanHostError(rc, "nodal_displacements")
     return out
+
+
+def partition_plan(node_index, conn, nranks, rank):
+    """Row partition + halo plan of `rank` (stan_host_partition_plan) as a dict."""
+    node_index = np.ascontiguousarray(node_index, dtype=np.int32)
+    conn = np.ascontiguousarray(conn, dtype=np.int32).reshape(-1, 8)
+    n = node_index.shape[0]
+    row_starts = np.zeros(nranks + 1, np.int64)
+    halo = np.zeros(n, np.int32)
+    send_rows = np.zeros(n, np.int32)
+    nbr = np.zeros(nranks, np.int32)
+    send_off = np.zeros(nranks + 1, np.int64)
+    recv_off = np.zeros(nranks + 1, np.int64)
+    nh, nn = C.c_int64(0), C.c_int32(0)
+    rc = load().stan_host_partition_plan(
+        C.c_int64(n), _p(node_index, C.c_int32), C.c_int64(conn.shape[0]), _p(conn, C.c_int32),
+        C.c_int32(nranks), C.c_int32(rank), _p(row_starts, C.c_int64), C.byref(nh),
+        _p(halo, C.c_int32), C.byref(nn), _p(nbr, C.c_int32), _p(send_off, C.c_int64),
+        _p(send_rows, C.c_int32), _p(recv_off, C.c_int64))
+    if rc:
+        raise StanHostError(rc, "partition_plan")
+    k = nn.value
+    return dict(row_starts=row_starts, halo_glob=halo[:nh.value].copy(), nbr=nbr[:k].copy(),
+                send_off=send_off[:k + 1].copy(), recv_off=recv_off[:k + 1].copy(),
+                send_rows=send_rows[:send_off[k]].copy())
 
 
 # ---- STAN_Database mirror + STdb codec (stan_db part of include/stan_host.h) -----------------

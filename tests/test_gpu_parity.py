@@ -171,7 +171,9 @@ def test_cg_parity_with_oracle(gpu_ctx, oracle, n, etype):
         tol = U_TOL if eps == 1e-12 else 1e-3   # at loose eps both stop O(kappa*eps) from the solution
         assert np.abs(U - Uo).max() <= tol * np.abs(Uo).max()
         # same algorithm => iteration counts agree up to rounding-induced drift
-        assert abs(rep["iterations"] - repo["iterations"]) <= max(5, repo["iterations"] // 20)
+        # (a type-7 stop sits on the rounding floor, where the count is noise-dependent)
+        slack = 10 if rep["terminationtype"] == 1 else 4
+        assert abs(rep["iterations"] - repo["iterations"]) <= max(5, repo["iterations"] // slack)
     K.free()
 
 
@@ -320,3 +322,54 @@ def test_native_console_driver_end_to_end(built_libs, oracle, tmp_path):
     out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "HEX8_G1" in out.stderr
     assert open(path, "rb").read() == before
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+def test_shards_and_halo_plan_on_one_gpu(built_libs, nranks):
+    """Every rank's shard, assembled as a DETACHED rank on this GPU: the device-derived halo
+    plan equals the host plan (tests/test_distributed.py runs the sharded CG on it over gloo)
+    and shard x [owned | halo] reproduces the rows of the unsharded product bit for bit."""
+    import torch  # noqa: F401
+    from stan_amd import hip, host
+    job = problem.cube_job(11, jitter=0.1)
+    args = (job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+    ctx = hip.Context(0)
+    K1 = ctx.assemble_hex8(*args)
+    x = np.random.default_rng(2).standard_normal(job.n_dof)
+    y_ref = K1.spmv_local(x)
+    K1.free()
+    for r in range(nranks):
+        ctx.comm_init(r, nranks, None)
+        K = ctx.assemble_hex8(*args)
+        dev, ref = K.plan(), host.partition_plan(job.node_index, job.conn, nranks, r)
+        assert np.array_equal(dev["row_starts"][:nranks + 1], ref["row_starts"])
+        for k in ("halo_glob", "nbr", "send_off", "recv_off", "send_rows"):
+            assert np.array_equal(dev[k], ref[k]), k
+        r0, r1 = dev["row_begin"], dev["row_end"]
+        xb = x.reshape(-1, 3)
+        x_local = np.concatenate([xb[r0:r1], xb[dev["halo_glob"]]]).ravel()
+        assert np.array_equal(K.spmv_local(x_local), y_ref[3 * r0:3 * r1])
+        with pytest.raises(hip.StanHipError) as ei:      # a detached rank cannot run collectives
+            K.cg_solve(job.F, 1e-8)
+        assert ei.value.code == hip.E_COMM
+        K.free()
+    ctx.close()
+
+
+def test_single_rank_rccl_communicator(built_libs):
+    """The RCCL code path (dlopen, all-reduce, broadcast-gather) on a real 1-rank communicator
+    gives the same bits as the communicator-free path."""
+    import torch  # noqa: F401
+    from stan_amd import hip
+    job = problem.cube_job(8, jitter=0.1)
+    args = (job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+    res = []
+    for use_comm in (False, True):
+        ctx = hip.Context(0)
+        if use_comm:
+            ctx.comm_init(0, 1, ctx.unique_id())
+        K = ctx.assemble_hex8(*args)
+        res.append(K.cg_solve(job.F, 1e-10))
+        K.free()
+        ctx.close()
+    assert res[0][1] == res[1][1] and np.array_equal(res[0][0], res[1][0])
