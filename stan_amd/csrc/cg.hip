@@ -155,7 +155,18 @@ __global__ void k_init_scalars(double *sc, int64_t *st, double epsf) {
 // the value stream is a contiguous 512-B (fp64) / 256-B (fp32) wave access; x is gathered
 // (24 B per block, L2 / Infinity-Cache resident: neighbouring rows share columns).
 // DOT: also the per-block partial of x_own . y  (p.Ap of the CG).
-template <typename VT, bool DOT>
+// VAR selects tuning variants (STAN_OPT_SPMV_VARIANT, kept for A/B runs in one process):
+//   bit 0: non-temporal loads for the once-read matrix stream (keeps x in L2 / MALL)
+//   bit 1: XCD-contiguous slice mapping (blocks b, b+8, ... share an XCD: give each XCD a
+//          contiguous run of slices so that its L2 holds one window of x, not eight copies)
+//   bit 2: unroll the block loop by 4 instead of 2
+//   VAR 8: timing only -- reads the same bytes as 16-B (dwordx4) accesses; results are wrong
+template <typename T>
+__device__ __forceinline__ T ld_stream(const T *p, bool nt) {
+    return nt ? __builtin_nontemporal_load(p) : *p;
+}
+
+template <typename VT, bool DOT, int VAR>
 __global__ void __launch_bounds__(256)
 k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
        const int32_t *__restrict__ cols, const VT *__restrict__ vals,
@@ -163,26 +174,54 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
        const int64_t *st, int64_t kiter) {
     __shared__ double sh[4];
     if (stopped(st, kiter)) return;
+    constexpr bool NT = (VAR & 1) != 0 && VAR != 8;
+    constexpr bool XCD = (VAR & 2) != 0 && VAR != 8;
+    constexpr int UNR = ((VAR & 4) != 0 && VAR != 8) ? 4 : 2;
     const int lane = threadIdx.x & 63;
-    const int64_t slice = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int64_t bid = blockIdx.x;
+    if (XCD) {
+        const int64_t g = gridDim.x, cpx = g >> 3, rem = g & 7, xcd = bid & 7;
+        bid = xcd * cpx + (xcd < rem ? xcd : rem) + (bid >> 3);
+    }
+    const int64_t slice = bid * 4 + (threadIdx.x >> 6);
     double y0 = 0, y1 = 0, y2 = 0;
     const int64_t row = slice * 64 + lane;
     if (slice < nslices) {
         const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
         const int32_t *cp = cols + (int64_t)k0 * 64 + lane;
         const VT *vp = vals + (int64_t)k0 * 9 * 64 + lane;
-#pragma unroll 2
-        for (int32_t k = k0; k < k1; k++) {
-            const int64_t c = *cp;
-            const double a0 = (double)vp[0 * 64], a1 = (double)vp[1 * 64], a2 = (double)vp[2 * 64],
-                         a3 = (double)vp[3 * 64], a4 = (double)vp[4 * 64], a5 = (double)vp[5 * 64],
-                         a6 = (double)vp[6 * 64], a7 = (double)vp[7 * 64], a8 = (double)vp[8 * 64];
-            const double x0 = x[3 * c], x1 = x[3 * c + 1], x2 = x[3 * c + 2];
-            y0 += a0 * x0 + a1 * x1 + a2 * x2;
-            y1 += a3 * x0 + a4 * x1 + a5 * x2;
-            y2 += a6 * x0 + a7 * x1 + a8 * x2;
-            cp += 64;
-            vp += 9 * 64;
+        if (VAR == 8) {
+            typedef VT v2 __attribute__((ext_vector_type(2)));
+            const v2 *vq = (const v2 *)(vals + (int64_t)k0 * 9 * 64) + lane;
+            for (int32_t k = k0; k + 1 < k1; k += 2) {
+                const int64_t c = cp[0], c2 = cp[64];
+                double a[9], b[9];
+#pragma unroll
+                for (int j = 0; j < 9; j++) { const v2 t = vq[j * 64]; a[j] = (double)t.x; b[j] = (double)t.y; }
+                const double x0 = x[3 * c], x1 = x[3 * c + 1], x2 = x[3 * c + 2];
+                const double z0 = x[3 * c2], z1 = x[3 * c2 + 1], z2 = x[3 * c2 + 2];
+                y0 += a[0] * x0 + a[1] * x1 + a[2] * x2 + b[0] * z0 + b[1] * z1 + b[2] * z2;
+                y1 += a[3] * x0 + a[4] * x1 + a[5] * x2 + b[3] * z0 + b[4] * z1 + b[5] * z2;
+                y2 += a[6] * x0 + a[7] * x1 + a[8] * x2 + b[6] * z0 + b[7] * z1 + b[8] * z2;
+                cp += 128;
+                vq += 9 * 64;
+            }
+        } else {
+#pragma unroll UNR
+            for (int32_t k = k0; k < k1; k++) {
+                const int64_t c = ld_stream(cp, NT);
+                const double a0 = (double)ld_stream(vp + 0 * 64, NT), a1 = (double)ld_stream(vp + 1 * 64, NT),
+                             a2 = (double)ld_stream(vp + 2 * 64, NT), a3 = (double)ld_stream(vp + 3 * 64, NT),
+                             a4 = (double)ld_stream(vp + 4 * 64, NT), a5 = (double)ld_stream(vp + 5 * 64, NT),
+                             a6 = (double)ld_stream(vp + 6 * 64, NT), a7 = (double)ld_stream(vp + 7 * 64, NT),
+                             a8 = (double)ld_stream(vp + 8 * 64, NT);
+                const double x0 = x[3 * c], x1 = x[3 * c + 1], x2 = x[3 * c + 2];
+                y0 += a0 * x0 + a1 * x1 + a2 * x2;
+                y1 += a3 * x0 + a4 * x1 + a5 * x2;
+                y2 += a6 * x0 + a7 * x1 + a8 * x2;
+                cp += 64;
+                vp += 9 * 64;
+            }
         }
         if (row < nloc) {
             y[3 * row] = y0; y[3 * row + 1] = y1; y[3 * row + 2] = y2;
@@ -385,8 +424,18 @@ void launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double *x,
                  double *partial, const int64_t *st, int64_t k) {
     const unsigned grid = nblk(K->nslices, 4);
     if (grid == 0) return;
-    hipLaunchKernelGGL((k_spmv<VT, DOT>), dim3(grid), dim3(256), 0, ctx->stream, K->nslices,
-                       K->nloc, K->d_slot_ptr, K->d_cols, vals, x, y, partial, st, k);
+#define SPMV_CASE(V)                                                                              \
+    case V:                                                                                       \
+        hipLaunchKernelGGL((k_spmv<VT, DOT, V>), dim3(grid), dim3(256), 0, ctx->stream, K->nslices, \
+                           K->nloc, K->d_slot_ptr, K->d_cols, vals, x, y, partial, st, k);         \
+        break;
+    switch (ctx->spmv_variant) {
+        SPMV_CASE(1) SPMV_CASE(2) SPMV_CASE(3) SPMV_CASE(4) SPMV_CASE(5) SPMV_CASE(6) SPMV_CASE(7)
+        SPMV_CASE(8)
+        default:
+        SPMV_CASE(0)
+    }
+#undef SPMV_CASE
 }
 
 }  // namespace
