@@ -242,7 +242,11 @@ struct numeric_args {
     int32_t wmax;         // LDS accumulators are sized for this slice width
 };
 
-__global__ void __launch_bounds__(256) k_numeric(numeric_args A) {
+// two waves per SIMD (<= 128 VGPRs): measured 23.6 ms vs 39.7 ms at 148^3 (tools/asm_lab.sh)
+#ifndef STAN_NUM_WAVES
+#define STAN_NUM_WAVES 2
+#endif
+__global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A) {
     extern __shared__ double lds[];
     // carve-up (all 8-byte aligned):
     //   acc   [16][wmax][9]   double
@@ -277,30 +281,81 @@ __global__ void __launch_bounds__(256) k_numeric(numeric_args A) {
     double *gpw = gps + w * (8 * 8 * 10);
     const int s = lane >> 3, b = lane & 7;
 
+    // The incidence -> connectivity -> coordinates chain is three dependent global loads.
+    // Issue it for the wave's four rows up front so that the latencies overlap instead of
+    // being paid row by row (first 8 incidences of each row; longer rows load inline).
+    int64_t P0[4];
+    int DEG[4], RL[4];
+    int32_t EN[4], NB[4], COLG[4], TY[4], MI[4];
+    double X0[4], X1[4], X2[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int64_t row = row_base + w * 4 + i;
+        P0[i] = 0; DEG[i] = 0; RL[i] = 0;
+        if (row < A.nloc) {
+            P0[i] = A.ptr[row];
+            DEG[i] = (int)(A.ptr[row + 1] - P0[i]);
+            RL[i] = A.rowlen[row];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) EN[i] = s < DEG[i] ? A.list[P0[i] + s] : 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int32_t e = EN[i] >> 3;
+        NB[i] = 0; TY[i] = STAN_HEX8_G2; MI[i] = 0;
+        if (s < DEG[i]) {
+            NB[i] = A.conn[(int64_t)e * 8 + b];
+            TY[i] = A.elem_type[e];
+            MI[i] = A.elem_mat[e];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        COLG[i] = 0; X0[i] = X1[i] = X2[i] = 0.0;
+        if (s < DEG[i]) {
+            COLG[i] = A.perm[NB[i]];
+            X0[i] = A.xyz[3 * (int64_t)NB[i] + 0];
+            X1[i] = A.xyz[3 * (int64_t)NB[i] + 1];
+            X2[i] = A.xyz[3 * (int64_t)NB[i] + 2];
+        }
+    }
+
+#pragma unroll
     for (int i = 0; i < 4; i++) {
         const int r16 = w * 4 + i;
         const int64_t row = row_base + r16;
         if (row >= A.nloc) continue;  // wave-uniform
-        const int64_t p0 = A.ptr[row];
-        const int deg = (int)(A.ptr[row + 1] - p0);
-        const int rl = A.rowlen[row];
+        const int64_t p0 = P0[i];
+        const int deg = DEG[i];
+        const int rl = RL[i];
         for (int c0 = 0; c0 < deg; c0 += 8) {
             const bool valid = c0 + s < deg;
             int32_t e = 0, a = 0, type = STAN_HEX8_G2, colg = 0;
             double lam = 0, G = 0;
             if (valid) {
-                const int32_t en = A.list[p0 + c0 + s];
+                int32_t en, nb, m;
+                double x0, x1, x2;
+                if (c0 == 0) {
+                    en = EN[i]; nb = NB[i]; colg = COLG[i]; type = TY[i]; m = MI[i];
+                    x0 = X0[i]; x1 = X1[i]; x2 = X2[i];
+                } else {
+                    en = A.list[p0 + c0 + s];
+                    nb = A.conn[(int64_t)(en >> 3) * 8 + b];
+                    colg = A.perm[nb];
+                    type = A.elem_type[en >> 3];
+                    m = A.elem_mat[en >> 3];
+                    x0 = A.xyz[3 * (int64_t)nb + 0];
+                    x1 = A.xyz[3 * (int64_t)nb + 1];
+                    x2 = A.xyz[3 * (int64_t)nb + 2];
+                }
                 e = en >> 3;
                 a = en & 7;
-                const int32_t nb = A.conn[(int64_t)e * 8 + b];
-                colg = A.perm[nb];
-                type = A.elem_type[e];
-                const int32_t m = A.elem_mat[e];
                 lam = A.mat_lamG[2 * m];
                 G = A.mat_lamG[2 * m + 1];
-                xsw[(s * 8 + b) * 3 + 0] = A.xyz[3 * (int64_t)nb + 0];
-                xsw[(s * 8 + b) * 3 + 1] = A.xyz[3 * (int64_t)nb + 1];
-                xsw[(s * 8 + b) * 3 + 2] = A.xyz[3 * (int64_t)nb + 2];
+                xsw[(s * 8 + b) * 3 + 0] = x0;
+                xsw[(s * 8 + b) * 3 + 1] = x1;
+                xsw[(s * 8 + b) * 3 + 2] = x2;
             }
             // (all LDS traffic below is private to this wavefront: program order suffices,
             //  the fences only stop the compiler from reordering across the hand-off)
@@ -345,17 +400,53 @@ __global__ void __launch_bounds__(256) k_numeric(numeric_args A) {
                 }
             }
             const bool anydup = __ballot(isdup) != 0ull;
-            volatile double *ar = acc + r16 * W * 9;
-            for (int s2 = 0; s2 < 8; s2++) {
-                if (s == s2 && pos >= 0 && !isdup) {
+            if (!anydup && W <= 48) {
+                // Gather form: every lane stages its block, a map says which lane of incidence
+                // s2 feeds slot k, then lane k sums its slot over s2 = 0..7 in registers
+                // (ascending element index => fixed order) with independent, pipelined LDS
+                // reads -- instead of eight dependent read-modify-write rounds.
+                // stage aliases the Gauss-point scratch (dead after phase B), map the coordinates.
+                double *stage = gpw;             // [64 lanes][9]
+                int32_t *map = (int32_t *)xsw;   // [8 incidences][W slots] -> lane or -1
+                for (int t = lane; t < 8 * W; t += 64) map[t] = -1;
 #pragma unroll
-                    for (int j = 0; j < 9; j++) ar[pos * 9 + j] = ar[pos * 9 + j] + kb[j];
+                for (int j = 0; j < 9; j++) stage[lane * 9 + j] = kb[j];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (pos >= 0) map[s * W + pos] = lane;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int k = lane; k < rl; k += 64) {
+                    double t9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int s2 = 0; s2 < 8; s2++) {
+                        const int32_t l = map[s2 * W + k];
+                        if (l >= 0) {
+#pragma unroll
+                            for (int j = 0; j < 9; j++) t9[j] += stage[l * 9 + j];
+                        }
+                    }
+                    double *ak = acc + (r16 * W + k) * 9;
+#pragma unroll
+                    for (int j = 0; j < 9; j++) ak[j] += t9[j];
                 }
-                if (anydup) {  // degenerate element listing one node twice: serialise
-                    for (int b2 = 1; b2 < 8; b2++) {
-                        if (s == s2 && b == b2 && pos >= 0 && isdup) {
+            } else {
+                // rows wider than the map, or a degenerate element listing one node twice:
+                // ordered read-modify-write, incidence by incidence
+                volatile double *ar = acc + r16 * W * 9;
+                for (int s2 = 0; s2 < 8; s2++) {
+                    if (s == s2 && pos >= 0 && !isdup) {
 #pragma unroll
-                            for (int j = 0; j < 9; j++) ar[pos * 9 + j] = ar[pos * 9 + j] + kb[j];
+                        for (int j = 0; j < 9; j++) ar[pos * 9 + j] = ar[pos * 9 + j] + kb[j];
+                    }
+                    if (anydup) {
+                        for (int b2 = 1; b2 < 8; b2++) {
+                            if (s == s2 && b == b2 && pos >= 0 && isdup) {
+#pragma unroll
+                                for (int j = 0; j < 9; j++) ar[pos * 9 + j] = ar[pos * 9 + j] + kb[j];
+                            }
                         }
                     }
                 }

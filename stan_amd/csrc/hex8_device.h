@@ -90,12 +90,15 @@ __device__ __forceinline__ void hex8_grad(const double *inv, int i, double px, d
 
 // Accumulate the (a,b) 3x3 block of K_e over the element's Gauss points.
 // gp: per Gauss point 10 doubles {J^-1, c} with stride `gstride` doubles between points.
+#ifndef STAN_GP_UNROLL
+#define STAN_GP_UNROLL 2  // 231 VGPRs, no spill at 2 waves/SIMD (full unroll spills)
+#endif
 __device__ __forceinline__ void hex8_block_ab(const double *gp, int gstride, int type, int a,
                                               int b, double lam, double G, double k[9]) {
     const double gl = hex8_gauss_loc(type);
 #pragma unroll
     for (int j = 0; j < 9; j++) k[j] = 0.0;
-#pragma unroll
+#pragma unroll STAN_GP_UNROLL
     for (int g = 0; g < 8; g++) {
         const double *q = gp + g * gstride;
         const double c = q[9];

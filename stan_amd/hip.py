@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libstan_hip.so")
+LIB_PATH = os.environ.get("STAN_HIP_LIB") or os.path.join(_HERE, "lib", "libstan_hip.so")
 
 HEX8_G1, HEX8_G2 = 1, 2
 PREC_FP64, PREC_MIXED = 0, 1
