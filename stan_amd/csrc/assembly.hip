@@ -104,6 +104,21 @@ __device__ inline void lds_bitonic_sort(int32_t *a, int P) {
     }
 }
 
+// bitonic sort of one value per lane across the 64-lane wavefront, in registers
+__device__ inline int32_t wave_bitonic_sort(int32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int32_t o = __shfl_xor(v, j, 64);
+            const bool keepmin = ((lane & j) == 0) == ((lane & k) == 0);
+            v = keepmin ? min(v, o) : max(v, o);
+        }
+    }
+    return v;
+}
+
 // ---- step 2: symbolic.  One 64-lane workgroup per owned block row. --------------------------
 // FILL=false: sort the row's incidence list in place, count distinct neighbour block rows,
 //             flag referenced non-owned block rows (halo discovery).
@@ -135,12 +150,15 @@ k_symbolic(int64_t nloc, int64_t r0, int64_t r1, const int64_t *ptr, int32_t *li
         deg = STAN_MAX_INCIDENT;
     }
     // incidence entries ascending (= ascending element index, then local node)
-    ent[lane] = lane < deg ? list[p0 + lane] : 0x7fffffff;
-    __syncthreads();
-    if (!FILL) {
-        lds_bitonic_sort(ent, 64);
-        if (lane < deg) list[p0 + lane] = ent[lane];
+    {
+        int32_t en = lane < deg ? list[p0 + lane] : 0x7fffffff;
+        if (!FILL) {
+            en = wave_bitonic_sort(en);
+            if (lane < deg) list[p0 + lane] = en;
+        }
+        ent[lane] = en;
     }
+    __syncthreads();
     const int ncand = deg * 8;
     int P = 64;
     while (P < ncand) P <<= 1;
@@ -153,7 +171,11 @@ k_symbolic(int64_t nloc, int64_t r0, int64_t r1, const int64_t *ptr, int32_t *li
         cand[i] = c;
     }
     __syncthreads();
-    lds_bitonic_sort(cand, P);
+    if (P == 64) {  // the common case (<= 8 incident elements): sort in registers
+        cand[lane] = wave_bitonic_sort(cand[lane]);
+        __syncthreads();
+    } else
+        lds_bitonic_sort(cand, P);
     // distinct values, in ascending (global) order
     int32_t base = 0;
     for (int i0 = 0; i0 < P; i0 += 64) {
