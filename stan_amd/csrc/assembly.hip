@@ -208,10 +208,14 @@ k_symbolic(int64_t nloc, int64_t r0, int64_t r1, const int64_t *ptr, int32_t *li
 }
 
 // slice width = longest row of the slice; also accumulates block count and max width
-__global__ void __launch_bounds__(64)
-k_slice_width(const int32_t *rowlen, int32_t *width, unsigned long long *nblocks, int32_t *maxw) {
-    const int lane = threadIdx.x;
-    int v = rowlen[(int64_t)blockIdx.x * 64 + lane];
+// (4 slices per workgroup, one atomic pair per workgroup: 51 k same-address atomics were 1.2 ms)
+__global__ void __launch_bounds__(256)
+k_slice_width(int32_t nslices, const int32_t *rowlen, int32_t *width, unsigned long long *nblocks,
+              int32_t *maxw) {
+    __shared__ int sh_s[4], sh_m[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t slice = (int64_t)blockIdx.x * 4 + w;
+    int v = slice < nslices ? rowlen[slice * 64 + lane] : 0;
     int s = v;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
@@ -219,15 +223,24 @@ k_slice_width(const int32_t *rowlen, int32_t *width, unsigned long long *nblocks
         s += __shfl_xor(s, d, 64);
     }
     if (lane == 0) {
-        width[blockIdx.x] = v;
-        atomicAdd(nblocks, (unsigned long long)s);
-        atomicMax(maxw, v);
+        if (slice < nslices) width[slice] = v;
+        sh_s[w] = s;
+        sh_m[w] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(nblocks, (unsigned long long)(sh_s[0] + sh_s[1] + sh_s[2] + sh_s[3]));
+        atomicMax(maxw, max(max(sh_m[0], sh_m[1]), max(sh_m[2], sh_m[3])));
     }
 }
 
 __global__ void k_count_fixed(int64_t n, const int32_t *red, unsigned long long *count) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && red[i] == -1) atomicAdd(count, 1ull);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) c += red[i] == -1;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (unsigned long long)c);
 }
 
 __global__ void k_i64_to_i32(const int64_t *in, int32_t *out, int64_t n) {
@@ -265,6 +278,9 @@ struct numeric_args {
 };
 
 // two waves per SIMD (<= 128 VGPRs): measured 23.6 ms vs 39.7 ms at 148^3 (tools/asm_lab.sh)
+#ifndef STAN_ABL
+#define STAN_ABL 0
+#endif
 #ifndef STAN_NUM_WAVES
 #define STAN_NUM_WAVES 2
 #endif
@@ -400,7 +416,11 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
             int pos = -1;
             if (valid) {
                 // phase B: block (a, b) of element e
+#if STAN_ABL == 1
+                for (int j = 0; j < 9; j++) kb[j] = gpw[s * 10 + j];
+#else
                 hex8_block_ab(gpw + s * 10, 8 * 10, type, a, b, lam, G, kb);
+#endif
                 // phase C: slot of column colg in this row (columns ascending)
                 const int32_t lc = (colg >= A.r0 && colg < A.r1)
                                        ? (int32_t)(colg - A.r0)
@@ -422,7 +442,9 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
                 }
             }
             const bool anydup = __ballot(isdup) != 0ull;
-            if (!anydup && W <= 48) {
+            if (STAN_ABL == 2) {
+                if (pos == 12345) acc[0] = kb[0];
+            } else if (!anydup && W <= 48) {
                 // Gather form: every lane stages its block, a map says which lane of incidence
                 // s2 feeds slot k, then lane k sums its slot over s2 = 0..7 in registers
                 // (ascending element index => fixed order) with independent, pipelined LDS
@@ -481,7 +503,7 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
     __syncthreads();
 
     // write-out with the essential BCs applied: 16 consecutive lanes = one full 128-B line
-    for (int t = tid; t < 16 * sw * 9; t += 256) {
+    for (int t = tid; t < (STAN_ABL == 3 ? 16 : 16 * sw * 9); t += 256) {
         const int r16 = t & 15, kc = t >> 4;
         const int comp = kc % 9, k = kc / 9;
         const int64_t row = row_base + r16;
@@ -709,7 +731,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     int64_t *d_sp64; STANCHK(stan_dmalloc(ctx, &d_sp64, (size_t)K->nslices + 2)); tmp.own(d_sp64);
     HIPCHK(ctx, hipMemsetAsync(d_status + 16, 0, 16, st));
     if (K->nslices > 0)
-        hipLaunchKernelGGL(k_slice_width, dim3((unsigned)K->nslices), dim3(64), 0, st, K->d_rowlen,
+        hipLaunchKernelGGL(k_slice_width, dim3(nblk(K->nslices, 4)), dim3(256), 0, st, K->nslices, K->d_rowlen,
                            d_width, (unsigned long long *)(d_status + 16), (int32_t *)(d_status + 17));
     STANCHK(stan_scan_exclusive(ctx, d_width, d_sp64, K->nslices));
     STANCHK(stan_dmalloc(ctx, &K->d_slot_ptr, (size_t)K->nslices + 1));
@@ -761,7 +783,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemsetAsync(d_status + 9, 0, 8, st));
-    hipLaunchKernelGGL(k_count_fixed, dim3(nblk(n_dof, 256)), dim3(256), 0, st, n_dof, d_red,
+    hipLaunchKernelGGL(k_count_fixed, dim3(nblk(n_dof, 256) > 2048 ? 2048 : nblk(n_dof, 256)), dim3(256), 0, st, n_dof, d_red,
                        (unsigned long long *)(d_status + 9));
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 8, d_status + 8, 16, hipMemcpyDeviceToHost, st));
 

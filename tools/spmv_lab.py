@@ -28,3 +28,24 @@ for v in variants:
     t = np.array(res[v])
     print("variant %d: median %.4f ms min %.4f ms -> %.0f GB/s (%.1f%% of 8 TB/s)%s" %
           (v, np.median(t), t.min(), bytes_alg / np.median(t) / 1e6, bytes_alg / np.median(t) / 1e6 / 80, ok))
+
+# context: what a plain device copy reaches on THIS device (read + write bytes / time)
+a = torch.empty(1 << 29, dtype=torch.float64, device="cuda")   # 4 GiB
+b = torch.empty_like(a)
+for _ in range(2):
+    b.copy_(a)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    b.copy_(a)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 10
+print("torch copy 4 GiB -> 4 GiB: %.3f ms = %.0f GB/s (read+write)" % (ms, 2 * a.numel() * 8 / ms / 1e6))
+s_ = a.sum(); torch.cuda.synchronize()
+e0.record()
+for _ in range(10):
+    s_ = a.sum()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 10
+print("torch sum of 4 GiB (read only): %.3f ms = %.0f GB/s" % (ms, a.numel() * 8 / ms / 1e6))
