@@ -49,3 +49,46 @@ def cube_bcs(n, h=1.0, clamp_faces="x", load=(0.0, 0.0, 50.0)):
     spc = idx[fixed].astype(np.int32)
     ld = idx[i == n].astype(np.int32)
     return spc, ld, np.asarray(load, dtype=np.float64)
+
+
+def star_mesh(k=5, layers=3, rings=2, h=1.0):
+    """An UNSTRUCTURED hex mesh: a regular k-gon cut into k quadrilateral sectors around its
+    centre (each sector refined `rings` x `rings`), extruded `layers` times in z.  The centre
+    line has valence k in the plane (2k incident hexes inside the stack: more than the 8 of a
+    structured mesh for k > 4, fewer for k = 3) and the sector seams are irregular too.
+    Returns xyz [n,3] float64 and conn [e,8] int32 (CHEXA order, det J > 0)."""
+    m = rings
+    pts = {}
+    coords = []
+
+    def pid(p):
+        key = (round(p[0], 9), round(p[1], 9))
+        if key not in pts:
+            pts[key] = len(coords)
+            coords.append((p[0], p[1]))
+        return pts[key]
+
+    quads = []
+    ang = 2 * np.pi / k
+    c = np.zeros(2)
+    for s in range(k):
+        v = np.array([np.cos(s * ang), np.sin(s * ang)])                 # polygon vertex
+        e0 = 0.5 * (v + np.array([np.cos((s - 1) * ang), np.sin((s - 1) * ang)]))  # mid of previous edge
+        e1 = 0.5 * (v + np.array([np.cos((s + 1) * ang), np.sin((s + 1) * ang)]))  # mid of next edge
+        # sector quad (counter-clockwise): centre -> e0 -> v -> e1, bilinear m x m refinement
+        def P(a, b):
+            u, w = a / m, b / m
+            return (1 - u) * (1 - w) * c + u * (1 - w) * e0 + u * w * v + (1 - u) * w * e1
+        for a in range(m):
+            for b in range(m):
+                quads.append([pid(P(a, b)), pid(P(a + 1, b)), pid(P(a + 1, b + 1)), pid(P(a, b + 1))])
+    n2 = len(coords)
+    xy = np.array(coords)
+    xyz = np.concatenate([np.column_stack([xy, np.full(n2, z * h)]) for z in range(layers + 1)])
+    conn = []
+    for z in range(layers):
+        for q in quads:
+            conn.append([q[0] + z * n2, q[1] + z * n2, q[2] + z * n2, q[3] + z * n2,
+                         q[0] + (z + 1) * n2, q[1] + (z + 1) * n2, q[2] + (z + 1) * n2,
+                         q[3] + (z + 1) * n2])
+    return xyz.astype(np.float64), np.array(conn, dtype=np.int32)

@@ -380,3 +380,43 @@ def test_single_rank_rccl_communicator(built_libs):
         K.free()
         ctx.close()
     assert res[0][1] == res[1][1] and np.array_equal(res[0][0], res[1][0])
+
+
+def _star_job(k, layers=3, rings=2):
+    from stan_amd.cube import star_mesh
+    xyz, conn = star_mesh(k, layers, rings)
+    z0 = np.nonzero(xyz[:, 2] == 0)[0]
+    top = np.nonzero(xyz[:, 2] == xyz[:, 2].max())[0]
+    return problem.make_job(xyz, conn, z0, np.ones((len(z0), 3)), top,
+                            np.tile([0.0, 10.0, 5.0], (len(top), 1)))
+
+
+@pytest.mark.parametrize("k,rings", [(3, 2), (5, 2), (7, 3), (12, 1)])
+def test_unstructured_mesh_parity(gpu_ctx, oracle, k, rings):
+    """Irregular valence: 2k hexes meet at the centre line (k=7: 14 > 8 incidences -> second
+    incidence chunk and the 128-candidate LDS sort; k=12: a 75-block row -> the wide-row
+    accumulation path)."""
+    job = _star_job(k, rings=rings)
+    K, A = _assemble_both(gpu_ctx, oracle, job)
+    rowptr, col, val = K.to_csr()
+    assert np.array_equal(rowptr, A.ridx) and np.array_equal(col, A.idx)
+    assert np.abs(val - A.vals).max() <= K_TOL * np.abs(A.vals).max()
+    assert K.info()["max_row_blocks"] == (3 * (2 * k + 1) if rings == 1 else K.info()["max_row_blocks"])
+    U, rep = K.cg_solve(job.F, 1e-12)
+    Uo, repo = oracle.cg(A, job.F, 1e-12)
+    assert np.abs(U - Uo).max() <= U_TOL * np.abs(Uo).max()
+    K.free()
+
+
+def test_valence_limits_are_errors(gpu_ctx):
+    from stan_amd import hip
+    job = _star_job(20, rings=1)      # centre row couples to 123 nodes > 96
+    with pytest.raises(hip.StanHipError) as ei:
+        gpu_ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type,
+                              job.mat_E_nu, job.red)
+    assert ei.value.code == hip.E_VALENCE
+    job = _star_job(33, rings=1)      # 66 > 64 incidences on the centre line
+    with pytest.raises(hip.StanHipError) as ei:
+        gpu_ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type,
+                              job.mat_E_nu, job.red)
+    assert ei.value.code == hip.E_VALENCE

@@ -86,3 +86,12 @@ def test_cube_job_sizes(built_libs):
     for n in (4, 10):
         j = problem.cube_job(n)
         assert j.n_dof == 3 * (n + 1) ** 3 and j.n_fixed == 3 * (n + 1) ** 2
+
+
+@pytest.mark.parametrize("k", [3, 5, 7, 12])
+def test_assign_dof_unstructured(oracle, built_libs, k):
+    from stan_amd.cube import star_mesh
+    xyz, conn = star_mesh(k, 3, 2)
+    idx, _ = host.assign_dof(xyz.shape[0], conn)
+    rc, ref = oracle.assign_dof(xyz.shape[0], conn)
+    assert rc == 0 and np.array_equal(idx, ref)
