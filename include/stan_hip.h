@@ -76,6 +76,8 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
  *                           (default 10 = ALGLIB's ItsBeforeRUpdate; 0 = never). */
 #define STAN_OPT_CG_MERIT_STOP 1
 #define STAN_OPT_CG_RUPDATE 2
+#define STAN_OPT_OVERLAP_HALO 4 /* 1 (default): sharded SpMV = interior slices on a side stream
+                                  while the halo is exchanged, then the boundary slices */
 #define STAN_OPT_SPMV_VARIANT 3 /* tuning variants of the SpMV kernel (cg.hip), A/B runs only */
 int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value);
 

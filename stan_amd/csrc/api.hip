@@ -53,6 +53,9 @@ void stan_hip_destroy(stan_ctx *ctx) {
     hipSetDevice(ctx->device);
     if (ctx->comm && ctx->nccl.CommDestroy) ctx->nccl.CommDestroy(ctx->comm);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->side) hipStreamDestroy(ctx->side);
+    if (ctx->ev_a) hipEventDestroy(ctx->ev_a);
+    if (ctx->ev_b) hipEventDestroy(ctx->ev_b);
     if (ctx->h_status) hipHostFree(ctx->h_status);
     if (ctx->d_status) hipFree(ctx->d_status);
     delete ctx;
@@ -77,6 +80,7 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
     if (!ctx) return STAN_E_ARG;
     if (option == STAN_OPT_CG_MERIT_STOP) ctx->cg_merit_stop = value != 0;
     else if (option == STAN_OPT_CG_RUPDATE && value >= 0 && value < (1 << 30)) ctx->cg_rupdate = (int)value;
+    else if (option == STAN_OPT_OVERLAP_HALO) ctx->overlap_halo = value != 0;
     else if (option == STAN_OPT_SPMV_VARIANT && value >= 0 && value <= 8) ctx->spmv_variant = (int)value;
     else { ctx->err = "set_option: unknown option or bad value"; return STAN_E_ARG; }
     return STAN_OK;
@@ -144,6 +148,7 @@ void stan_hip_matrix_free(stan_matrix *K) {
     hipFree(K->d_slot_ptr); hipFree(K->d_rowlen); hipFree(K->d_cols); hipFree(K->d_vals);
     hipFree(K->d_vals32); hipFree(K->d_red); hipFree(K->d_fixmask); hipFree(K->d_scale);
     hipFree(K->d_send_rows); hipFree(K->d_halo_glob); hipFree(K->d_sendbuf);
+    hipFree(K->d_sl_int); hipFree(K->d_sl_bnd);
     delete K;
 }
 

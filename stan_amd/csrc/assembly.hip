@@ -523,6 +523,21 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
     }
 }
 
+// slice class: 1 if any row of the slice references a halo column (local index >= nloc)
+__global__ void __launch_bounds__(64)
+k_slice_class(int64_t nloc, const int32_t *rowlen, const int32_t *slot_ptr, const int32_t *cols,
+              int32_t *is_bnd, int32_t *is_int) {
+    const int lane = threadIdx.x;
+    const int64_t slice = blockIdx.x;
+    const int64_t row = slice * 64 + lane;
+    const int32_t k0 = slot_ptr[slice];
+    bool f = false;
+    if (row < nloc)
+        for (int k = 0; k < rowlen[row]; k++) f |= cols[((int64_t)k0 + k) * 64 + lane] >= nloc;
+    const bool any = __ballot(f) != 0ull;
+    if (lane == 0) { is_bnd[slice] = any ? 1 : 0; is_int[slice] = any ? 0 : 1; }
+}
+
 // ---- per-row rank mask (which ranks need this owned row's x) --------------------------------
 __global__ void k_row_rankflag(int64_t nloc, const int32_t *rowlen, const int32_t *slot_ptr,
                                const int32_t *cols, const int32_t *halo_glob, int64_t q0,
@@ -787,6 +802,30 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
                        (unsigned long long *)(d_status + 9));
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 8, d_status + 8, 16, hipMemcpyDeviceToHost, st));
 
+    // interior / boundary slice lists for the overlapped SpMV (also built for a 1-rank
+    // communicator, where every slice is interior, so that the two-stream path can be tested)
+    if ((ctx->nranks > 1 || ctx->comm) && K->nslices > 0) {
+        int32_t *d_fb, *d_fi; int64_t *d_sb, *d_si;
+        STANCHK(stan_dmalloc(ctx, &d_fb, (size_t)K->nslices + 1)); tmp.own(d_fb);
+        STANCHK(stan_dmalloc(ctx, &d_fi, (size_t)K->nslices + 1)); tmp.own(d_fi);
+        STANCHK(stan_dmalloc(ctx, &d_sb, (size_t)K->nslices + 2)); tmp.own(d_sb);
+        STANCHK(stan_dmalloc(ctx, &d_si, (size_t)K->nslices + 2)); tmp.own(d_si);
+        hipLaunchKernelGGL(k_slice_class, dim3((unsigned)K->nslices), dim3(64), 0, st, nloc,
+                           K->d_rowlen, K->d_slot_ptr, K->d_cols, d_fb, d_fi);
+        STANCHK(stan_scan_exclusive(ctx, d_fb, d_sb, K->nslices));
+        STANCHK(stan_scan_exclusive(ctx, d_fi, d_si, K->nslices));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 6, d_sb + K->nslices, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 7, d_si + K->nslices, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        K->n_sl_bnd = (int32_t)ctx->h_status[6];
+        K->n_sl_int = (int32_t)ctx->h_status[7];
+        STANCHK(stan_dmalloc(ctx, &K->d_sl_bnd, (size_t)K->n_sl_bnd));
+        STANCHK(stan_dmalloc(ctx, &K->d_sl_int, (size_t)K->n_sl_int));
+        hipLaunchKernelGGL(k_compact_flags, dim3(nblk(K->nslices, 256)), dim3(256), 0, st, d_fb, d_sb,
+                           K->d_sl_bnd, (int64_t)K->nslices);
+        hipLaunchKernelGGL(k_compact_flags, dim3(nblk(K->nslices, 256)), dim3(256), 0, st, d_fi, d_si,
+                           K->d_sl_int, (int64_t)K->nslices);
+    }
     // halo exchange plan
     if (ctx->nranks > 1) {
         std::vector<int32_t> hg((size_t)K->nhalo);

@@ -171,7 +171,8 @@ __global__ void __launch_bounds__(256)
 k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
        const int32_t *__restrict__ cols, const VT *__restrict__ vals,
        const double *__restrict__ x, double *__restrict__ y, double *partial,
-       const int64_t *st, int64_t kiter) {
+       const int64_t *st, int64_t kiter, const int32_t *__restrict__ slist, int32_t nlist,
+       int32_t poff) {
     __shared__ double sh[4];
     if (stopped(st, kiter)) return;
     constexpr bool NT = (VAR & 1) != 0 && VAR != 8;
@@ -183,7 +184,8 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
         const int64_t g = gridDim.x, cpx = g >> 3, rem = g & 7, xcd = bid & 7;
         bid = xcd * cpx + (xcd < rem ? xcd : rem) + (bid >> 3);
     }
-    const int64_t slice = bid * 4 + (threadIdx.x >> 6);
+    int64_t slice = bid * 4 + (threadIdx.x >> 6);
+    if (slist) slice = slice < nlist ? (int64_t)slist[slice] : (int64_t)nslices;  // interior / boundary list
     double y0 = 0, y1 = 0, y2 = 0;
     const int64_t row = slice * 64 + lane;
     if (slice < nslices) {
@@ -231,7 +233,7 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
         double d = 0;
         if (slice < nslices && row < nloc) d = y0 * x[3 * row] + y1 * x[3 * row + 1] + y2 * x[3 * row + 2];
         const double t = block_sum(d, sh);
-        if (threadIdx.x == 0) partial[blockIdx.x] = t;
+        if (threadIdx.x == 0) partial[blockIdx.x + poff] = t;
     }
 }
 
@@ -419,15 +421,23 @@ int alloc(stan_ctx *ctx, dev_bufs &b, T **p, size_t n) {
     return rc;
 }
 
+// which: 0 = all slices, 1 = interior list, 2 = boundary list (partials offset by the
+// interior launch's block count).  Returns the number of partials this launch writes.
 template <typename VT, bool DOT>
-void launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double *x, double *y,
-                 double *partial, const int64_t *st, int64_t k) {
-    const unsigned grid = nblk(K->nslices, 4);
-    if (grid == 0) return;
-#define SPMV_CASE(V)                                                                              \
-    case V:                                                                                       \
-        hipLaunchKernelGGL((k_spmv<VT, DOT, V>), dim3(grid), dim3(256), 0, ctx->stream, K->nslices, \
-                           K->nloc, K->d_slot_ptr, K->d_cols, vals, x, y, partial, st, k);         \
+unsigned launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double *x, double *y,
+                     double *partial, const int64_t *st, int64_t k, int which = 0,
+                     hipStream_t stream = nullptr) {
+    if (!stream) stream = ctx->stream;
+    const int32_t *slist = which == 1 ? K->d_sl_int : which == 2 ? K->d_sl_bnd : nullptr;
+    const int32_t nlist = which == 1 ? K->n_sl_int : which == 2 ? K->n_sl_bnd : K->nslices;
+    const int32_t poff = which == 2 ? (int32_t)nblk(K->n_sl_int, 4) : 0;
+    const unsigned grid = nblk(nlist, 4);
+    if (grid == 0) return 0;
+#define SPMV_CASE(V)                                                                          \
+    case V:                                                                                   \
+        hipLaunchKernelGGL((k_spmv<VT, DOT, V>), dim3(grid), dim3(256), 0, stream, K->nslices, \
+                           K->nloc, K->d_slot_ptr, K->d_cols, vals, x, y, partial, st, k,     \
+                           slist, nlist, poff);                                               \
         break;
     switch (ctx->spmv_variant) {
         SPMV_CASE(1) SPMV_CASE(2) SPMV_CASE(3) SPMV_CASE(4) SPMV_CASE(5) SPMV_CASE(6) SPMV_CASE(7)
@@ -436,6 +446,7 @@ void launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double *x,
         SPMV_CASE(0)
     }
 #undef SPMV_CASE
+    return grid;
 }
 
 }  // namespace
@@ -514,7 +525,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     STANCHK(alloc(ctx, bufs, &v, (size_t)n3));
     STANCHK(alloc(ctx, bufs, &bh, (size_t)n3));
     const unsigned spmv_blocks = nblk(K->nslices, 4);
-    const size_t npart = 2 * (size_t)(spmv_blocks > VEC_BLOCKS ? spmv_blocks : VEC_BLOCKS);
+    const size_t npart = 2 * (size_t)(spmv_blocks > VEC_BLOCKS ? spmv_blocks : VEC_BLOCKS) + 16;
     STANCHK(alloc(ctx, bufs, &partial, npart));
     STANCHK(alloc(ctx, bufs, &sc, (size_t)S_NSCAL));
     STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
@@ -535,22 +546,47 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     int64_t its_before_restart = K->n_red > 0 ? K->n_red : 1;
     const int64_t hard_cap = 0x7fffffff;  // iteration counter is int32 in the report
 
+    // Sharded SpMV with the halo exchange hidden behind the interior slices: the slices whose
+    // rows reference no halo column run on a side stream while the main stream packs, sends
+    // and receives; the boundary slices follow on the main stream.  RCCL only ever sees the
+    // main stream.
+    const bool split = dist && ctx->overlap_halo && K->d_sl_bnd != nullptr;
+    if (split && !ctx->side) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
+    }
     std::vector<hipEvent_t> spmv_ev;
-    auto spmv = [&](const double *x, double *y, bool dot, int64_t k) {
+    unsigned spmv_parts = 0;
+    // y = A^ x (x gets its halo filled first when sharded); returns 0 or an error code
+    auto spmv = [&](double *x, double *y, bool dot, int64_t k) -> int {
         if (ctx->profiling) {
             hipEvent_t a, b;
             hipEventCreate(&a); hipEventCreate(&b);
             hipEventRecord(a, st_);
             spmv_ev.push_back(a); spmv_ev.push_back(b);
         }
-        if (mixed) {
-            if (dot) launch_spmv<float, true>(ctx, K, K->d_vals32, x, y, partial, stt, k);
-            else launch_spmv<float, false>(ctx, K, K->d_vals32, x, y, partial, stt, k);
+        auto go = [&](int which, hipStream_t s) -> unsigned {
+            if (mixed)
+                return dot ? launch_spmv<float, true>(ctx, K, K->d_vals32, x, y, partial, stt, k, which, s)
+                           : launch_spmv<float, false>(ctx, K, K->d_vals32, x, y, partial, stt, k, which, s);
+            return dot ? launch_spmv<double, true>(ctx, K, K->d_vals, x, y, partial, stt, k, which, s)
+                       : launch_spmv<double, false>(ctx, K, K->d_vals, x, y, partial, stt, k, which, s);
+        };
+        if (split) {
+            HIPCHK(ctx, hipEventRecord(ctx->ev_a, st_));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_a, 0));
+            spmv_parts = go(1, ctx->side);
+            HIPCHK(ctx, hipEventRecord(ctx->ev_b, ctx->side));
+            STANCHK(stan_comm_halo_exchange(ctx, K, x));
+            HIPCHK(ctx, hipStreamWaitEvent(st_, ctx->ev_b, 0));
+            spmv_parts += go(2, st_);
         } else {
-            if (dot) launch_spmv<double, true>(ctx, K, K->d_vals, x, y, partial, stt, k);
-            else launch_spmv<double, false>(ctx, K, K->d_vals, x, y, partial, stt, k);
+            if (dist) STANCHK(stan_comm_halo_exchange(ctx, K, x));
+            spmv_parts = go(0, st_);
         }
         if (ctx->profiling) hipEventRecord(spmv_ev.back(), st_);
+        return STAN_OK;
     };
 
     int64_t *h_st = ctx->h_status + 16;  // pinned
@@ -568,9 +604,9 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     while (!done && rc == STAN_OK) {
         // enqueue one chunk of iterations
         for (int c = 0; c < CHUNK && k < hard_cap; c++, k++) {
-            if (dist) { rc = stan_comm_halo_exchange(ctx, K, p); if (rc) break; }
-            spmv(p, v, true, k);
-            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st_, partial, (int)spmv_blocks, 1,
+            rc = spmv(p, v, true, k);
+            if (rc) break;
+            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st_, partial, (int)spmv_parts, 1,
                                sc + S_VMV);
             if (dist) { rc = stan_comm_allreduce_sum_f64(ctx, sc + S_VMV, 1); if (rc) break; }
             step_args a;
@@ -580,9 +616,9 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             a.refresh = ctx->cg_rupdate > 0 && (k % ctx->cg_rupdate) == 0;
             hipLaunchKernelGGL(k_step, dim3(vg), dim3(VEC_T), 0, st_, a);
             if (a.refresh) {
-                if (dist) { rc = stan_comm_halo_exchange(ctx, K, xb[k & 1]); if (rc) break; }
                 // a -5/-4 stop of this iteration is caught by k_refresh/k_update (ITER_B <= k)
-                spmv(xb[k & 1], v, false, k);
+                rc = spmv(xb[k & 1], v, false, k);
+                if (rc) break;
                 hipLaunchKernelGGL(k_refresh, dim3(vg), dim3(VEC_T), 0, st_, n3, k,
                                    (const int64_t *)stt, bh, v, xb[k & 1], r, partial);
             }
@@ -692,7 +728,12 @@ int stan_spmv_local(stan_ctx *ctx, stan_matrix *K, const double *d_x, double *d_
     STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
     int64_t init[T_NSTAT] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0, 0, 0, 0, 0, 0};
     HIPCHK(ctx, hipMemcpyAsync(stt, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-    launch_spmv<double, false>(ctx, K, K->d_vals, d_x, d_y, nullptr, stt, 1);
+    if (K->d_sl_bnd) {  // sharded: interior + boundary lists must cover every slice exactly once
+        HIPCHK(ctx, hipMemsetAsync(d_y, 0xff, (size_t)(3 * K->nloc) * 8, ctx->stream));  // NaN
+        launch_spmv<double, false>(ctx, K, K->d_vals, d_x, d_y, nullptr, stt, 1, 1);
+        launch_spmv<double, false>(ctx, K, K->d_vals, d_x, d_y, nullptr, stt, 1, 2);
+    } else
+        launch_spmv<double, false>(ctx, K, K->d_vals, d_x, d_y, nullptr, stt, 1);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return STAN_OK;

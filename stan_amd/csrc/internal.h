@@ -58,6 +58,9 @@ struct stan_ctx {
     // solver options (include/stan_hip.h STAN_OPT_*)
     bool cg_merit_stop = true;
     int cg_rupdate = 10;
+    bool overlap_halo = true;  // interior SpMV on a side stream while the halo is exchanged
+    hipStream_t side = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
     int spmv_variant = 1;  // non-temporal matrix stream: measured 1.124 vs 1.216 ms at 148^3 (profiles/r01)
     // profiling
     bool profiling = false;
@@ -94,6 +97,9 @@ struct stan_matrix {
     int32_t *d_halo_glob = nullptr;   // [nhalo] global block index of each halo column
     double *d_sendbuf = nullptr;      // [3*send_total]
     std::vector<int64_t> row_starts;  // [nranks+1] partition
+    // slices whose rows reference no halo column (interior) / at least one (boundary)
+    int32_t *d_sl_int = nullptr, *d_sl_bnd = nullptr;
+    int32_t n_sl_int = 0, n_sl_bnd = 0;
 };
 
 // ---- scan.hip -------------------------------------------------------------------------------
