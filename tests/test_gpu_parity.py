@@ -420,3 +420,57 @@ def test_valence_limits_are_errors(gpu_ctx):
         gpu_ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type,
                               job.mat_E_nu, job.red)
     assert ei.value.code == hip.E_VALENCE
+
+
+def test_edge_cases_empty_and_fully_fixed(gpu_ctx, oracle):
+    """Degenerate inputs go through without a crash: every DOF fixed (N = 0), a node that no
+    element references (empty matrix row), and a model with nodes but no elements."""
+    from stan_amd import host
+    job = problem.cube_job(2)
+    # every node clamped: the reduced system is empty, U is empty, termination type 1
+    allfix = np.full(job.n_dof, -1, np.int32)
+    K = gpu_ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type,
+                              job.mat_E_nu, allfix)
+    assert K.info()["n_reduced"] == 0
+    U, rep = K.cg_solve(np.zeros(0), 1e-8)
+    assert U.shape == (0,) and rep["terminationtype"] == 1 and rep["iterations"] == 0
+    rp, col, val = K.to_csr()
+    assert rp.tolist() == [0] and col.size == 0
+    K.free()
+    # an orphan node appended after the mesh (DOFs numbered after the BFS range)
+    xyz = np.vstack([job.xyz, [[9.0, 9.0, 9.0]]])
+    nd = np.vstack([job.node_dof, [[81, 82, 83]]]).astype(np.int32)
+    red, nfix = host.dof_reduction(84, nd, np.nonzero(job.xyz[:, 0] == 0)[0], np.ones((9, 3)))
+    K = gpu_ctx.assemble_hex8(xyz, nd, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, red)
+    rc, A = oracle.assemble(xyz, nd, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, red)
+    rp, col, val = K.to_csr()
+    assert np.array_equal(rp, A.ridx) and np.array_equal(col, A.idx)   # three empty rows at the end
+    F = np.zeros(84 - nfix); F[:54] = job.F
+    U, rep = K.cg_solve(F, 1e-10)
+    Uo, _ = oracle.cg(A, F, 1e-10)
+    assert np.abs(U - Uo).max() <= U_TOL * np.abs(Uo).max() and not U[54:].any()
+    K.free()
+    # nodes without elements: K = 0, CG reports "not positive definite" (p'Ap = 0), U = 0
+    K = gpu_ctx.assemble_hex8(job.xyz, job.node_dof, np.zeros((0, 8), np.int32), np.zeros(0, np.int32),
+                              np.zeros(0, np.uint8), job.mat_E_nu, job.red)
+    assert K.info()["n_blocks"] == 0
+    U, rep = K.cg_solve(job.F, 1e-8)
+    assert rep["terminationtype"] == -5 and not U.any()
+    K.free()
+
+
+def test_overlap_option_does_not_change_the_bits(built_libs):
+    import torch  # noqa: F401
+    from stan_amd import hip
+    job = problem.cube_job(9, jitter=0.1)
+    args = (job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+    res = []
+    for overlap in (1, 0):
+        ctx = hip.Context(0)
+        ctx.comm_init(0, 1, ctx.unique_id())
+        ctx.set_option(hip.OPT_OVERLAP_HALO, overlap)
+        K = ctx.assemble_hex8(*args)
+        res.append(K.cg_solve(job.F, 1e-10))
+        K.free()
+        ctx.close()
+    assert res[0][1] == res[1][1] and np.array_equal(res[0][0], res[1][0])
