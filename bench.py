@@ -140,6 +140,18 @@ def main():
 
     # sanity of the timed work (rank 0): converged to eps, true residual through an
     # independent product is checked in tests; here the solver's own report
+    # context for the roofline: what a plain read-only reduction reaches on THIS device
+    dev_read = None
+    if rank == 0:
+        probe = torch.empty(1 << 27, dtype=torch.float64, device=dev)  # 1 GiB
+        probe.sum(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            probe.sum()
+        e1.record(); torch.cuda.synchronize()
+        dev_read = probe.numel() * 8 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del probe
     ok = rep["terminationtype"] == 1 and rep["rel_residual"] <= args.eps
     out = None
     if rank == 0:
@@ -174,7 +186,11 @@ def main():
                        "assemble_ms": asm_ms / args.steps, "cg_ms": cg_ms / args.steps,
                        "matrix_format": "BSELL-64 3x3 blocks (fp%s values + int32 block cols)" %
                                         ("32" if args.mixed else "64"),
-                       "parallelism": "rows sharded x%d" % world},
+                       "parallelism": "rows sharded x%d" % world,
+                       # SURVEY section 8d assembly bytes: coords + connectivity read, K written once
+                       "assembly_GBs": (job.conn.shape[0] * (192 + 32) + info["n_slots"] * 64 * 72)
+                                       / (asm_ms / args.steps * 1e-3) / 1e9 if asm_ms > 0 else None,
+                       "device_read_GBs": dev_read},
             "roofline": {"bound": "hbm", "kernel": "k_spmv (BSELL-64 SpMV + fused p.Ap)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
