@@ -74,19 +74,27 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # STAN_BENCH_BACKEND / STAN_BENCH_DEVICE: test hooks (tests/test_gpu_sharded.py runs this
+    # file with several ranks on ONE GPU over gloo + tests/fake_rccl); the driver uses neither
+    backend = os.environ.get("STAN_BENCH_BACKEND", "nccl")
+    dev_index = int(os.environ.get("STAN_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    ctl = dev if backend == "nccl" else torch.device("cpu")   # where control-plane tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     # ---- synthetic job (host: mesh, Database.AssignDOF, BC tables; outside the timed region)
     job = problem.cube_job(args.n, etype=args.etype)
-    ctx = hip.Context(local_rank)
+    ctx = hip.Context(dev_index)
     if world > 1:
-        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        uid = torch.zeros(128, dtype=torch.uint8, device=ctl)
         if rank == 0:
-            uid = torch.tensor(list(ctx.unique_id()), dtype=torch.uint8, device=dev)
+            uid = torch.tensor(list(ctx.unique_id()), dtype=torch.uint8, device=ctl)
         dist.broadcast(uid, 0)
         ctx.comm_init(rank, world, bytes(uid.cpu().tolist()))
     ctx.set_option(hip.OPT_CG_MERIT_STOP, 0)
@@ -134,7 +142,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -12,6 +12,7 @@
 // on it and loads on hosts without RCCL (and next to torch's bundled librccl.so.1).
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "internal.h"
@@ -26,8 +27,11 @@ typedef int (*fn_commInitRank)(void **, int, nccl_uid, int);
 int load_rccl(stan_ctx *ctx) {
     rccl_api &n = ctx->nccl;
     if (n.handle) return STAN_OK;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // STAN_RCCL_LIB: test hook only (tests/fake_rccl: several ranks on ONE GPU, which RCCL refuses)
+    const char *names[] = {getenv("STAN_RCCL_LIB"), "librccl.so.1", "librccl.so",
+                           "/opt/rocm/lib/librccl.so.1"};
     for (const char *nm : names) {
+        if (!nm || !*nm) continue;
         n.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
         if (n.handle) break;
     }

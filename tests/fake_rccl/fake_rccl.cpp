@@ -1,0 +1,195 @@
+// fake_rccl.cpp -- TEST INFRASTRUCTURE ONLY: a stand-in for the handful of RCCL entry points
+// libstan_hip.so resolves with dlopen (comm.hip), implemented over POSIX shared memory and
+// host-staged hipMemcpy, so that SEVERAL RANKS CAN SHARE THE ONE GPU of the test box.
+// Real RCCL refuses that ("Duplicate GPU detected"), which would leave the sharded CG
+// (halo exchange, all-reduces, result gather, two-stream overlap) untested end to end.
+// Selected only through the environment variable STAN_RCCL_LIB; the product default is the
+// real librccl.so.1.  Every call is synchronous (it drains the stream it is given).
+//
+// Semantics kept from NCCL: collectives are matched by call order; ncclSend/ncclRecv pair up
+// per (source, destination) in issue order inside a group; ncclAllReduce sums in rank order.
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr int MAXR = 16;
+constexpr size_t MAILBOX = 64u << 20;  // bytes per rank
+constexpr int MAXOPS = 256;
+
+struct Desc { int peer; int kind; size_t off, bytes; };  // kind 0 = send to peer, 1 = broadcast
+struct Header {
+    std::atomic<int> init, arrived, sense;
+    int nranks;
+    int nops[MAXR];
+    Desc ops[MAXR][MAXOPS];
+};
+struct Comm {
+    Header *h;
+    char *box;  // nranks mailboxes
+    int rank, nranks;
+    int local_sense;
+    char name[64];
+    size_t bytes;
+};
+struct Op { int kind; const void *src; void *dst; size_t bytes; int peer; hipStream_t st; };  // 0 send 1 recv 2 bcast
+thread_local int g_depth = 0;
+thread_local std::vector<Op> g_ops;
+thread_local Comm *g_comm = nullptr;
+
+void barrier(Comm *c) {
+    c->local_sense ^= 1;
+    if (c->h->arrived.fetch_add(1) + 1 == c->nranks) {
+        c->h->arrived.store(0);
+        c->h->sense.store(c->local_sense);
+    } else
+        while (c->h->sense.load() != c->local_sense) sched_yield();
+}
+size_t tsize(int dt) { return dt == 1 ? 1 : 8; }  // ncclUint8 = 1; ncclInt64 = 4 and ncclFloat64 = 8 are 8 bytes
+
+int flush_group(Comm *c) {
+    if (!c) return 5;
+    for (const Op &o : g_ops) hipStreamSynchronize(o.st);
+    // phase 1: publish what this rank sends / broadcasts
+    size_t off = 0;
+    int n = 0;
+    char *mine = c->box + (size_t)c->rank * MAILBOX;
+    for (const Op &o : g_ops) {
+        if (o.kind == 1) continue;
+        if (o.kind == 2 && o.peer != c->rank) continue;  // not the root of this broadcast
+        if (off + o.bytes > MAILBOX || n >= MAXOPS) { fprintf(stderr, "fake_rccl: mailbox overflow\n"); return 5; }
+        hipMemcpy(mine + off, o.src, o.bytes, hipMemcpyDeviceToHost);
+        c->h->ops[c->rank][n++] = Desc{o.kind == 0 ? o.peer : -1, o.kind == 0 ? 0 : 1, off, o.bytes};
+        off += o.bytes;
+    }
+    c->h->nops[c->rank] = n;
+    barrier(c);
+    // phase 2: pick up what is addressed to this rank, matching in issue order per source
+    int taken_send[MAXR] = {0}, taken_bc[MAXR] = {0};
+    for (const Op &o : g_ops) {
+        if (o.kind == 0) continue;
+        if (o.kind == 2 && o.peer == c->rank) {  // root: in place or copy to recv buffer
+            if (o.dst != o.src) hipMemcpy(o.dst, o.src, o.bytes, hipMemcpyDeviceToDevice);
+            taken_bc[c->rank]++;
+            continue;
+        }
+        const int src = o.peer;
+        const int want_kind = o.kind == 1 ? 0 : 1;
+        int &taken = want_kind == 0 ? taken_send[src] : taken_bc[src];
+        int seen = 0;
+        const Desc *d = nullptr;
+        for (int i = 0; i < c->h->nops[src]; i++) {
+            const Desc &q = c->h->ops[src][i];
+            if (q.kind != want_kind || (want_kind == 0 && q.peer != c->rank)) continue;
+            if (seen++ == taken) { d = &q; break; }
+        }
+        if (!d || d->bytes != o.bytes) { fprintf(stderr, "fake_rccl: rank %d found no matching message from %d\n", c->rank, src); return 5; }
+        hipMemcpy(o.dst, c->box + (size_t)src * MAILBOX + d->off, o.bytes, hipMemcpyHostToDevice);
+        taken++;
+    }
+    barrier(c);
+    g_ops.clear();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ncclGetUniqueId(void *id) {
+    memset(id, 0, 128);
+    snprintf((char *)id, 64, "/stan_fake_rccl_%d_%ld", (int)getpid(), (long)random());
+    return 0;
+}
+
+struct nccl_uid { char internal[128]; };
+int ncclCommInitRank(void **comm, int nranks, nccl_uid id, int rank) {
+    if (nranks > MAXR) return 4;
+    Comm *c = new Comm();
+    c->rank = rank; c->nranks = nranks; c->local_sense = 0;
+    strncpy(c->name, id.internal, 63);
+    c->bytes = sizeof(Header) + (size_t)nranks * MAILBOX;
+    int fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)c->bytes) != 0) return 2;
+    void *p = mmap(nullptr, c->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return 2;
+    c->h = (Header *)p;  // a fresh shm segment is zero-filled: arrived = sense = 0
+    c->box = (char *)p + sizeof(Header);
+    c->h->nranks = nranks;
+    c->h->init.fetch_add(1);
+    while (c->h->init.load() < nranks) sched_yield();
+    barrier(c);
+    *comm = c;
+    g_comm = c;
+    return 0;
+}
+
+int ncclCommDestroy(void *comm) {
+    Comm *c = (Comm *)comm;
+    barrier(c);
+    if (c->rank == 0) shm_unlink(c->name);
+    munmap((void *)c->h, c->bytes);
+    delete c;
+    return 0;
+}
+
+int ncclAllReduce(const void *send, void *recv, size_t count, int dt, int op, void *comm, hipStream_t st) {
+    Comm *c = (Comm *)comm;
+    if (op != 0 || (dt != 8 && dt != 4)) return 4;
+    const size_t bytes = count * 8;
+    if (bytes > MAILBOX) return 5;
+    hipStreamSynchronize(st);
+    hipMemcpy(c->box + (size_t)c->rank * MAILBOX, send, bytes, hipMemcpyDeviceToHost);
+    barrier(c);
+    std::vector<char> out(bytes);
+    for (size_t i = 0; i < count; i++) {
+        if (dt == 8) {
+            double s = 0;
+            for (int r = 0; r < c->nranks; r++) s += ((const double *)(c->box + (size_t)r * MAILBOX))[i];
+            ((double *)out.data())[i] = s;
+        } else {
+            int64_t s = 0;
+            for (int r = 0; r < c->nranks; r++) s += ((const int64_t *)(c->box + (size_t)r * MAILBOX))[i];
+            ((int64_t *)out.data())[i] = s;
+        }
+    }
+    barrier(c);
+    hipMemcpy(recv, out.data(), bytes, hipMemcpyHostToDevice);
+    return 0;
+}
+
+int ncclGroupStart() { g_depth++; return 0; }
+int ncclGroupEnd() {
+    if (--g_depth > 0) return 0;
+    return g_ops.empty() ? 0 : flush_group(g_comm);
+}
+int ncclSend(const void *buf, size_t count, int dt, int peer, void *comm, hipStream_t st) {
+    g_comm = (Comm *)comm;
+    g_ops.push_back(Op{0, buf, nullptr, count * tsize(dt), peer, st});
+    return g_depth ? 0 : flush_group(g_comm);
+}
+int ncclRecv(void *buf, size_t count, int dt, int peer, void *comm, hipStream_t st) {
+    g_comm = (Comm *)comm;
+    g_ops.push_back(Op{1, nullptr, buf, count * tsize(dt), peer, st});
+    return g_depth ? 0 : flush_group(g_comm);
+}
+int ncclBroadcast(const void *send, void *recv, size_t count, int dt, int root, void *comm, hipStream_t st) {
+    g_comm = (Comm *)comm;
+    g_ops.push_back(Op{2, send, recv, count * tsize(dt), root, st});
+    return g_depth ? 0 : flush_group(g_comm);
+}
+const char *ncclGetErrorString(int r) {
+    return r == 0 ? "success" : r == 4 ? "fake_rccl: invalid argument" : r == 5 ? "fake_rccl: protocol error" : "fake_rccl: system error";
+}
+
+}  // extern "C"

@@ -1,0 +1,34 @@
+"""One rank of the sharded solve, for tests/test_gpu_sharded.py (launched by torch.distributed.run
+with the gloo control plane; every rank drives GPU 0 through tests/fake_rccl)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+from stan_amd import hip, problem  # noqa: E402
+
+n, out_dir, overlap = int(sys.argv[1]), sys.argv[2], int(sys.argv[3])
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+job = problem.cube_job(n, jitter=0.05)
+ctx = hip.Context(0)
+box = [ctx.unique_id() if rank == 0 else None]
+dist.broadcast_object_list(box, 0)
+ctx.comm_init(rank, world, box[0])
+ctx.set_option(hip.OPT_OVERLAP_HALO, overlap)
+K = ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+info = K.info()
+res = {}
+for tag, eps, prec in (("fp64", 1e-7, hip.PREC_FP64), ("mixed", 1e-6, hip.PREC_MIXED)):
+    U, rep = K.cg_solve(job.F, eps, precision_mode=prec)
+    res[tag] = (U, rep)
+np.savez(os.path.join(out_dir, "rank%d.npz" % rank), U=res["fp64"][0], Um=res["mixed"][0],
+         its=res["fp64"][1]["iterations"], term=res["fp64"][1]["terminationtype"],
+         rows=np.array([info["row_begin"], info["row_end"], info["n_halo"]]))
+K.free()
+ctx.close()
+dist.barrier()
+dist.destroy_process_group()
