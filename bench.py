@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=148, help="cube edge in elements (148 -> ~10 M DOF)")
+    ap.add_argument("--size", dest="n", type=int, default=148, help="cube edge in elements (148 -> ~10 M DOF)")
     ap.add_argument("--eps", type=float, default=1e-8)
     ap.add_argument("--mixed", action="store_true", help="fp32 matrix / fp64 vectors")
     ap.add_argument("--etype", type=int, default=2, help="2 = HEX8_G2, 1 = HEX8_G1")
