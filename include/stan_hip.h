@@ -78,6 +78,8 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
 #define STAN_OPT_CG_RUPDATE 2
 #define STAN_OPT_OVERLAP_HALO 4 /* 1 (default): sharded SpMV = interior slices on a side stream
                                   while the halo is exchanged, then the boundary slices */
+#define STAN_OPT_ASSEMBLY_MODE 5 /* 0 (default): row-owner gather; 1: one element per wavefront +
+                                   colour-ordered scatter (the north-star variant, single rank) */
 #define STAN_OPT_SPMV_VARIANT 3 /* tuning variants of the SpMV kernel (cg.hip), A/B runs only */
 int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value);
 
@@ -206,6 +208,8 @@ typedef struct stan_profile {
     int64_t cg_iteration_vector_bytes; /* vector traffic of one CG iteration        */
     int32_t iterations;
     int32_t termination_type;
+    int32_t assembly_colours; /* element colours of the last mode-1 assembly */
+    int32_t reserved;
 } stan_profile;
 int stan_hip_set_profiling(stan_ctx *ctx, int32_t enabled);
 int stan_hip_get_profile(stan_ctx *ctx, stan_profile *out);

@@ -80,6 +80,7 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
     if (!ctx) return STAN_E_ARG;
     if (option == STAN_OPT_CG_MERIT_STOP) ctx->cg_merit_stop = value != 0;
     else if (option == STAN_OPT_CG_RUPDATE && value >= 0 && value < (1 << 30)) ctx->cg_rupdate = (int)value;
+    else if (option == STAN_OPT_ASSEMBLY_MODE && (value == 0 || value == 1)) ctx->assembly_mode = (int)value;
     else if (option == STAN_OPT_OVERLAP_HALO) ctx->overlap_halo = value != 0;
     else if (option == STAN_OPT_SPMV_VARIANT && value >= 0 && value <= 8) ctx->spmv_variant = (int)value;
     else { ctx->err = "set_option: unknown option or bad value"; return STAN_E_ARG; }
@@ -94,6 +95,7 @@ int stan_hip_set_profiling(stan_ctx *ctx, int32_t enabled) {
 int stan_hip_get_profile(stan_ctx *ctx, stan_profile *out) {
     if (!ctx || !out) return STAN_E_ARG;
     *out = ctx->prof;
+    out->assembly_colours = ctx->prof_colours;
     return STAN_OK;
 }
 

@@ -61,6 +61,8 @@ struct stan_ctx {
     bool overlap_halo = true;  // interior SpMV on a side stream while the halo is exchanged
     hipStream_t side = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    int assembly_mode = 0;     // 0 row-owner gather (default), 1 element-wave colour scatter
+    int prof_colours = 0;
     int spmv_variant = 1;  // non-temporal matrix stream: measured 1.124 vs 1.216 ms at 148^3 (profiles/r01)
     // profiling
     bool profiling = false;
@@ -114,6 +116,12 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
                          stan_matrix **outK);
 int stan_ke_batch_device(stan_ctx *ctx, int64_t n, const double *d_xyz8, double E, double nu,
                          const uint8_t *d_type, double *d_out);
+
+// ---- assembly_scatter.hip ---------------------------------------------------------------------
+int stan_assemble_colour_scatter(stan_ctx *ctx, stan_matrix *K, int64_t n_elem, const int32_t *d_conn,
+                                 const int32_t *d_perm, const double *d_xyz, const int32_t *d_elem_mat,
+                                 const uint8_t *d_elem_type, const double *d_lamG, const int64_t *d_ptr,
+                                 const int32_t *d_list, long long *d_bad);
 
 // ---- cg.hip ---------------------------------------------------------------------------------
 int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_f,

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("STAN_HIP_LIB") or os.path.join(_HERE, "lib", "libstan
 
 HEX8_G1, HEX8_G2 = 1, 2
 PREC_FP64, PREC_MIXED = 0, 1
-OPT_CG_MERIT_STOP, OPT_CG_RUPDATE, OPT_SPMV_VARIANT, OPT_OVERLAP_HALO = 1, 2, 3, 4
+OPT_CG_MERIT_STOP, OPT_CG_RUPDATE, OPT_SPMV_VARIANT, OPT_OVERLAP_HALO, OPT_ASSEMBLY_MODE = 1, 2, 3, 4, 5
 E_HIP, E_ARG, E_ALLOC, E_DETJ, E_DOF_LAYOUT, E_VALENCE, E_COMM, E_UNSUPPORTED = (
     -1, -2, -3, -4, -5, -6, -7, -8)
 
@@ -44,7 +44,8 @@ class Profile(C.Structure):
                 ("numeric_ms", C.c_double), ("cg_ms", C.c_double), ("spmv_ms_total", C.c_double),
                 ("spmv_launches", C.c_int64), ("spmv_bytes", C.c_int64),
                 ("cg_iteration_vector_bytes", C.c_int64), ("iterations", C.c_int32),
-                ("termination_type", C.c_int32)]
+                ("termination_type", C.c_int32), ("assembly_colours", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class StanHipError(RuntimeError):
