@@ -784,6 +784,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         STANCHK(stan_assemble_colour_scatter(ctx, K, n_elem, d_conn, d_perm, d_xyz, d_elem_mat, d_elem_type,
                                              d_lamG, d_ptr, d_list, (long long *)(d_status + 8)));
     } else {
+        ctx->prof_colours = 0;
         numeric_args A;
         A.nloc = nloc; A.r0 = r0; A.r1 = r1; A.nhalo = K->nhalo;
         A.ptr = d_ptr; A.list = d_list; A.conn = d_conn; A.perm = d_perm; A.xyz = d_xyz;
