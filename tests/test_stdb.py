@@ -181,3 +181,35 @@ def test_plumbing_bdf_to_stdb_to_results(built_libs, oracle, tmp_path):
     assert disp[:, 2].max() > 0 and abs(disp[cube_bcs(n)[0]]).max() == 0
     # the EList the reference serializes after AssignDOF is present too
     assert r.serialize() == m.serialize()
+
+
+def test_results_file_streams_through_the_flush_boundary(built_libs, tmp_path):
+    """the result payload is ~1.7 KB per element (2 x 2 MatrixST of
+    8x6, unpacked doubles); the writer streams entries instead of building one buffer
+    (protobuf-net's MemoryStream caps the reference at 2 GB).  24^3 = 13 824 elements ->
+    ~27 MB, several 1 MiB flushes; file == in-memory serialisation, and it reads back."""
+    import time
+    n = 24
+    d, xyz, conn = _cube_db(n)
+    d.assign_dof()
+    rng = np.random.default_rng(0)
+    disp = rng.standard_normal((xyz.shape[0], 3))
+    strain = rng.standard_normal((n ** 3, 8, 6))
+    stress = rng.standard_normal((n ** 3, 8, 6))
+    d.set_results(disp, strain, stress)
+    path = str(tmp_path / "big.STdb")
+    t0 = time.perf_counter()
+    d.write_stdb(path)
+    t1 = time.perf_counter()
+    size = os.path.getsize(path)
+    assert size > 20e6
+    assert open(path, "rb").read() == d.serialize()
+    r = host.Db.read_stdb(path)
+    t2 = time.perf_counter()
+    d1, e1, s1 = r.results(1)
+    assert np.array_equal(d1, disp) and np.array_equal(e1, strain) and np.array_equal(s1, stress)
+    assert (t1 - t0) < 10 and (t2 - t1) < 10      # ~100 MB/s or better on one core
+    # packed encoding is ~10 % smaller and reads back identically
+    d.write_stdb(path, packed=True)
+    assert os.path.getsize(path) < 0.95 * size
+    assert host.Db.read_stdb(path).serialize() == d.serialize()
