@@ -80,6 +80,9 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
                                   while the halo is exchanged, then the boundary slices */
 #define STAN_OPT_ASSEMBLY_MODE 5 /* 0 (default): row-owner gather; 1: one element per wavefront +
                                    colour-ordered scatter (the north-star variant, single rank) */
+#define STAN_OPT_CG_FUSED_REFRESH 6 /* 1 (default): on refresh iterations A x and A p come from ONE
+                                     matrix pass and r = b - (A x + a A p); 0: ALGLIB's literal
+                                     second product A (x + a p).  Same value up to rounding. */
 #define STAN_OPT_SPMV_VARIANT 3 /* tuning variants of the SpMV kernel (cg.hip), A/B runs only */
 int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value);
 

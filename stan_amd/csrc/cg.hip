@@ -254,6 +254,55 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
     }
 }
 
+// Two right-hand sides in ONE pass over the matrix: y = A x and y2 = A x2 (+ the x.y partial).
+// Used on the residual-refresh iterations: r = b - A(x + a p) = b - (A x + a A p), so the
+// refresh needs A x next to the A p every iteration needs -- one matrix stream instead of two.
+template <typename VT>
+__global__ void __launch_bounds__(256)
+k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
+        const int32_t *__restrict__ cols, const VT *__restrict__ vals,
+        const double *__restrict__ x, const double *__restrict__ x2, double *__restrict__ y,
+        double *__restrict__ y2, double *partial, const int64_t *st, int64_t kiter,
+        const int32_t *__restrict__ slist, int32_t nlist, int32_t poff) {
+    __shared__ double sh[4];
+    if (stopped(st, kiter)) return;
+    const int lane = threadIdx.x & 63;
+    int64_t slice = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slist) slice = slice < nlist ? (int64_t)slist[slice] : (int64_t)nslices;
+    double y0 = 0, y1 = 0, yy2 = 0, z0 = 0, z1 = 0, z2 = 0;
+    const int64_t row = slice * 64 + lane;
+    if (slice < nslices) {
+        const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
+        const int32_t *cp = cols + (int64_t)k0 * 64 + lane;
+        const VT *vp = vals + (int64_t)k0 * 9 * 64 + lane;
+#pragma unroll 2
+        for (int32_t k = k0; k < k1; k++) {
+            const int64_t c = ld_stream(cp, true);
+            double a[9];
+#pragma unroll
+            for (int j = 0; j < 9; j++) a[j] = (double)ld_stream(vp + j * 64, true);
+            const double x0 = x[3 * c], x1 = x[3 * c + 1], xx2 = x[3 * c + 2];
+            const double u0 = x2[3 * c], u1 = x2[3 * c + 1], u2 = x2[3 * c + 2];
+            y0 += a[0] * x0 + a[1] * x1 + a[2] * xx2;
+            y1 += a[3] * x0 + a[4] * x1 + a[5] * xx2;
+            yy2 += a[6] * x0 + a[7] * x1 + a[8] * xx2;
+            z0 += a[0] * u0 + a[1] * u1 + a[2] * u2;
+            z1 += a[3] * u0 + a[4] * u1 + a[5] * u2;
+            z2 += a[6] * u0 + a[7] * u1 + a[8] * u2;
+            cp += 64;
+            vp += 9 * 64;
+        }
+        if (row < nloc) {
+            y[3 * row] = y0; y[3 * row + 1] = y1; y[3 * row + 2] = yy2;
+            y2[3 * row] = z0; y2[3 * row + 1] = z1; y2[3 * row + 2] = z2;
+        }
+    }
+    double d = 0;
+    if (slice < nslices && row < nloc) d = y0 * x[3 * row] + y1 * x[3 * row + 1] + yy2 * x[3 * row + 2];
+    const double t = block_sum(d, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x + poff] = t;
+}
+
 // ---- CG step kernels ----------------------------------------------------------------------------
 struct step_args {
     int64_t n3;           // 3 * owned block rows
@@ -267,7 +316,9 @@ struct step_args {
     const double *v;      // A^ p
     const double *bh;
     double *partial;      // [blocks][2]: r2, merit
-    int refresh;          // 1: only cx is formed here (residual recomputed from A^ cx)
+    const double *w;      // A^ x (fused refresh)
+    int refresh;          // 0: r -= a v; 1: only cx is formed here (r from a second SpMV);
+                          // 2: fused refresh, r = b^ - (w + a v) with w = A^ x from the same pass
 };
 
 __global__ void __launch_bounds__(VEC_T) k_step(step_args a) {
@@ -294,14 +345,21 @@ __global__ void __launch_bounds__(VEC_T) k_step(step_args a) {
         const double pi = a.p[i];
         const double cx = a.xcur[i] + alpha * pi;
         a.xnext[i] = cx;
-        if (!a.refresh) {
+        if (a.refresh == 0) {
             const double cr = a.r[i] - alpha * a.v[i];
             a.r[i] = cr;
             s_r2 += cr * cr;
             s_mf -= (cr + a.bh[i]) * cx;
+        } else if (a.refresh == 2) {
+            const double b = a.bh[i];
+            const double mv = a.w[i] + alpha * a.v[i];  // A^ (x + a p)
+            const double cr = b - mv;
+            a.r[i] = cr;
+            s_r2 += cr * cr;
+            s_mf += (mv - 2 * b) * cx;
         }
     }
-    if (!a.refresh) {
+    if (a.refresh != 1) {
         const double t0 = block_sum(s_r2, sh);
         const double t1 = block_sum(s_mf, sh);
         if (threadIdx.x == 0) {
@@ -466,6 +524,20 @@ unsigned launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double
     return grid;
 }
 
+template <typename VT>
+unsigned launch_spmv2(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double *x, const double *x2,
+                      double *y, double *y2, double *partial, const int64_t *st, int64_t k, int which,
+                      hipStream_t stream) {
+    const int32_t *slist = which == 1 ? K->d_sl_int : which == 2 ? K->d_sl_bnd : nullptr;
+    const int32_t nlist = which == 1 ? K->n_sl_int : which == 2 ? K->n_sl_bnd : K->nslices;
+    const int32_t poff = which == 2 ? (int32_t)nblk(K->n_sl_int, 4) : 0;
+    const unsigned grid = nblk(nlist, 4);
+    if (grid == 0) return 0;
+    hipLaunchKernelGGL((k_spmv2<VT>), dim3(grid), dim3(256), 0, stream, K->nslices, K->nloc, K->d_slot_ptr,
+                       K->d_cols, vals, x, x2, y, y2, partial, st, k, slist, nlist, poff);
+    return grid;
+}
+
 }  // namespace
 
 // Diagonal scaling of the matrix (once per matrix): A^ = S K S.
@@ -533,13 +605,14 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     const int64_t ng = 3 * ((npad > K->nloc + K->nhalo ? npad : K->nloc + K->nhalo));
     const int64_t dof0 = 3 * K->r0;
     dev_bufs bufs;
-    double *xb[2], *p, *r, *v, *bh, *partial, *sc;
+    double *xb[2], *p, *r, *v, *w, *bh, *partial, *sc;
     int64_t *stt;
     STANCHK(alloc(ctx, bufs, &xb[0], (size_t)ng));
     STANCHK(alloc(ctx, bufs, &xb[1], (size_t)ng));
     STANCHK(alloc(ctx, bufs, &p, (size_t)ng));
     STANCHK(alloc(ctx, bufs, &r, (size_t)n3));
     STANCHK(alloc(ctx, bufs, &v, (size_t)n3));
+    STANCHK(alloc(ctx, bufs, &w, (size_t)n3));
     STANCHK(alloc(ctx, bufs, &bh, (size_t)n3));
     const unsigned spmv_blocks = nblk(K->nslices, 4);
     const size_t npart = 2 * (size_t)(spmv_blocks > VEC_BLOCKS ? spmv_blocks : VEC_BLOCKS) + 16;
@@ -606,6 +679,35 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         return STAN_OK;
     };
 
+    // v = A^ x and w = A^ x2 in one matrix pass (fused residual refresh)
+    auto spmv2 = [&](double *x, double *x2, int64_t k) -> int {
+        if (ctx->profiling) {
+            hipEvent_t a, b;
+            hipEventCreate(&a); hipEventCreate(&b);
+            hipEventRecord(a, st_);
+            spmv_ev.push_back(a); spmv_ev.push_back(b);
+        }
+        auto go = [&](int which, hipStream_t s) -> unsigned {
+            return mixed ? launch_spmv2<float>(ctx, K, K->d_vals32, x, x2, v, w, partial, stt, k, which, s)
+                         : launch_spmv2<double>(ctx, K, K->d_vals, x, x2, v, w, partial, stt, k, which, s);
+        };
+        if (split) {
+            HIPCHK(ctx, hipEventRecord(ctx->ev_a, st_));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_a, 0));
+            spmv_parts = go(1, ctx->side);
+            HIPCHK(ctx, hipEventRecord(ctx->ev_b, ctx->side));
+            STANCHK(stan_comm_halo_exchange(ctx, K, x));
+            STANCHK(stan_comm_halo_exchange(ctx, K, x2));
+            HIPCHK(ctx, hipStreamWaitEvent(st_, ctx->ev_b, 0));
+            spmv_parts += go(2, st_);
+        } else {
+            if (dist) { STANCHK(stan_comm_halo_exchange(ctx, K, x)); STANCHK(stan_comm_halo_exchange(ctx, K, x2)); }
+            spmv_parts = go(0, st_);
+        }
+        if (ctx->profiling) hipEventRecord(spmv_ev.back(), st_);
+        return STAN_OK;
+    };
+
     int64_t *h_st = ctx->h_status + 16;  // pinned
     hipEvent_t poll[2];
     hipEventCreateWithFlags(&poll[0], hipEventDisableTiming);
@@ -621,7 +723,9 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     while (!done && rc == STAN_OK) {
         // enqueue one chunk of iterations
         for (int c = 0; c < CHUNK && k < hard_cap; c++, k++) {
-            rc = spmv(p, v, true, k);
+            const bool refresh = ctx->cg_rupdate > 0 && (k % ctx->cg_rupdate) == 0;
+            const bool fused = refresh && ctx->cg_fused_refresh;
+            rc = fused ? spmv2(p, xb[(k - 1) & 1], k) : spmv(p, v, true, k);
             if (rc) break;
             hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st_, partial, (int)spmv_parts, 1,
                                sc + S_VMV);
@@ -629,10 +733,10 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             step_args a;
             a.n3 = n3; a.k = k; a.sc = sc; a.st = stt;
             a.xcur = xb[(k - 1) & 1]; a.xnext = xb[k & 1];
-            a.r = r; a.p = p; a.v = v; a.bh = bh; a.partial = partial;
-            a.refresh = ctx->cg_rupdate > 0 && (k % ctx->cg_rupdate) == 0;
+            a.r = r; a.p = p; a.v = v; a.w = w; a.bh = bh; a.partial = partial;
+            a.refresh = refresh ? (fused ? 2 : 1) : 0;
             hipLaunchKernelGGL(k_step, dim3(vg), dim3(VEC_T), 0, st_, a);
-            if (a.refresh) {
+            if (a.refresh == 1) {
                 // a -5/-4 stop of this iteration is caught by k_refresh/k_update (ITER_B <= k)
                 rc = spmv(xb[k & 1], v, false, k);
                 if (rc) break;

@@ -58,6 +58,7 @@ struct stan_ctx {
     // solver options (include/stan_hip.h STAN_OPT_*)
     bool cg_merit_stop = true;
     int cg_rupdate = 10;
+    bool cg_fused_refresh = true;  // A x and A p of a refresh iteration in one matrix pass
     bool overlap_halo = true;  // interior SpMV on a side stream while the halo is exchanged
     hipStream_t side = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;

@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("STAN_HIP_LIB") or os.path.join(_HERE, "lib", "libstan
 HEX8_G1, HEX8_G2 = 1, 2
 PREC_FP64, PREC_MIXED = 0, 1
 OPT_CG_MERIT_STOP, OPT_CG_RUPDATE, OPT_SPMV_VARIANT, OPT_OVERLAP_HALO, OPT_ASSEMBLY_MODE = 1, 2, 3, 4, 5
+OPT_CG_FUSED_REFRESH = 6
 E_HIP, E_ARG, E_ALLOC, E_DETJ, E_DOF_LAYOUT, E_VALENCE, E_COMM, E_UNSUPPORTED = (
     -1, -2, -3, -4, -5, -6, -7, -8)
 

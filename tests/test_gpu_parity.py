@@ -508,3 +508,23 @@ def test_colour_scatter_assembly_mode_parity(built_libs, oracle, case):
     Uo, _ = oracle.cg(A, job.F, 1e-10)
     assert np.abs(U - Uo).max() <= 20 * U_TOL * np.abs(Uo).max()
     K.free(); K2.free(); ctx.close()
+
+
+def test_fused_refresh_equals_literal_refresh(gpu_ctx, oracle):
+    """Refresh iterations: r = b - (A x + a A p) from one matrix pass (default) against ALGLIB's
+    literal second product b - A (x + a p): the same numbers up to rounding."""
+    from stan_amd import hip
+    job = problem.cube_job(14, jitter=0.05)
+    K, A = _assemble_both(gpu_ctx, oracle, job)
+    out = {}
+    for fused in (1, 0):
+        gpu_ctx.set_option(hip.OPT_CG_FUSED_REFRESH, fused)
+        out[fused] = K.cg_solve(job.F, 1e-7)
+    gpu_ctx.set_option(hip.OPT_CG_FUSED_REFRESH, 1)
+    (U1, r1), (U0, r0) = out[1], out[0]
+    Uo, repo = oracle.cg(A, job.F, 1e-7)
+    assert r1["terminationtype"] == r0["terminationtype"] == repo["terminationtype"] == 1
+    assert abs(r1["iterations"] - r0["iterations"]) <= 2 and abs(r0["iterations"] - repo["iterations"]) <= 3
+    assert np.abs(U1 - U0).max() <= 1e-6 * np.abs(U0).max()
+    assert np.abs(U1 - Uo).max() <= 1e-5 * np.abs(Uo).max()
+    K.free()
