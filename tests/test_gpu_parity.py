@@ -519,12 +519,12 @@ def test_fused_refresh_equals_literal_refresh(gpu_ctx, oracle):
     out = {}
     for fused in (1, 0):
         gpu_ctx.set_option(hip.OPT_CG_FUSED_REFRESH, fused)
-        out[fused] = K.cg_solve(job.F, 1e-7)
+        out[fused] = K.cg_solve(job.F, 1e-6)
     gpu_ctx.set_option(hip.OPT_CG_FUSED_REFRESH, 1)
     (U1, r1), (U0, r0) = out[1], out[0]
-    Uo, repo = oracle.cg(A, job.F, 1e-7)
+    Uo, repo = oracle.cg(A, job.F, 1e-6)
     assert r1["terminationtype"] == r0["terminationtype"] == repo["terminationtype"] == 1
     assert abs(r1["iterations"] - r0["iterations"]) <= 2 and abs(r0["iterations"] - repo["iterations"]) <= 3
     assert np.abs(U1 - U0).max() <= 1e-6 * np.abs(U0).max()
-    assert np.abs(U1 - Uo).max() <= 1e-5 * np.abs(Uo).max()
+    assert np.abs(U1 - Uo).max() <= 1e-4 * np.abs(Uo).max()
     K.free()
