@@ -317,6 +317,7 @@ struct step_args {
     const double *bh;
     double *partial;      // [blocks][2]: r2, merit
     const double *w;      // A^ x (fused refresh)
+    int merit;            // 0: the merit-function stop is off, skip its sum (and the b^ read)
     int refresh;          // 0: r -= a v; 1: only cx is formed here (r from a second SpMV);
                           // 2: fused refresh, r = b^ - (w + a v) with w = A^ x from the same pass
 };
@@ -349,7 +350,7 @@ __global__ void __launch_bounds__(VEC_T) k_step(step_args a) {
             const double cr = a.r[i] - alpha * a.v[i];
             a.r[i] = cr;
             s_r2 += cr * cr;
-            s_mf -= (cr + a.bh[i]) * cx;
+            if (a.merit) s_mf -= (cr + a.bh[i]) * cx;
         } else if (a.refresh == 2) {
             const double b = a.bh[i];
             const double mv = a.w[i] + alpha * a.v[i];  // A^ (x + a p)
@@ -735,6 +736,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             a.xcur = xb[(k - 1) & 1]; a.xnext = xb[k & 1];
             a.r = r; a.p = p; a.v = v; a.w = w; a.bh = bh; a.partial = partial;
             a.refresh = refresh ? (fused ? 2 : 1) : 0;
+            a.merit = ctx->cg_merit_stop ? 1 : 0;
             hipLaunchKernelGGL(k_step, dim3(vg), dim3(VEC_T), 0, st_, a);
             if (a.refresh == 1) {
                 // a -5/-4 stop of this iteration is caught by k_refresh/k_update (ITER_B <= k)
