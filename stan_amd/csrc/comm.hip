@@ -20,7 +20,7 @@
 namespace {
 
 struct nccl_uid { char internal[128]; };
-constexpr int NCCL_SUM = 0, NCCL_INT64 = 4, NCCL_F64 = 8;
+constexpr int NCCL_SUM = 0, NCCL_F64 = 8;
 
 typedef int (*fn_commInitRank)(void **, int, nccl_uid, int);
 
@@ -118,12 +118,6 @@ extern "C" int stan_hip_comm_init(stan_ctx *ctx, int rank, int nranks, const cha
 int stan_comm_allreduce_sum_f64(stan_ctx *ctx, double *d_buf, size_t count) {
     if (!ctx->comm) return no_comm(ctx);
     NCCLCHK(ctx, ctx->nccl.AllReduce(d_buf, d_buf, count, NCCL_F64, NCCL_SUM, ctx->comm, ctx->stream));
-    return STAN_OK;
-}
-
-int stan_comm_allreduce_sum_i64(stan_ctx *ctx, int64_t *d_buf, size_t count) {
-    if (!ctx->comm) return no_comm(ctx);
-    NCCLCHK(ctx, ctx->nccl.AllReduce(d_buf, d_buf, count, NCCL_INT64, NCCL_SUM, ctx->comm, ctx->stream));
     return STAN_OK;
 }
 

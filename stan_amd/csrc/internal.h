@@ -143,7 +143,6 @@ int stan_recover_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz, con
 
 // ---- comm.cpp -------------------------------------------------------------------------------
 int stan_comm_allreduce_sum_f64(stan_ctx *ctx, double *d_buf, size_t count);
-int stan_comm_allreduce_sum_i64(stan_ctx *ctx, int64_t *d_buf, size_t count);
 // exchange: pack rows listed in K->d_send_rows from d_vec (3 doubles per block row) and
 // receive into d_vec + 3*nloc (halo region).
 int stan_comm_halo_exchange(stan_ctx *ctx, stan_matrix *K, double *d_vec);
