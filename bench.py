@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--eps", type=float, default=1e-8)
     ap.add_argument("--mixed", action="store_true", help="fp32 matrix / fp64 vectors")
     ap.add_argument("--etype", type=int, default=2, help="2 = HEX8_G2, 1 = HEX8_G1")
-    ap.add_argument("--cpu-n", type=int, default=40, help="cube edge of the CPU-baseline sample")
+    ap.add_argument("--cpu-n", type=int, default=56, help="cube edge of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
