@@ -7,7 +7,8 @@
 // (SolverFunctions.cs:18-20 throws when stdout is redirected) and no 10 s sleep at exit
 // (Solver.cs:67-68).  LinSolver "Cholesky"/"LU" (SolverFunctions.cs:332-516) are outside the
 // hot path: the driver reports them as unsupported instead of silently using CG.
-// Extra switches (never stored in the STdb): --device N, --mixed, --no-merit-stop, --packed.
+// Extra switches (never stored in the STdb): --device N, --mixed, --no-merit-stop, --packed,
+// --json (one JSON line with sizes, iterations, phase times and the SpMV's HBM rate).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -42,12 +43,13 @@ static int fail(const char *what, const std::string &msg) {
 int main(int argc, char **argv) {
     std::string path;
     int device = 0, precision = STAN_PREC_FP64;
-    bool merit_stop = true, packed = false;
+    bool merit_stop = true, packed = false, json = false;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--mixed")) precision = STAN_PREC_MIXED;
         else if (!strcmp(argv[i], "--no-merit-stop")) merit_stop = false;
         else if (!strcmp(argv[i], "--packed")) packed = true;
+        else if (!strcmp(argv[i], "--json")) json = true;
         else path = argv[i];
     }
     if (path.empty()) {  // Path = path[0] -> IndexOutOfRangeException in the reference
@@ -84,6 +86,10 @@ int main(int argc, char **argv) {
         stan_ctx *ctx = nullptr;
         if (stan_hip_init(device, &ctx)) return fail("stan_hip_init", stan_hip_last_error(nullptr));
         stan_hip_set_option(ctx, STAN_OPT_CG_MERIT_STOP, merit_stop ? 1 : 0);
+        if (json) stan_hip_set_profiling(ctx, 1);
+        double t_asm = 0, t_cg = 0;
+        int32_t cg_type = 0, cg_its = 0;
+        double cg_rel = 0;
 
         printf("   K Matrix assembly: ");  // SolverFunctions.cs:127
         fflush(stdout);
@@ -94,7 +100,10 @@ int main(int argc, char **argv) {
                                    (int32_t)(fm.mat_E_nu.size() / 2), fm.mat_E_nu.data(), DB.nDOF,
                                    red.data(), &K))
             return fail("ParallelAssembly_K", stan_hip_last_error(ctx));
-        printf("          Done in %.2fs\n", secs(t0));
+        t_asm = secs(t0);
+        printf("          Done in %.2fs\n", t_asm);
+        stan_matrix_info minfo;
+        stan_hip_matrix_info(K, &minfo);
 
         std::vector<double> U((size_t)(DB.nDOF - n_fixed), 0.0);
         const std::string &ls = DB.AnalysisLib.LinSolver;
@@ -108,7 +117,9 @@ int main(int argc, char **argv) {
                                   DB.AnalysisLib.LinSolverIterMax, precision, U.data(), &type, &its, &rel))
                 return fail("LinearSolver_CG", stan_hip_last_error(ctx));
             printf(type == 1 || type == 7 ? "  NORMAL " : "  ERROR ");  // SolverFunctions.cs:323-327
-            printf(" (type %d) in %.2fs\n", type, secs(t0));
+            t_cg = secs(t0);
+            cg_type = type; cg_its = its; cg_rel = rel;
+            printf(" (type %d) in %.2fs\n", type, t_cg);
             printf("   CG iterations: %d, scaled relative residual %.3e\n", its, rel);
         } else if (ls == "Cholesky" || ls == "LU") {
             return fail("solver selection", "LinSolver '" + ls + "' is a direct solver outside the GPU hot path");
@@ -128,6 +139,17 @@ int main(int argc, char **argv) {
                                   strain.data(), stress.data()))
             return fail("Recovery_Stress", stan_hip_last_error(ctx));  // G1: the reference throws here too
         printf("            Done\n");
+        if (json) {  // one machine-readable line per run (metrics/logging)
+            stan_profile pr;
+            stan_hip_get_profile(ctx, &pr);
+            const double spmv_ms = pr.spmv_launches ? pr.spmv_ms_total / (double)pr.spmv_launches : 0;
+            printf("{\"n_dof\": %d, \"n_reduced\": %lld, \"blocks_3x3\": %lld, \"cg_iterations\": %d, "
+                   "\"termination_type\": %d, \"rel_residual\": %.3e, \"t_assembly_s\": %.4f, \"t_cg_s\": %.4f, "
+                   "\"spmv_ms\": %.4f, \"spmv_GBs\": %.1f, \"hbm_frac\": %.3f}\n",
+                   DB.nDOF, (long long)minfo.n_reduced, (long long)minfo.n_blocks, cg_its, cg_type, cg_rel, t_asm,
+                   t_cg, spmv_ms, spmv_ms > 0 ? pr.spmv_bytes / spmv_ms / 1e6 : 0.0,
+                   spmv_ms > 0 ? pr.spmv_bytes / spmv_ms / 1e6 / 8000.0 : 0.0);
+        }
         stan_hip_destroy(ctx);
 
         // Solver.cs:81-90 (initialise step 0/1), :203-210 (update), Main :56

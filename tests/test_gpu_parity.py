@@ -305,9 +305,13 @@ def test_native_console_driver_end_to_end(built_libs, oracle, tmp_path):
     d.set_analysis(tol=1e-12)
     path = str(tmp_path / "model.STdb")
     d.write_stdb(path)
-    out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([exe, "--json", path], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "NORMAL" in out.stdout and "Stress recovery" in out.stdout
+    import json
+    summary = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert summary["n_dof"] == 3 * (n + 1) ** 3 and summary["termination_type"] in (1, 7)
+    assert summary["cg_iterations"] > 0 and summary["spmv_ms"] > 0
     r = host.Db.read_stdb(path)
     assert r.sizes()["result_step"] == 1
     disp, strain, stress = r.results(1)
