@@ -203,7 +203,11 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch": prof["spmv_bytes"], "avg_launch_ms": avg_ms,
-                         "launches": int(spmv_n)},
+                         "launches": int(spmv_n),
+                         # refresh iterations: A p and A x from one matrix pass (not in the average)
+                         "two_product_launches": int(prof["spmv2_launches"]),
+                         "two_product_avg_ms": (prof["spmv2_ms_total"] / prof["spmv2_launches"]
+                                                if prof["spmv2_launches"] else None)},
         }
         if not args.no_cpu and world == 1:
             base, _, _ = cpu_baseline(args.cpu_n, args.eps)

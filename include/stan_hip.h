@@ -213,6 +213,8 @@ typedef struct stan_profile {
     int32_t termination_type;
     int32_t assembly_colours; /* element colours of the last mode-1 assembly */
     int32_t reserved;
+    double spmv2_ms_total;    /* two-product launches of the refresh iterations (k_spmv2),  */
+    int64_t spmv2_launches;   /* NOT included in spmv_ms_total / spmv_launches              */
 } stan_profile;
 int stan_hip_set_profiling(stan_ctx *ctx, int32_t enabled);
 int stan_hip_get_profile(stan_ctx *ctx, stan_profile *out);

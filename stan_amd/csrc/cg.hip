@@ -647,7 +647,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
     }
-    std::vector<hipEvent_t> spmv_ev;
+    std::vector<hipEvent_t> spmv_ev, spmv2_ev;
     unsigned spmv_parts = 0;
     // y = A^ x (x gets its halo filled first when sharded); returns 0 or an error code
     auto spmv = [&](double *x, double *y, bool dot, int64_t k) -> int {
@@ -686,7 +686,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             hipEvent_t a, b;
             hipEventCreate(&a); hipEventCreate(&b);
             hipEventRecord(a, st_);
-            spmv_ev.push_back(a); spmv_ev.push_back(b);
+            spmv2_ev.push_back(a); spmv2_ev.push_back(b);
         }
         auto go = [&](int which, hipStream_t s) -> unsigned {
             return mixed ? launch_spmv2<float>(ctx, K, K->d_vals32, x, x2, v, w, partial, stt, k, which, s)
@@ -705,7 +705,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             if (dist) { STANCHK(stan_comm_halo_exchange(ctx, K, x)); STANCHK(stan_comm_halo_exchange(ctx, K, x2)); }
             spmv_parts = go(0, st_);
         }
-        if (ctx->profiling) hipEventRecord(spmv_ev.back(), st_);
+        if (ctx->profiling) hipEventRecord(spmv2_ev.back(), st_);
         return STAN_OK;
     };
 
@@ -809,6 +809,15 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         ctx->prof.spmv_ms_total = tot;
         ctx->prof.spmv_launches = (int64_t)(spmv_ev.size() / 2);
         for (hipEvent_t ev : spmv_ev) hipEventDestroy(ev);
+        double tot2 = 0;
+        for (size_t i = 0; i + 1 < spmv2_ev.size(); i += 2) {
+            float t = 0;
+            hipEventElapsedTime(&t, spmv2_ev[i], spmv2_ev[i + 1]);
+            tot2 += t;
+        }
+        ctx->prof.spmv2_ms_total = tot2;
+        ctx->prof.spmv2_launches = (int64_t)(spmv2_ev.size() / 2);
+        for (hipEvent_t ev : spmv2_ev) hipEventDestroy(ev);
         hipEventDestroy(ev0); hipEventDestroy(ev1);
         ctx->prof.iterations = (int32_t)its;
         ctx->prof.termination_type = type;

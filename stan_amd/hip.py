@@ -46,7 +46,7 @@ class Profile(C.Structure):
                 ("spmv_launches", C.c_int64), ("spmv_bytes", C.c_int64),
                 ("cg_iteration_vector_bytes", C.c_int64), ("iterations", C.c_int32),
                 ("termination_type", C.c_int32), ("assembly_colours", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("reserved", C.c_int32), ("spmv2_ms_total", C.c_double), ("spmv2_launches", C.c_int64)]
 
 
 class StanHipError(RuntimeError):
