@@ -21,11 +21,11 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def built_libs():
-    """Make sure the in-tree shared libraries exist (hipcc cross-compiles without a GPU)."""
+    """Bring the in-tree shared libraries and the console driver up to date (make is a no-op
+    when they are; hipcc cross-compiles without a GPU) -- a stale binary against a changed
+    header is worse than a missing one."""
     import __graft_entry__ as g
-    from stan_amd import hip, host
-    if not (os.path.exists(hip.LIB_PATH) and os.path.exists(host.LIB_PATH)):
-        g.build()
+    g.build()
     return True
 
 
