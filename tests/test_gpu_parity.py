@@ -581,3 +581,24 @@ def test_full_size_cube_properties(gpu_ctx):
     print("mixed-precision relative deviation at 148^3: %.2e" % mixed_err)
     assert mixed_err <= 2e-2
     K.free(); K2.free()
+
+
+def test_more_ranks_than_slices(built_libs):
+    """A 27-node mesh cut for 8 ranks: rank 7 owns the only slice, the others own nothing and
+    must still assemble (empty shard) without an error."""
+    import torch  # noqa: F401
+    from stan_amd import hip, host
+    job = problem.cube_job(2)
+    ctx = hip.Context(0)
+    owned = []
+    for r in range(8):
+        ctx.comm_init(r, 8, None)
+        K = ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type,
+                              job.mat_E_nu, job.red)
+        i = K.info()
+        owned.append(i["row_end"] - i["row_begin"])
+        ref = host.partition_plan(job.node_index, job.conn, 8, r)
+        assert np.array_equal(K.plan()["halo_glob"], ref["halo_glob"]) and i["n_halo"] == 0
+        K.free()
+    assert sum(owned) == 27 and owned.count(0) == 7
+    ctx.close()
