@@ -161,6 +161,10 @@ def cg(crs, b, epsf, maxits=0, merit_stop=True, rupdate=10):
                    rel_residual=rel.value)
 
 
+def set_mv_threads(n):
+    lib().stan_oracle_set_mv_threads(C.c_int(int(n)))
+
+
 def include_bc(red, U):
     red = np.ascontiguousarray(red, dtype=np.int32)
     U = np.ascontiguousarray(U, dtype=np.float64)

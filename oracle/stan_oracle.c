@@ -591,6 +591,53 @@ void stan_oracle_smv_upper(const stan_oracle_crs *A, const double *x, double *y)
     }
 }
 
+/* ---- optional all-cores mode of the CG's matrix-vector product (NOT what the reference does:
+ * alglib's sparsesmv is serial; this only provides the second, clearly labelled CPU number of
+ * BASELINE.md section 2).  The symmetric matrix is expanded to full CRS once and rows are
+ * gathered in parallel. */
+static int g_mv_threads = 1;
+void stan_oracle_set_mv_threads(int n) { g_mv_threads = n > 1 ? n : 1; }
+
+typedef struct { int64_t *rp; int32_t *ci; double *v; } full_crs;
+static void full_from_upper(const stan_oracle_crs *A, full_crs *F) {
+    int64_t n = A->n;
+    F->rp = calloc((size_t)n + 1, sizeof(int64_t));
+    for (int64_t i = 0; i < n; i++)
+        for (int64_t q = A->ridx[i]; q < A->ridx[i + 1]; q++) {
+            F->rp[i + 1]++;
+            if (A->idx[q] != i) F->rp[(int64_t)A->idx[q] + 1]++;
+        }
+    for (int64_t i = 0; i < n; i++) F->rp[i + 1] += F->rp[i];
+    F->ci = malloc(sizeof(int32_t) * (size_t)(F->rp[n] ? F->rp[n] : 1));
+    F->v = malloc(sizeof(double) * (size_t)(F->rp[n] ? F->rp[n] : 1));
+    int64_t *fill = malloc(sizeof(int64_t) * (size_t)(n ? n : 1));
+    memcpy(fill, F->rp, sizeof(int64_t) * (size_t)n);
+    /* pass 1: transposed strictly-upper entries (row order => ascending columns), pass 2: upper */
+    for (int64_t i = 0; i < n; i++)
+        for (int64_t q = A->ridx[i]; q < A->ridx[i + 1]; q++)
+            if (A->idx[q] != i) {
+                int64_t j = A->idx[q];
+                F->ci[fill[j]] = (int32_t)i;
+                F->v[fill[j]++] = A->vals[q];
+            }
+    for (int64_t i = 0; i < n; i++)
+        for (int64_t q = A->ridx[i]; q < A->ridx[i + 1]; q++) {
+            F->ci[fill[i]] = A->idx[q];
+            F->v[fill[i]++] = A->vals[q];
+        }
+    free(fill);
+}
+static void full_mv(const full_crs *F, int64_t n, const double *x, double *y) {
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(g_mv_threads) schedule(static)
+#endif
+    for (int64_t i = 0; i < n; i++) {
+        double a = 0;
+        for (int64_t q = F->rp[i]; q < F->rp[i + 1]; q++) a += F->v[q] * x[F->ci[q]];
+        y[i] = a;
+    }
+}
+
 /* SolverFunctions.cs:270-330 -> alglib.lincg* (3.16.0), restated from the
  * published algorithm: diagonal preconditioner applied as symmetric scaling,
  * x0 = 0, residual refresh every 10 iterations, merit-function stop. */
@@ -622,10 +669,14 @@ int stan_oracle_cg_opt(const stan_oracle_crs *A, const double *b_in, double epsf
     }
     for (int64_t i = 0; i < n; i++) b[i] = b_in[i] * s[i];
     int nmv = 0, its = 0, term = 0;
+    const int use_full = g_mv_threads > 1;
+    full_crs Ffull = {0, 0, 0};
+    if (use_full) full_from_upper(A, &Ffull);
 #define MV(vec, vmv)                                         \
     do {                                                     \
         for (int64_t i_ = 0; i_ < n; i_++) t[i_] = (vec)[i_] * s[i_]; \
-        stan_oracle_smv_upper(A, t, mv);                     \
+        if (use_full) full_mv(&Ffull, n, t, mv);             \
+        else stan_oracle_smv_upper(A, t, mv);                \
         (vmv) = 0;                                           \
         for (int64_t i_ = 0; i_ < n; i_++) {                 \
             mv[i_] *= s[i_];                                 \
@@ -733,6 +784,7 @@ finish:
     if (rel_res) *rel_res = bnorm > 0 ? sqrt(r2) / bnorm : 0;
     free(s); free(b); free(rx); free(cx); free(r); free(cr); free(p); free(z); free(cz);
     free(mv); free(t);
+    if (use_full) { free(Ffull.rp); free(Ffull.ci); free(Ffull.v); }
     return 0;
 }
 

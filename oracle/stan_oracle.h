@@ -92,6 +92,10 @@ int stan_oracle_cg_opt(const stan_oracle_crs *A, const double *b, double epsf, i
                        int merit_stop, int itsbeforerupdate, double *x, int32_t *terminationtype,
                        int32_t *iterations, int32_t *nmv, double *rel_residual_scaled);
 
+/* n > 1: the CG's matrix-vector product runs on n OpenMP threads over an expanded full CRS
+ * (a labelled, fairer CPU number; alglib's own product is serial).  Default 1. */
+void stan_oracle_set_mv_threads(int n);
+
 /* SolverFunctions.cs:520-538 Include_BC_DOF */
 void stan_oracle_include_bc(int64_t n_dof, const int32_t *red, const double *U, double *U_full);
 
