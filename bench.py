@@ -32,13 +32,25 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
+def effective_cores():
+    """CPUs this process may really use: affinity mask and cgroup CPU quota, not os.cpu_count()."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(n, eps):
     """Oracle = port of the reference algorithm (parallel K_e, serial locked scatter into a
     hash table, serial symmetric-upper CG), timed on this host's cores."""
     from oracle import pyoracle as O
     from stan_amd import problem
     job = problem.cube_job(n)
-    threads = min(8, os.cpu_count() or 1)
+    threads = min(8, effective_cores())
     t0 = time.perf_counter()
     rc, A = O.assemble(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type,
                        job.mat_E_nu, job.red, n_threads=threads)
@@ -51,7 +63,7 @@ def cpu_baseline(n, eps):
                       (n, job.n_dof, t1 - t0, threads, eps, t2 - t1, rep["iterations"])}
     # second, labelled number: same arithmetic, the CG's matrix-vector
     # product on all cores (NOT what alglib does)
-    allc = min(64, os.cpu_count() or 1)
+    allc = effective_cores()
     O.set_mv_threads(allc)
     t3 = time.perf_counter()
     U2, rep2 = O.cg(A, job.F, eps, merit_stop=False)
