@@ -191,3 +191,24 @@ def test_recovery_constant_strain(oracle):
     assert np.allclose(e, np.tile(ev, (8, 1)), rtol=1e-10, atol=1e-16)
     assert np.allclose(s, np.tile(D_matrix(210000.0, 0.3) @ ev, (8, 1)), rtol=1e-10)
     assert oracle.recover_hex8(x, 210000.0, 0.3, 1, dU)[0] == -4  # G1 throws in the reference
+
+
+def test_cg_restatement_tracks_textbook_jacobi_pcg(oracle):
+    """The restated lincg (symmetric diagonal scaling + plain CG, residual refresh every 10)
+    is textbook Jacobi-PCG in different variables: SciPy's CG on S K S needs the same number
+    of iterations (+-2 %) for the same scaled-residual tolerance and lands on the same U."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as sla
+    job = problem.cube_job(10, jitter=0.05)
+    rc, A = oracle.assemble(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type,
+                            job.mat_E_nu, job.red)
+    K = A.to_scipy_full()
+    s = 1.0 / np.sqrt(K.diagonal())
+    Ks = sp.diags(s) @ K @ sp.diags(s)
+    its = [0]
+    y, info = sla.cg(Ks, s * job.F, rtol=1e-6, atol=0.0, maxiter=10000,
+                     callback=lambda xk: its.__setitem__(0, its[0] + 1))
+    U, rep = oracle.cg(A, job.F, 1e-6)
+    assert info == 0 and rep["terminationtype"] == 1
+    assert abs(its[0] - rep["iterations"]) <= max(2, rep["iterations"] // 50)
+    assert np.abs(s * y - U).max() <= 1e-5 * np.abs(U).max()
