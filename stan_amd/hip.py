@@ -4,8 +4,8 @@ This is plumbing for tests, bench.py and __graft_entry__: the product is the
 shared library.  There is NO CPU fallback: loading fails loudly if the library
 has not been built, and stan_hip_init fails if no GPU is present.
 
-Import torch BEFORE this module in any process that also uses torch, so that
-both share one HIP runtime (torch bundles its own libamdhip64.so.7).
+load() imports torch first (when installed) so that this library and torch share ONE HIP
+runtime: torch bundles its own libamdhip64.so.7 and librccl.so.1.
 """
 import ctypes as C
 import os
@@ -66,6 +66,14 @@ def load():
             raise RuntimeError(
                 "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback)" % LIB_PATH)
+        # torch bundles its own libamdhip64.so.7 / librccl.so.1.  If this library came first it
+        # would pull in /opt/rocm's copies and a later `import torch` would add a SECOND HIP
+        # runtime to the process (RCCL then fails with "no ROCm-capable device").  Loading
+        # torch first makes both share one runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.stan_hip_last_error.restype = C.c_char_p
         _lib.stan_hip_last_bad_element.restype = C.c_int64
