@@ -198,6 +198,13 @@ int stan_hip_spmv(stan_ctx *ctx, stan_matrix *K, const double *x, double *y);
 int stan_hip_spmv_bench(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode, int32_t reps,
                         double *avg_ms);
 
+/* Measurement aid: the same operator converted on the device to scalar CSR (fp64 values,
+ * int32 columns) and multiplied by a CSR-vector kernel, timed like stan_hip_spmv_bench: the
+ * number next to the BSELL-64 format decision.  max_rel_diff compares its product
+ * with the BSELL-64 one.  Single-rank contexts, matrix in its current (scaled or not) state. */
+int stan_hip_csr_spmv_bench(stan_ctx *ctx, stan_matrix *K, int32_t reps, double *avg_ms,
+                            int64_t *bytes_per_launch, double *max_rel_diff);
+
 /* Per-phase device timings of the most recent assemble / solve, measured with HIP events on
  * the context stream (profiling must be enabled first; it adds one event pair per launch). */
 typedef struct stan_profile {

@@ -29,7 +29,7 @@ EXPORTS = [
     "stan_hip_cg_solve", "stan_hip_cg_solve_dev", "stan_hip_matrix_info", "stan_hip_ke_hex8",
     "stan_hip_ke_hex8_batch", "stan_hip_matrix_to_csr", "stan_hip_spmv", "stan_hip_spmv_bench",
     "stan_hip_set_profiling", "stan_hip_get_profile", "stan_hip_set_option", "stan_hip_recover_hex8", "stan_hip_recover_hex8_dev",
-    "stan_hip_matrix_plan", "stan_hip_spmv_local",
+    "stan_hip_matrix_plan", "stan_hip_spmv_local", "stan_hip_csr_spmv_bench",
 ]
 
 
@@ -315,6 +315,12 @@ class Matrix:
         self.ctx._chk(self.ctx.lib.stan_hip_spmv_local(self.ctx.h, self.k, _ptr(x_local, C.c_double),
                                                        _ptr(y, C.c_double)))
         return y
+
+    def csr_spmv_bench(self, reps=20):
+        ms, nb, diff = C.c_double(0), C.c_int64(0), C.c_double(0)
+        self.ctx._chk(self.ctx.lib.stan_hip_csr_spmv_bench(self.ctx.h, self.k, C.c_int32(reps),
+                                                           C.byref(ms), C.byref(nb), C.byref(diff)))
+        return ms.value, nb.value, diff.value
 
     def spmv_bench(self, reps=20, precision_mode=PREC_FP64):
         ms = C.c_double(0)

@@ -29,6 +29,12 @@ for v in variants:
     print("variant %d: median %.4f ms min %.4f ms -> %.0f GB/s (%.1f%% of 8 TB/s)%s" %
           (v, np.median(t), t.min(), bytes_alg / np.median(t) / 1e6, bytes_alg / np.median(t) / 1e6 / 80, ok))
 
+# the same operator in scalar CSR (fp64 + int32 columns), CSR-vector kernel
+if n <= 160:
+    ms, nbytes, diff = K.csr_spmv_bench(20)
+    print("scalar CSR: %.4f ms for %.3f GB -> %.0f GB/s (%.1f%% of 8 TB/s); product differs from BSELL-64 by %.1e" %
+          (ms, nbytes / 1e9, nbytes / ms / 1e6, nbytes / ms / 1e6 / 80, diff))
+
 # context: what a plain device copy reaches on THIS device (read + write bytes / time)
 a = torch.empty(1 << 29, dtype=torch.float64, device="cuda")   # 4 GiB
 b = torch.empty_like(a)
