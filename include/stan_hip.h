@@ -149,6 +149,17 @@ int stan_hip_recover_hex8_dev(stan_ctx *ctx, int64_t n_nodes, const double *d_xy
                               int32_t n_mat, const double *mat_E_nu, double *d_strain,
                               double *d_stress);
 
+/* ---- element nodal forces: replaces Element.Compute_NodalForces + the R assembly ---------- */
+/* (Element.cs:248-255, Solver.cs:184-196).  f_e = sum_g BL[g]^T dS[g] det J_g w, where dS[g] is
+ * the NODE-extrapolated stress row g that Recovery_Stress left behind -- the reference indexes
+ * its node list by Gauss point number and that is kept.  elem_forces [n_elem*24] (node-major,
+ * = Element.NodalForces) and/or R [n_dof] (R[DOF] += f, full numbering, before Exclude_BC_DOF);
+ * either may be NULL, not both.  The linear-static driver discards R (Solver.cs:199). */
+int stan_hip_nodal_forces_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz, const double *disp,
+                               const int32_t *node_dof, int64_t n_elem, const int32_t *conn,
+                               const int32_t *elem_mat, const uint8_t *elem_type, int32_t n_mat,
+                               const double *mat_E_nu, int64_t n_dof, double *elem_forces, double *R);
+
 /* ---- introspection / parity helpers ------------------------------------------------------- */
 typedef struct stan_matrix_info {
     int64_t n_dof;        /* full DOF count                                      */

@@ -81,6 +81,15 @@ def recover_hex8(xyz8, E, nu, etype, dU):
     return rc, e.reshape(8, 6), s.reshape(8, 6)
 
 
+def nodal_forces_hex8(xyz8, etype, stress_nodes):
+    xyz8 = np.ascontiguousarray(xyz8, dtype=np.float64).reshape(24)
+    sn = np.ascontiguousarray(stress_nodes, dtype=np.float64).reshape(48)
+    f = np.zeros(24)
+    rc = lib().stan_oracle_nodal_forces_hex8(_p(xyz8, C.c_double), etype, _p(sn, C.c_double),
+                                             _p(f, C.c_double))
+    return rc, f
+
+
 def assign_dof(n_nodes, conn):
     conn = np.ascontiguousarray(conn, dtype=np.int32)
     out = np.full(n_nodes, -1, dtype=np.int32)

@@ -290,6 +290,31 @@ int stan_oracle_recover_hex8(const double xyz8[24], const double D[36], int type
     return 0;
 }
 
+/* Element.cs:248-255 Compute_NodalForces, called right after Recovery_Stress (Solver.cs:186-187):
+ *   NodalForces = sum_g (BL[g]^T * dS[g]) * (J[g].Det3() * GaussWeight)
+ * where dS is the list filled by Recovery_Stress, i.e. the NODE-extrapolated stress increments,
+ * indexed here by the Gauss point number (reference quirk, kept: SURVEY.md Appendix B).
+ * stress_nodes = the [8][6] output of stan_oracle_recover_hex8. */
+int stan_oracle_nodal_forces_hex8(const double xyz8[24], int type, const double stress_nodes[48],
+                                  double forces[24]) {
+    if (type == STAN_HEX8_G1) return -4; /* Recovery_Stress has thrown before this is reached */
+    int ngp = type_ngp(type);
+    if (ngp < 0) return -2;
+    double w = type_weight(type);
+    for (int r = 0; r < 24; r++) forces[r] = 0;
+    for (int g = 0; g < ngp; g++) {
+        mst J, BL;
+        if (gauss_point(xyz8, type, g, &J, &BL)) return -1;
+        double sc = mst_det3(&J) * w;
+        for (int r = 0; r < 24; r++) { /* MatrixST.cs:404-418 operator*: inner index ascending */
+            double c = 0;
+            for (int k = 0; k < 6; k++) c += G(&BL, k, r) * stress_nodes[g * 6 + k];
+            forces[r] = forces[r] + c * sc; /* operator+ allocates K + term (MatrixST.cs:327-339) */
+        }
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* Database.cs:140-234 AssignDOF (literal)                                    */
 int stan_oracle_assign_dof(int64_t n_nodes, int64_t n_elem, const int32_t *conn,

@@ -106,6 +106,13 @@ void stan_oracle_include_bc(int64_t n_dof, const int32_t *red, const double *U, 
 int stan_oracle_recover_hex8(const double xyz8[24], const double D[36], int type,
                              const double dU[24], double strain[48], double stress[48]);
 
+/* Element.cs:248-255 Compute_NodalForces for one element, from the node-extrapolated stress
+ * rows stan_oracle_recover_hex8 returned (the reference indexes that node list by Gauss point
+ * number -- kept).  forces: 24, node-major.  The driver sums them into R[DOF] (Solver.cs:189-196)
+ * and discards R in the linear-static path (Solver.cs:199). */
+int stan_oracle_nodal_forces_hex8(const double xyz8[24], int type, const double stress_nodes[48],
+                                  double forces[24]);
+
 #ifdef __cplusplus
 }
 #endif

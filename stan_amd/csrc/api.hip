@@ -191,7 +191,7 @@ int stan_hip_recover_hex8_dev(stan_ctx *ctx, int64_t n_nodes, const double *d_xy
         return STAN_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return stan_recover_device(ctx, n_nodes, d_xyz, d_disp, n_elem, d_conn, d_elem_mat, d_elem_type,
-                               n_mat, mat_E_nu, d_strain, d_stress);
+                               n_mat, mat_E_nu, d_strain, d_stress, nullptr, nullptr, nullptr);
 }
 
 int stan_hip_recover_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz, const double *disp,
@@ -216,11 +216,47 @@ int stan_hip_recover_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz, con
     STANCHK(de.alloc(ctx, (size_t)n_elem * 48));
     STANCHK(ds.alloc(ctx, (size_t)n_elem * 48));
     STANCHK(stan_recover_device(ctx, n_nodes, dx.p, du.p, n_elem, dc.p, dm.p, dt.p, n_mat, mat_E_nu,
-                                de.p, ds.p));
+                                de.p, ds.p, nullptr, nullptr, nullptr));
     if (n_elem) {
         HIPCHK(ctx, hipMemcpyAsync(strain, de.p, (size_t)n_elem * 48 * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(stress, ds.p, (size_t)n_elem * 48 * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return STAN_OK;
+}
+
+int stan_hip_nodal_forces_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz, const double *disp,
+                               const int32_t *node_dof, int64_t n_elem, const int32_t *conn,
+                               const int32_t *elem_mat, const uint8_t *elem_type, int32_t n_mat,
+                               const double *mat_E_nu, int64_t n_dof, double *elem_forces, double *R) {
+    if (!ctx || !xyz || !disp || !node_dof || !mat_E_nu || n_nodes <= 0 || n_mat <= 0 || n_elem < 0 ||
+        n_dof != n_nodes * 3 || (!elem_forces && !R) || (n_elem > 0 && (!conn || !elem_mat || !elem_type)))
+        return STAN_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (int64_t e = 0; e < n_elem; e++) {
+        if (elem_mat[e] < 0 || elem_mat[e] >= n_mat) { ctx->err = "nodal_forces_hex8: elem_mat out of range"; return STAN_E_ARG; }
+        for (int a = 0; a < 8; a++)
+            if (conn[e * 8 + a] < 0 || conn[e * 8 + a] >= n_nodes) { ctx->err = "nodal_forces_hex8: node index out of range"; return STAN_E_ARG; }
+    }
+    for (int64_t k = 0; k < n_dof; k++)
+        if (node_dof[k] < 0 || node_dof[k] >= n_dof) { ctx->err = "nodal_forces_hex8: DOF out of range"; return STAN_E_DOF_LAYOUT; }
+    dbuf<double> dx, du, df, dR; dbuf<int32_t> dc, dm, dd; dbuf<uint8_t> dt;
+    STANCHK(dx.upload(ctx, xyz, (size_t)n_nodes * 3));
+    STANCHK(du.upload(ctx, disp, (size_t)n_nodes * 3));
+    STANCHK(dd.upload(ctx, node_dof, (size_t)n_nodes * 3));
+    STANCHK(dc.upload(ctx, conn, (size_t)n_elem * 8));
+    STANCHK(dm.upload(ctx, elem_mat, (size_t)n_elem));
+    STANCHK(dt.upload(ctx, elem_type, (size_t)n_elem));
+    if (elem_forces) STANCHK(df.alloc(ctx, (size_t)n_elem * 24));
+    if (R) {
+        STANCHK(dR.alloc(ctx, (size_t)n_dof));
+        HIPCHK(ctx, hipMemsetAsync(dR.p, 0, (size_t)n_dof * 8, ctx->stream));
+    }
+    STANCHK(stan_recover_device(ctx, n_nodes, dx.p, du.p, n_elem, dc.p, dm.p, dt.p, n_mat, mat_E_nu,
+                                nullptr, nullptr, dd.p, elem_forces ? df.p : nullptr, R ? dR.p : nullptr));
+    if (elem_forces && n_elem)
+        HIPCHK(ctx, hipMemcpyAsync(elem_forces, df.p, (size_t)n_elem * 24 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (R) HIPCHK(ctx, hipMemcpyAsync(R, dR.p, (size_t)n_dof * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return STAN_OK;
 }

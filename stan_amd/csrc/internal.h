@@ -139,7 +139,8 @@ int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K);
 int stan_recover_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz, const double *d_disp,
                         int64_t n_elem, const int32_t *d_conn, const int32_t *d_elem_mat,
                         const uint8_t *d_elem_type, int32_t n_mat, const double *mat_E_nu,
-                        double *d_strain, double *d_stress);
+                        double *d_strain, double *d_stress, const int32_t *d_node_dof,
+                        double *d_elem_forces, double *d_R);
 
 // ---- comm.cpp -------------------------------------------------------------------------------
 int stan_comm_allreduce_sum_f64(stan_ctx *ctx, double *d_buf, size_t count);

@@ -5,9 +5,12 @@
 //   value_i = sum_g N[i][g] value_g,  N[i][g] = shape function g at xi = (+-1)/(1/sqrt 3).
 // The reference reads the B_g it cached during K_Initial (~10 KB per element); here B_g is
 // recomputed from the coordinates (embarrassingly parallel, 8 lanes per element = one per
-// Gauss point, node extrapolation through wavefront shuffles).  Compute_NodalForces
-// (Element.cs:248-255) only feeds a vector the linear-static driver discards
-// (Solver.cs:199) and is not computed.
+// Gauss point, node extrapolation through wavefront shuffles).
+// Compute_NodalForces (Element.cs:248-255) + the R assembly (Solver.cs:189-196) are the FORCES
+// variant of the same kernel: f_e = sum_g B_g^T dS[g] det J_g w, with dS[g] the NODE-extrapolated
+// stress of node g exactly as the reference indexes it; R[DOF] accumulates with fp64 atomics
+// (the reference's own "+=" under Parallel.ForEach is an unsynchronised race).  The linear-static
+// driver discards R (Solver.cs:199), so the console driver does not ask for it.
 // HEX8_G1 makes the reference throw (N has one row, indexed by node: Element.cs:242 vs
 // FE_Library.cs:77-81): reported as STAN_E_UNSUPPORTED with the element index.
 #include "internal.h"
@@ -15,21 +18,26 @@
 
 namespace {
 
+template <bool FORCES>
 __global__ void __launch_bounds__(256)
 k_recover(int64_t n_elem, const double *xyz, const double *disp, const int32_t *conn,
           const int32_t *elem_mat, const uint8_t *elem_type, const double *mat_lamG,
-          double *strain, double *stress, long long *bad_elem, long long *g1_elem) {
+          double *strain, double *stress, long long *bad_elem, long long *g1_elem,
+          const int32_t *node_dof, double *elem_forces, double *R) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t e = t >> 3;
     const int g = (int)(t & 7);
     const int lane = threadIdx.x & 63;
     const bool valid = e < n_elem;
     double eps[6] = {0, 0, 0, 0, 0, 0}, sig[6] = {0, 0, 0, 0, 0, 0};
+    double o[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, det = 0, px = 0, py = 0, pz = 0;
+    bool live = false;  // a HEX8_G2 element of the batch
     if (valid) {
         const int type = elem_type[e];
         if (type != STAN_HEX8_G2) {
             if (g == 0) atomicMin(g1_elem, (long long)e);
         } else {
+            live = true;
             double x[24], u[24];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
@@ -40,12 +48,11 @@ k_recover(int64_t n_elem, const double *xyz, const double *disp, const int32_t *
                     u[3 * i + c] = disp[3 * nd + c];
                 }
             }
-            double o[10];
-            const double det = hex8_gp_setup(x, type, g, o);
+            det = hex8_gp_setup(x, type, g, o);
             if (det == 0.0) atomicMin(bad_elem, (long long)e);
             const double gl = hex8_gauss_loc(type);
-            const double px = hex8_sign(HEX8_SX, g) * gl, py = hex8_sign(HEX8_SY, g) * gl,
-                         pz = hex8_sign(HEX8_SZ, g) * gl;
+            px = hex8_sign(HEX8_SX, g) * gl; py = hex8_sign(HEX8_SY, g) * gl;
+            pz = hex8_sign(HEX8_SZ, g) * gl;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 double gr[3];
@@ -83,11 +90,42 @@ k_recover(int64_t n_elem, const double *xyz, const double *disp, const int32_t *
             ns[c] += N * __shfl(sig[c], src, 64);
         }
     }
-    if (valid) {
+    if (valid && strain) {
 #pragma unroll
         for (int c = 0; c < 6; c++) {
             strain[e * 48 + i * 6 + c] = ne[c];
             stress[e * 48 + i * 6 + c] = ns[c];
+        }
+    }
+    if (FORCES) {
+        // lane g: B_g^T ns * det J_g * w (w = 1 for HEX8_G2), then the sum over the 8 lanes of
+        // the element; node a's three components end up on lane a
+        const double sc = live ? det : 0.0;
+        double mine[3] = {0, 0, 0};
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            double gr[3] = {0, 0, 0};
+            if (live) hex8_grad(o, a, px, py, pz, gr);
+            double f[3];
+            f[0] = (gr[0] * ns[0] + gr[1] * ns[3] + gr[2] * ns[5]) * sc;
+            f[1] = (gr[1] * ns[1] + gr[0] * ns[3] + gr[2] * ns[4]) * sc;
+            f[2] = (gr[2] * ns[2] + gr[1] * ns[4] + gr[0] * ns[5]) * sc;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                double v = f[c];
+                v += __shfl_xor(v, 1, 64);
+                v += __shfl_xor(v, 2, 64);
+                v += __shfl_xor(v, 4, 64);
+                if (a == i) mine[c] = v;
+            }
+        }
+        if (live) {
+            const int64_t nd = conn[e * 8 + i];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                if (elem_forces) elem_forces[e * 24 + 3 * i + c] = mine[c];
+                if (R) unsafeAtomicAdd(&R[node_dof[3 * nd + c]], mine[c]);
+            }
         }
     }
 }
@@ -97,8 +135,10 @@ k_recover(int64_t n_elem, const double *xyz, const double *disp, const int32_t *
 int stan_recover_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz, const double *d_disp,
                         int64_t n_elem, const int32_t *d_conn, const int32_t *d_elem_mat,
                         const uint8_t *d_elem_type, int32_t n_mat, const double *mat_E_nu,
-                        double *d_strain, double *d_stress) {
+                        double *d_strain, double *d_stress, const int32_t *d_node_dof,
+                        double *d_elem_forces, double *d_R) {
     (void)n_nodes;
+    const bool forces = d_elem_forces || d_R;
     if (n_elem <= 0) return STAN_OK;
     std::vector<double> lamG(2 * (size_t)n_mat);
     for (int m = 0; m < n_mat; m++) stan_lame(mat_E_nu[2 * m], mat_E_nu[2 * m + 1], &lamG[2 * m], &lamG[2 * m + 1]);
@@ -109,9 +149,15 @@ int stan_recover_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz, con
     hipError_t e1 = hipMemcpyAsync(d_lamG, lamG.data(), lamG.size() * 8, hipMemcpyHostToDevice, st);
     hipError_t e2 = hipMemcpyAsync(ctx->d_status + 8, init, 16, hipMemcpyHostToDevice, st);
     const int64_t nthreads = n_elem * 8;
-    hipLaunchKernelGGL(k_recover, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, n_elem,
-                       d_xyz, d_disp, d_conn, d_elem_mat, d_elem_type, d_lamG, d_strain, d_stress,
-                       (long long *)(ctx->d_status + 8), (long long *)(ctx->d_status + 9));
+    const dim3 grid((unsigned)((nthreads + 255) / 256)), block(256);
+    if (forces)
+        hipLaunchKernelGGL(k_recover<true>, grid, block, 0, st, n_elem, d_xyz, d_disp, d_conn, d_elem_mat,
+                           d_elem_type, d_lamG, d_strain, d_stress, (long long *)(ctx->d_status + 8),
+                           (long long *)(ctx->d_status + 9), d_node_dof, d_elem_forces, d_R);
+    else
+        hipLaunchKernelGGL(k_recover<false>, grid, block, 0, st, n_elem, d_xyz, d_disp, d_conn, d_elem_mat,
+                           d_elem_type, d_lamG, d_strain, d_stress, (long long *)(ctx->d_status + 8),
+                           (long long *)(ctx->d_status + 9), nullptr, nullptr, nullptr);
     hipError_t e3 = hipGetLastError();
     hipError_t e4 = hipMemcpyAsync(ctx->h_status + 8, ctx->d_status + 8, 16, hipMemcpyDeviceToHost, st);
     hipError_t e5 = hipStreamSynchronize(st);

@@ -29,6 +29,7 @@ EXPORTS = [
     "stan_hip_cg_solve", "stan_hip_cg_solve_dev", "stan_hip_matrix_info", "stan_hip_ke_hex8",
     "stan_hip_ke_hex8_batch", "stan_hip_matrix_to_csr", "stan_hip_spmv", "stan_hip_spmv_bench",
     "stan_hip_set_profiling", "stan_hip_get_profile", "stan_hip_set_option", "stan_hip_recover_hex8", "stan_hip_recover_hex8_dev",
+    "stan_hip_nodal_forces_hex8",
     "stan_hip_matrix_plan", "stan_hip_spmv_local", "stan_hip_csr_spmv_bench",
 ]
 
@@ -191,6 +192,25 @@ class Context:
             _ptr(elem_type, C.c_uint8), C.c_int32(mat_E_nu.shape[0]), _ptr(mat_E_nu, C.c_double),
             _ptr(strain, C.c_double), _ptr(stress, C.c_double)))
         return strain, stress
+
+    def nodal_forces_hex8(self, xyz, disp, node_dof, conn, elem_mat, elem_type, mat_E_nu):
+        """Element.NodalForces [n_elem,24] and the assembled R [n_dof] (Solver.cs:184-196)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+        disp = np.ascontiguousarray(disp, dtype=np.float64)
+        node_dof = np.ascontiguousarray(node_dof, dtype=np.int32)
+        conn = np.ascontiguousarray(conn, dtype=np.int32).reshape(-1, 8)
+        elem_mat = np.ascontiguousarray(elem_mat, dtype=np.int32)
+        elem_type = np.ascontiguousarray(elem_type, dtype=np.uint8)
+        mat_E_nu = np.ascontiguousarray(mat_E_nu, dtype=np.float64).reshape(-1, 2)
+        ne, n_dof = conn.shape[0], xyz.shape[0] * 3
+        f = np.zeros((ne, 24))
+        R = np.zeros(n_dof)
+        self._chk(self.lib.stan_hip_nodal_forces_hex8(
+            self.h, C.c_int64(xyz.shape[0]), _ptr(xyz, C.c_double), _ptr(disp, C.c_double),
+            _ptr(node_dof, C.c_int32), C.c_int64(ne), _ptr(conn, C.c_int32), _ptr(elem_mat, C.c_int32),
+            _ptr(elem_type, C.c_uint8), C.c_int32(mat_E_nu.shape[0]), _ptr(mat_E_nu, C.c_double),
+            C.c_int64(n_dof), _ptr(f, C.c_double), _ptr(R, C.c_double)))
+        return f, R
 
     # -- assembly ------------------------------------------------------------------------
     def assemble_hex8(self, xyz, node_dof, conn, elem_mat, elem_type, mat_E_nu, red):

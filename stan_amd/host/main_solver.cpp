@@ -19,21 +19,11 @@
 #include "../../include/stan_hip.h"
 #include "../../include/stan_host.h"
 #include "model.h"
+#include "solver_functions.h"
 
 using namespace stan;
 using clk = std::chrono::steady_clock;
 static double secs(clk::time_point a) { return std::chrono::duration<double>(clk::now() - a).count(); }
-
-static void Welcome_Messsage() {  // SolverFunctions.cs:23-44
-    puts("");
-    puts("  ========================================================== ");
-    puts("  ********************************************************** ");
-    puts("                  STAN - STructural ANalyser                 ");
-    puts("  ********************************************************** ");
-    puts("      Solver: Linear, Statics  (MI355X native hot path)      ");
-    puts("  ========================================================== ");
-    puts("                                                             ");
-}
 
 static int fail(const char *what, const std::string &msg) {
     fprintf(stderr, "\n  ERROR in %s: %s\n", what, msg.c_str());
@@ -56,12 +46,15 @@ int main(int argc, char **argv) {
         fprintf(stderr, "usage: stan_solver [--device N] [--mixed] [--no-merit-stop] <model.STdb>\n");
         return 2;
     }
-    Welcome_Messsage();
+    SolverOptions opt;
+    opt.device = device; opt.precision = precision; opt.merit_stop = merit_stop; opt.profile = json;
+    SolverFunctions Functions(opt);  // Solver.cs:16
+    Functions.Welcome_Messsage();
 
     printf("   Reading input file: ");  // Solver.cs:23-41
     Database DB;
     std::string err;
-    if (!ReadStdb(path, &DB, &err)) return fail("ProtoDeserialize", err);
+    if (!Functions.ProtoDeserialize(path, &DB, &err)) return fail("ProtoDeserialize", err);
     printf("     Done\n");
 
     printf("   DoF ordering: ");  // Solver.cs:44-47
@@ -70,87 +63,55 @@ int main(int argc, char **argv) {
     printf("           Done\n");
     fputs(DB.Database_Summary().c_str(), stdout);  // Solver.cs:50
 
-    if (DB.AnalysisLib.Type == "Linear_Statics") {  // Solver.cs:53-57
+    if (DB.AnalysisLib.Type == "Linear_Statics") try {  // Solver.cs:53-57, SolverLinearStatics :72-217
         const auto t_total = clk::now();
         const char *separator = "  ========================================================== ";
         printf("\n%s\n        LINEAR STATIC ANALYSIS \n%s\n", separator, separator);
 
-        FlatModel fm;
-        if (Flatten(DB, &fm, &err)) return fail("model", err);
-        std::vector<int32_t> red;
+        // Fix_DOF / nDOF_reduction / F (Solver.cs:104-152)
+        std::vector<int32_t> nDOF_reduction;
         std::vector<double> F;
         int64_t n_fixed = 0;
-        if (BuildReductionAndLoads(DB, &red, &n_fixed, &F, &err)) return fail("boundary conditions", err);
-        const int64_t n_nodes = (int64_t)DB.NodeLib.Count(), n_elem = (int64_t)DB.ElemLib.Count();
+        if (BuildReductionAndLoads(DB, &nDOF_reduction, &n_fixed, &F, &err)) return fail("boundary conditions", err);
+        const int64_t n_nodes = (int64_t)DB.NodeLib.Count();
 
-        stan_ctx *ctx = nullptr;
-        if (stan_hip_init(device, &ctx)) return fail("stan_hip_init", stan_hip_last_error(nullptr));
-        stan_hip_set_option(ctx, STAN_OPT_CG_MERIT_STOP, merit_stop ? 1 : 0);
-        if (json) stan_hip_set_profiling(ctx, 1);
-        double t_asm = 0, t_cg = 0;
-        int32_t cg_type = 0, cg_its = 0;
-        double cg_rel = 0;
-
-        printf("   K Matrix assembly: ");  // SolverFunctions.cs:127
-        fflush(stdout);
-        auto t0 = clk::now();
-        stan_matrix *K = nullptr;
-        if (stan_hip_assemble_hex8(ctx, n_nodes, fm.xyz.data(), fm.node_dof.data(), n_elem,
-                                   fm.conn.data(), fm.elem_mat.data(), fm.elem_type.data(),
-                                   (int32_t)(fm.mat_E_nu.size() / 2), fm.mat_E_nu.data(), DB.nDOF,
-                                   red.data(), &K))
-            return fail("ParallelAssembly_K", stan_hip_last_error(ctx));
-        t_asm = secs(t0);
-        printf("          Done in %.2fs\n", t_asm);
+        SparseMatrixHandle K;
+        Functions.ParallelAssembly_K(DB, nDOF_reduction, 1, "Initial", &K);  // Solver.cs:157
         stan_matrix_info minfo;
-        stan_hip_matrix_info(K, &minfo);
+        stan_hip_matrix_info(K.K, &minfo);
 
         std::vector<double> U((size_t)(DB.nDOF - n_fixed), 0.0);
         const std::string &ls = DB.AnalysisLib.LinSolver;
         if (ls == "CG") {  // Solver.cs:162
-            printf("   Solving linear system...   ");  // SolverFunctions.cs:273
-            fflush(stdout);
-            t0 = clk::now();
-            int32_t type = 0, its = 0;
-            double rel = 0;
-            if (stan_hip_cg_solve(ctx, K, F.data(), DB.AnalysisLib.LinSolverTolerance,
-                                  DB.AnalysisLib.LinSolverIterMax, precision, U.data(), &type, &its, &rel))
-                return fail("LinearSolver_CG", stan_hip_last_error(ctx));
-            printf(type == 1 || type == 7 ? "  NORMAL " : "  ERROR ");  // SolverFunctions.cs:323-327
-            t_cg = secs(t0);
-            cg_type = type; cg_its = its; cg_rel = rel;
-            printf(" (type %d) in %.2fs\n", type, t_cg);
-            printf("   CG iterations: %d, scaled relative residual %.3e\n", its, rel);
+            U = Functions.LinearSolver_CG(K, F, DB.AnalysisLib);
+            printf("   CG iterations: %d, scaled relative residual %.3e\n", Functions.last_iterations,
+                   Functions.last_rel_residual);
         } else if (ls == "Cholesky" || ls == "LU") {
             return fail("solver selection", "LinSolver '" + ls + "' is a direct solver outside the GPU hot path");
         }  // any other string: the reference leaves U = 0 (Solver.cs:160-164)
-        stan_hip_matrix_free(K);
 
-        // Include_BC_DOF + write-back (SolverFunctions.cs:520-538, Solver.cs:168-178)
+        // U = Include_BC_DOF(U, nDOF_reduction); node.dU_buffer[d] = U[DOF[d]] (Solver.cs:168-178)
+        const std::vector<double> Ufull = Functions.Include_BC_DOF(U, nDOF_reduction);
         std::vector<double> disp((size_t)n_nodes * 3);
-        stan_host_nodal_displacements(n_nodes, fm.node_dof.data(), red.data(), U.data(), disp.data());
+        for (size_t k = 0; k < disp.size(); k++) disp[k] = Ufull[(size_t)K.flat.node_dof[k]];
 
         printf("   Stress recovery: ");  // Solver.cs:183
         fflush(stdout);
-        std::vector<double> strain((size_t)n_elem * 48), stress((size_t)n_elem * 48);
-        if (stan_hip_recover_hex8(ctx, n_nodes, fm.xyz.data(), disp.data(), n_elem, fm.conn.data(),
-                                  fm.elem_mat.data(), fm.elem_type.data(),
-                                  (int32_t)(fm.mat_E_nu.size() / 2), fm.mat_E_nu.data(),
-                                  strain.data(), stress.data()))
-            return fail("Recovery_Stress", stan_hip_last_error(ctx));  // G1: the reference throws here too
+        std::vector<double> strain, stress;
+        Functions.Recovery_Stress(K, disp, &strain, &stress);
         printf("            Done\n");
         if (json) {  // one machine-readable line per run (metrics/logging)
             stan_profile pr;
-            stan_hip_get_profile(ctx, &pr);
+            stan_hip_get_profile(K.ctx, &pr);
             const double spmv_ms = pr.spmv_launches ? pr.spmv_ms_total / (double)pr.spmv_launches : 0;
             printf("{\"n_dof\": %d, \"n_reduced\": %lld, \"blocks_3x3\": %lld, \"cg_iterations\": %d, "
                    "\"termination_type\": %d, \"rel_residual\": %.3e, \"t_assembly_s\": %.4f, \"t_cg_s\": %.4f, "
                    "\"spmv_ms\": %.4f, \"spmv_GBs\": %.1f, \"hbm_frac\": %.3f}\n",
-                   DB.nDOF, (long long)minfo.n_reduced, (long long)minfo.n_blocks, cg_its, cg_type, cg_rel, t_asm,
-                   t_cg, spmv_ms, spmv_ms > 0 ? pr.spmv_bytes / spmv_ms / 1e6 : 0.0,
+                   DB.nDOF, (long long)minfo.n_reduced, (long long)minfo.n_blocks, Functions.last_iterations,
+                   Functions.last_termination_type, Functions.last_rel_residual, Functions.last_assembly_s,
+                   Functions.last_cg_s, spmv_ms, spmv_ms > 0 ? pr.spmv_bytes / spmv_ms / 1e6 : 0.0,
                    spmv_ms > 0 ? pr.spmv_bytes / spmv_ms / 1e6 / 8000.0 : 0.0);
         }
-        stan_hip_destroy(ctx);
 
         // Solver.cs:81-90 (initialise step 0/1), :203-210 (update), Main :56
         size_t i = 0;
@@ -173,12 +134,14 @@ int main(int argc, char **argv) {
         }
         printf("\n%s\n  Total CPU time: %.2f s\n%s\n", separator, secs(t_total), separator);
         DB.AnalysisLib.Result_StepNo = 1;
+    } catch (const std::exception &e) {  // the C# lets these escape Main as unhandled exceptions
+        return fail("SolverLinearStatics", e.what());
     } else if (DB.AnalysisLib.Type == "Nonlinear_Statics") {
         return fail("analysis type", "Nonlinear_Statics is unreachable from the GUI "
                                      "(MainWindow.xaml.cs:444) and outside the hot path");
     }
 
     // ExportOutput: overwrite the input path (Solver.cs:454-462)
-    if (!WriteStdb(DB, path, packed, &err)) return fail("ExportOutput", err);
+    if (!Functions.ProtoSerialize(DB, path, packed, &err)) return fail("ExportOutput", err);
     return 0;
 }

@@ -1,0 +1,101 @@
+// solver_functions.cpp -- see solver_functions.h.
+#include "solver_functions.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+
+namespace stan {
+
+using clk = std::chrono::steady_clock;
+static double secs(clk::time_point a) { return std::chrono::duration<double>(clk::now() - a).count(); }
+
+SparseMatrixHandle::~SparseMatrixHandle() {
+    if (K) stan_hip_matrix_free(K);
+    if (ctx) stan_hip_destroy(ctx);
+}
+
+void SolverFunctions::Welcome_Messsage() const {  // SolverFunctions.cs:23-44 (no window sizing, :18-20)
+    puts("");
+    puts("  ========================================================== ");
+    puts("  ********************************************************** ");
+    puts("                  STAN - STructural ANalyser                 ");
+    puts("  ********************************************************** ");
+    puts("      Solver: Linear, Statics  (MI355X native hot path)      ");
+    puts("  ========================================================== ");
+    puts("                                                             ");
+}
+
+void SolverFunctions::ParallelAssembly_K(const Database &DB, const std::vector<int32_t> &red, int inc,
+                                         const std::string &type, SparseMatrixHandle *K) const {
+    if (type != "Initial" || inc != 1)  // "Tangent" belongs to the unfinished nonlinear driver
+        throw std::runtime_error("ParallelAssembly_K: only type \"Initial\" at increment 1 (linear statics)");
+    const auto t0 = clk::now();
+    printf("   K Matrix assembly: ");  // SolverFunctions.cs:127
+    fflush(stdout);
+    std::string err;
+    if (Flatten(DB, &K->flat, &err)) throw std::runtime_error(err);
+    if (stan_hip_init(opt_.device, &K->ctx)) throw std::runtime_error(stan_hip_last_error(nullptr));
+    stan_hip_set_option(K->ctx, STAN_OPT_CG_MERIT_STOP, opt_.merit_stop ? 1 : 0);
+    if (opt_.profile) stan_hip_set_profiling(K->ctx, 1);
+    const FlatModel &f = K->flat;
+    const int rc = stan_hip_assemble_hex8(K->ctx, (int64_t)DB.NodeLib.Count(), f.xyz.data(), f.node_dof.data(),
+                                          (int64_t)DB.ElemLib.Count(), f.conn.data(), f.elem_mat.data(),
+                                          f.elem_type.data(), (int32_t)(f.mat_E_nu.size() / 2),
+                                          f.mat_E_nu.data(), DB.nDOF, red.data(), &K->K);
+    if (rc) throw std::runtime_error(stan_hip_last_error(K->ctx));  // det J == 0: MatrixST.cs:315-318 throws
+    const_cast<SolverFunctions *>(this)->last_assembly_s = secs(t0);
+    printf("          Done in %.2fs\n", last_assembly_s);  // SolverFunctions.cs:177
+}
+
+std::vector<double> SolverFunctions::LinearSolver_CG(SparseMatrixHandle &K, const std::vector<double> &F,
+                                                     const Analysis &A) const {
+    const auto t0 = clk::now();
+    printf("   Solving linear system...   ");  // SolverFunctions.cs:273
+    fflush(stdout);
+    std::vector<double> U(F.size(), 0.0);
+    int32_t type = 0, its = 0;
+    double rel = 0;
+    if (stan_hip_cg_solve(K.ctx, K.K, F.data(), A.LinSolverTolerance, A.LinSolverIterMax, opt_.precision,
+                          U.data(), &type, &its, &rel))
+        throw std::runtime_error(stan_hip_last_error(K.ctx));
+    SolverFunctions *self = const_cast<SolverFunctions *>(this);
+    self->last_termination_type = type; self->last_iterations = its; self->last_rel_residual = rel;
+    self->last_cg_s = secs(t0);
+    printf(type == 1 || type == 7 ? "  NORMAL " : "  ERROR ");  // SolverFunctions.cs:323-324
+    printf(" (type %d) in %.2fs\n", type, last_cg_s);          // :325-327
+    return U;                                                    // :329, returned regardless
+}
+
+void SolverFunctions::Recovery_Stress(SparseMatrixHandle &K, const std::vector<double> &dU,
+                                      std::vector<double> *strain, std::vector<double> *stress) const {
+    const FlatModel &f = K.flat;
+    const int64_t n_nodes = (int64_t)(f.xyz.size() / 3), n_elem = (int64_t)f.elem_mat.size();
+    strain->assign((size_t)n_elem * 48, 0.0);
+    stress->assign((size_t)n_elem * 48, 0.0);
+    if (stan_hip_recover_hex8(K.ctx, n_nodes, f.xyz.data(), dU.data(), n_elem, f.conn.data(), f.elem_mat.data(),
+                              f.elem_type.data(), (int32_t)(f.mat_E_nu.size() / 2), f.mat_E_nu.data(),
+                              strain->data(), stress->data()))
+        throw std::runtime_error(stan_hip_last_error(K.ctx));  // HEX8_G1: the reference throws too (Element.cs:242)
+}
+
+std::vector<double> SolverFunctions::Include_BC_DOF(const std::vector<double> &A, const std::vector<int32_t> &red) const {
+    std::vector<double> full(red.size(), 0.0);  // SolverFunctions.cs:520-538
+    for (size_t i = 0; i < red.size(); i++) full[i] = red[i] == -1 ? 0.0 : A[i - (size_t)red[i]];
+    return full;
+}
+std::vector<double> SolverFunctions::Exclude_BC_DOF(const std::vector<double> &A, const std::vector<int32_t> &red) const {
+    size_t nfix = 0;  // SolverFunctions.cs:540-555
+    for (int32_t r : red) nfix += r == -1;
+    std::vector<double> out(red.size() - nfix, 0.0);
+    for (size_t i = 0; i < red.size(); i++)
+        if (red[i] != -1) out[i - (size_t)red[i]] = A[i];
+    return out;
+}
+double SolverFunctions::Vector_Norm(const std::vector<double> &v) const {
+    double n = 0;  // SolverFunctions.cs:559-569
+    for (double x : v) n += std::pow(x, 2);
+    return std::sqrt(n);
+}
+
+}  // namespace stan

@@ -1,0 +1,73 @@
+// solver_functions.h -- C++ mirror of STAN_Solver.SolverFunctions for the linear-static path
+// (SolverFunctions.cs): same method names, argument meaning, console lines and error
+// behaviour, with the two hot calls going through the C-ABI of libstan_hip.so.
+//   ParallelAssembly_K   SolverFunctions.cs:117-180  -> stan_hip_assemble_hex8
+//   LinearSolver_CG      SolverFunctions.cs:270-330  -> stan_hip_cg_solve
+//   Include_BC_DOF       SolverFunctions.cs:520-538
+//   Exclude_BC_DOF       SolverFunctions.cs:540-555
+//   Vector_Norm          SolverFunctions.cs:559-569
+//   ProtoSerialize / ProtoDeserialize  :48-63      -> stdb.cpp
+// Failures that make the C# throw (det J == 0 in MatrixST.Inverse, KeyNotFound on MatID ...)
+// throw std::runtime_error here; a CG that does not converge is reported, not thrown, and U is
+// returned regardless (SolverFunctions.cs:323-329).
+#pragma once
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/stan_hip.h"
+#include "model.h"
+
+namespace stan {
+
+// alglib.sparsematrix in the reference: here an opaque device-resident K plus its context.
+class SparseMatrixHandle {
+  public:
+    SparseMatrixHandle() {}
+    ~SparseMatrixHandle();
+    SparseMatrixHandle(const SparseMatrixHandle &) = delete;
+    SparseMatrixHandle &operator=(const SparseMatrixHandle &) = delete;
+    stan_ctx *ctx = nullptr;
+    stan_matrix *K = nullptr;
+    FlatModel flat;  // kept for Recovery_Stress (the reference caches J/BL on the elements)
+};
+
+struct SolverOptions {  // extras of the native driver, never stored in the STdb
+    int device = 0;
+    int precision = STAN_PREC_FP64;
+    bool merit_stop = true;
+    bool profile = false;
+};
+
+class SolverFunctions {
+  public:
+    explicit SolverFunctions(const SolverOptions &opt = SolverOptions()) : opt_(opt) {}
+
+    void Welcome_Messsage() const;
+    bool ProtoDeserialize(const std::string &path, Database *db, std::string *err) const { return ReadStdb(path, db, err); }
+    bool ProtoSerialize(const Database &db, const std::string &path, bool packed, std::string *err) const { return WriteStdb(db, path, packed, err); }
+
+    // K = ParallelAssembly_K(DB, nDOF_reduction, inc, "Initial")
+    void ParallelAssembly_K(const Database &DB, const std::vector<int32_t> &nDOF_reduction, int inc,
+                            const std::string &type, SparseMatrixHandle *K) const;
+    // U = LinearSolver_CG(K, F, AnalysisLib)
+    std::vector<double> LinearSolver_CG(SparseMatrixHandle &K, const std::vector<double> &F,
+                                        const Analysis &AnalysisLib) const;
+    // Element.Recovery_Stress + Update_StrainStress for every element (Solver.cs:183-210)
+    void Recovery_Stress(SparseMatrixHandle &K, const std::vector<double> &nodal_dU,
+                         std::vector<double> *strain, std::vector<double> *stress) const;
+
+    std::vector<double> Include_BC_DOF(const std::vector<double> &A, const std::vector<int32_t> &nDOF_reduction) const;
+    std::vector<double> Exclude_BC_DOF(const std::vector<double> &A, const std::vector<int32_t> &nDOF_reduction) const;
+    double Vector_Norm(const std::vector<double> &v) const;
+
+    // report of the last LinearSolver_CG
+    int last_termination_type = 0, last_iterations = 0;
+    double last_rel_residual = 0, last_assembly_s = 0, last_cg_s = 0;
+
+  private:
+    SolverOptions opt_;
+};
+
+}  // namespace stan

@@ -276,6 +276,26 @@ def test_stress_recovery_parity(gpu_ctx, oracle):
         assert np.abs(stress[e] - so).max() <= 1e-12 * np.abs(so).max()
 
 
+def test_nodal_forces_parity(gpu_ctx, oracle):
+    """Element.Compute_NodalForces + the R assembly of Solver.cs:184-196 against the oracle."""
+    job = problem.cube_job(5, jitter=0.1)
+    job.elem_mat = (np.arange(job.conn.shape[0]) % 2).astype(np.int32)
+    job.mat_E_nu = np.array([[210000.0, 0.3], [70000.0, 0.33]])
+    disp = np.random.default_rng(8).standard_normal(job.xyz.shape) * 1e-3
+    f, R = gpu_ctx.nodal_forces_hex8(job.xyz, disp, job.node_dof, job.conn, job.elem_mat,
+                                     job.elem_type, job.mat_E_nu)
+    fo = np.zeros_like(f)
+    for e in range(job.conn.shape[0]):
+        E, nu = job.mat_E_nu[job.elem_mat[e]]
+        rc, _, so = oracle.recover_hex8(job.xyz[job.conn[e]], E, nu, 2, disp[job.conn[e]].ravel())
+        rc2, fo[e] = oracle.nodal_forces_hex8(job.xyz[job.conn[e]], 2, so)
+        assert rc == 0 and rc2 == 0
+    assert np.abs(f - fo).max() <= 1e-12 * np.abs(fo).max()
+    Ro = np.zeros(job.n_dof)
+    np.add.at(Ro, job.node_dof[job.conn].reshape(-1, 24), fo)
+    assert np.abs(R - Ro).max() <= 1e-12 * np.abs(Ro).max()
+
+
 def test_stress_recovery_g1_is_an_error_like_the_reference(gpu_ctx):
     from stan_amd import hip
     job = problem.cube_job(2, etype=1)

@@ -193,6 +193,26 @@ def test_recovery_constant_strain(oracle):
     assert oracle.recover_hex8(x, 210000.0, 0.3, 1, dU)[0] == -4  # G1 throws in the reference
 
 
+def test_nodal_forces_constant_strain_equal_ke_times_u(oracle):
+    """Compute_NodalForces (Element.cs:248-255): with a constant-strain field the node-extrapolated
+    stress equals the Gauss-point stress, so the reference's dS[g] indexing quirk is invisible and
+    the element forces are exactly K_e u; with a general field they are NOT (quirk kept)."""
+    x = random_hexes(1, seed=6)[0]
+    eps0 = np.array([[1e-3, 2e-4, 3e-4], [2e-4, -5e-4, 1e-4], [3e-4, 1e-4, 7e-4]])
+    dU = (x @ eps0.T).ravel()
+    rc, e, s = oracle.recover_hex8(x, 210000.0, 0.3, 2, dU)
+    rc2, f = oracle.nodal_forces_hex8(x, 2, s)
+    rc3, K = oracle.ke_hex8(x, 210000.0, 0.3, 2)
+    assert rc == 0 and rc2 == 0 and rc3 == 0
+    assert np.abs(f - K @ dU).max() <= 1e-10 * np.abs(f).max()
+    assert abs(f.reshape(8, 3).sum(axis=0)).max() <= 1e-10 * np.abs(f).max()  # self-equilibrated
+    dU2 = np.random.default_rng(7).standard_normal(24) * 1e-3
+    _, _, s2 = oracle.recover_hex8(x, 210000.0, 0.3, 2, dU2)
+    _, f2 = oracle.nodal_forces_hex8(x, 2, s2)
+    assert np.abs(f2 - K @ dU2).max() > 1e-3 * np.abs(f2).max()
+    assert oracle.nodal_forces_hex8(x, 1, s)[0] == -4
+
+
 def test_cg_restatement_tracks_textbook_jacobi_pcg(oracle):
     """The restated lincg (symmetric diagonal scaling + plain CG, residual refresh every 10)
     is textbook Jacobi-PCG in different variables: SciPy's CG on S K S needs the same number
