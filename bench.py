@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--size", dest="n", type=int, default=148, help="cube edge in elements (148 -> ~10 M DOF)")
     ap.add_argument("--eps", type=float, default=1e-8)
     ap.add_argument("--mixed", action="store_true", help="fp32 matrix / fp64 vectors")
+    ap.add_argument("--fixed48", action="store_true",
+                    help="fp64 arithmetic on the 48-bit fixed-point stream of the scaled matrix")
     ap.add_argument("--etype", type=int, default=2, help="2 = HEX8_G2, 1 = HEX8_G1")
     ap.add_argument("--cpu-n", type=int, default=56, help="cube edge of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
@@ -134,7 +136,7 @@ def main():
     d_F = torch.from_numpy(job.F).to(dev)
     d_U = torch.zeros(job.n_red, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
-    prec = hip.PREC_MIXED if args.mixed else hip.PREC_FP64
+    prec = hip.PREC_MIXED if args.mixed else hip.PREC_FIXED48 if args.fixed48 else hip.PREC_FP64
 
     def step():
         K = ctx.assemble_hex8_dev(job.xyz.shape[0], d_xyz.data_ptr(), d_dof.data_ptr(),
@@ -192,9 +194,10 @@ def main():
         # for this workload; counters cannot be collected from inside this process
         traffic = None
         import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_spmv.json"))):
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_spmv*.json"))):
             d = json.load(open(f))
-            if d.get("workload_n") == args.n and not args.mixed and world == 1:
+            if (d.get("workload_n") == args.n and world == 1 and
+                    d.get("value_stream", 0) == prof["value_stream"]):
                 traffic = d["traffic_bytes_per_launch"]
         achieved = prof["spmv_bytes"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
@@ -206,7 +209,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64" if not args.mixed else "f32 matrix / f64 vectors",
+            "dtype": ("f32 matrix / f64 vectors" if args.mixed else
+                      "f64 (matrix streamed as 48-bit fixed point)" if args.fixed48 else "f64"),
             "data": "synthetic",
             "config": {"workload": "%d^3 HEX8_G%d cube, %d DOF, clamp x=0, PointLoad (0,0,50) on "
                                    "x=n; fp64 Jacobi-scaled CG to %.0e" %
@@ -216,8 +220,9 @@ def main():
                        "termination_type": rep["terminationtype"],
                        "rel_residual": rep["rel_residual"], "converged": bool(ok),
                        "assemble_ms": asm_ms / args.steps, "cg_ms": cg_ms / args.steps,
-                       "matrix_format": "BSELL-64 3x3 blocks (fp%s values + int32 block cols)" %
-                                        ("32" if args.mixed else "64"),
+                       "matrix_format": "BSELL-64 3x3 blocks (%s values + int32 block cols)" %
+                                        ("fp32" if args.mixed else "48-bit fixed-point" if args.fixed48
+                                         else "fp64"),
                        "parallelism": "rows sharded x%d" % world,
                        # SURVEY section 8d assembly bytes: coords + connectivity read, K written once
                        "assembly_GBs": (job.conn.shape[0] * (192 + 32) + info["n_slots"] * 64 * 72)

@@ -57,6 +57,11 @@ typedef struct stan_matrix stan_matrix;
 /* precision_mode of stan_hip_cg_solve */
 #define STAN_PREC_FP64 0  /* fp64 matrix, fp64 vectors (reference arithmetic)              */
 #define STAN_PREC_MIXED 1 /* fp32 matrix values, fp64 vectors and accumulation             */
+/* fp64 arithmetic on a 48-bit fixed-point copy of the Jacobi-scaled matrix: every entry of
+ * S K S is in [-1,1] for SPD K, stored as rint(a * 2^46) (absolute error <= 2^-47 = 7e-15 of
+ * the unit diagonal); 60 B per 3x3 block instead of 76 B.  If some |a| >= 2 (K not SPD) the
+ * fp64 values are streamed instead (stan_profile.value_stream tells). */
+#define STAN_PREC_FIXED48 2
 
 /* ---- context ------------------------------------------------------------------------- */
 /* `device` = HIP device ordinal this process drives.  Fails loudly (STAN_E_HIP) when no
@@ -83,7 +88,7 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
 #define STAN_OPT_CG_FUSED_REFRESH 6 /* 1 (default): on refresh iterations A x and A p come from ONE
                                      matrix pass and r = b - (A x + a A p); 0: ALGLIB's literal
                                      second product A (x + a p).  Same value up to rounding. */
-#define STAN_OPT_SPMV_VARIANT 3 /* tuning variants of the SpMV kernel (cg.hip), A/B runs only */
+#define STAN_OPT_SPMV_VARIANT 3 /* tuning variants of the SpMV kernel (cg.hip), A/B runs only; -1 = auto (default) */
 int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value);
 
 /* ---- multi-GPU (RCCL over xGMI) -------------------------------------------------------- */
@@ -230,7 +235,7 @@ typedef struct stan_profile {
     int32_t iterations;
     int32_t termination_type;
     int32_t assembly_colours; /* element colours of the last mode-1 assembly */
-    int32_t reserved;
+    int32_t value_stream;     /* STAN_PREC_* of the stream the last CG actually read */
     double spmv2_ms_total;    /* two-product launches of the refresh iterations (k_spmv2),  */
     int64_t spmv2_launches;   /* NOT included in spmv_ms_total / spmv_launches              */
 } stan_profile;

@@ -102,6 +102,39 @@ __global__ void k_to_fp32(const double *in, float *out, int64_t n) {
     for (; i < n; i += stride) out[i] = (float)in[i];
 }
 
+constexpr double FX48_ONE = 70368744177664.0;                          // 2^46
+constexpr double FX48_INV = 1.0 / 70368744177664.0;                    // 2^-46
+constexpr double FX48_BIAS = 4503599627370496.0 + 140737488355328.0;   // 2^52 + 2^47
+
+// scaled fp64 values -> FIXED-48 stream (see vstream<uint32_t>); *bad counts the entries
+// with |a| >= 2 (not representable: the matrix was not SPD-scalable)
+__global__ void __launch_bounds__(256)
+k_to_fx48(int64_t nslots, const double *vals, uint32_t *out, unsigned long long *bad) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t slot = t >> 6;
+    const int lane = (int)(t & 63);
+    if (slot >= nslots) return;
+    const double *v = vals + slot * 9 * 64 + lane;
+    uint32_t *o = out + slot * 14 * 64 + lane;
+    uint32_t hi[10];
+    int nbad = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const double a = v[j * 64] * FX48_ONE;
+        long long q = 0;
+        if (!(fabs(a) < 140737488355328.0)) nbad++;  // also catches NaN
+        else q = __double2ll_rn(a);
+        if (q >= 140737488355328LL) { q = 0; nbad++; }
+        const unsigned long long u = (unsigned long long)(q + 140737488355328LL);
+        o[j * 64] = (uint32_t)u;
+        hi[j] = (uint32_t)(u >> 32);
+    }
+    hi[9] = 0;
+#pragma unroll
+    for (int m = 0; m < 5; m++) o[(9 + m) * 64] = hi[2 * m] | (hi[2 * m + 1] << 16);
+    if (nbad) atomicAdd(bad, (unsigned long long)nbad);
+}
+
 // b^[i] = s_i * F[d - red[d]] on free DOFs, 0 on fixed ones; also x0 = 0, r = p = b^ and
 // partial sums of b^.b^ (x0 = 0 => r0 = b^, merit0 = 0).
 __global__ void __launch_bounds__(VEC_T)
@@ -183,6 +216,38 @@ __device__ __forceinline__ T ld_stream(const T *p, bool nt) {
     return nt ? __builtin_nontemporal_load(p) : *p;
 }
 
+// Value streams of the matrix.  double / float: vals[slot][9][64].
+// uint32_t = FIXED-48 (STAN_PREC_FIXED48): after the Jacobi scaling every entry of an SPD matrix
+// satisfies |a_ij| <= sqrt(a_ii a_jj) = 1, so no exponent is needed: q = rint(a * 2^46) as a
+// signed 48-bit integer (absolute error <= 2^-47 = 7.1e-15 of the unit diagonal), stored
+// offset-binary u = q + 2^47 as vals48[slot][14][64] dwords: rows 0..8 the low 32 bits of the
+// nine entries, rows 9..13 the high 16 bits packed two per dword.  60 B per block instead of
+// 76 B.  Decoding is one integer op and one exact fp64 subtraction per entry: the bits
+// 0x43300000'00000000 | u are the double 2^52 + u.  The 2^-46 is applied to the three
+// gathered x values instead of the nine entries (powers of two commute with rounding), so
+// the arithmetic is the fp64 product with the quantised matrix.
+template <typename VT> struct vstream { static constexpr int STRIDE = 9 * 64; static constexpr bool FX = false; };
+template <> struct vstream<uint32_t> { static constexpr int STRIDE = 14 * 64; static constexpr bool FX = true; };
+
+template <typename VT>
+__device__ __forceinline__ void load9(const VT *vp, bool nt, double a[9]) {
+#pragma unroll
+    for (int j = 0; j < 9; j++) a[j] = (double)ld_stream(vp + j * 64, nt);
+}
+template <>
+__device__ __forceinline__ void load9<uint32_t>(const uint32_t *vp, bool nt, double a[9]) {
+    uint32_t lo[9], hw[5];
+#pragma unroll
+    for (int j = 0; j < 9; j++) lo[j] = ld_stream(vp + j * 64, nt);
+#pragma unroll
+    for (int m = 0; m < 5; m++) hw[m] = ld_stream(vp + (9 + m) * 64, nt);
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const uint32_t h = (j & 1) ? (hw[j >> 1] >> 16) : (hw[j >> 1] & 0xffffu);
+        a[j] = __hiloint2double((int)(0x43300000u | h), (int)lo[j]) - FX48_BIAS;
+    }
+}
+
 template <typename VT, bool DOT, int VAR>
 __global__ void __launch_bounds__(256)
 k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
@@ -208,8 +273,8 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
     if (slice < nslices) {
         const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
         const int32_t *cp = cols + (int64_t)k0 * 64 + lane;
-        const VT *vp = vals + (int64_t)k0 * 9 * 64 + lane;
-        if (VAR == 8) {
+        const VT *vp = vals + (int64_t)k0 * vstream<VT>::STRIDE + lane;
+        if (VAR == 8 && !vstream<VT>::FX) {
             typedef VT v2 __attribute__((ext_vector_type(2)));
             const v2 *vq = (const v2 *)(vals + (int64_t)k0 * 9 * 64) + lane;
             for (int32_t k = k0; k + 1 < k1; k += 2) {
@@ -229,17 +294,15 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
 #pragma unroll UNR
             for (int32_t k = k0; k < k1; k++) {
                 const int64_t c = ld_stream(cp, NT);
-                const double a0 = (double)ld_stream(vp + 0 * 64, NT), a1 = (double)ld_stream(vp + 1 * 64, NT),
-                             a2 = (double)ld_stream(vp + 2 * 64, NT), a3 = (double)ld_stream(vp + 3 * 64, NT),
-                             a4 = (double)ld_stream(vp + 4 * 64, NT), a5 = (double)ld_stream(vp + 5 * 64, NT),
-                             a6 = (double)ld_stream(vp + 6 * 64, NT), a7 = (double)ld_stream(vp + 7 * 64, NT),
-                             a8 = (double)ld_stream(vp + 8 * 64, NT);
-                const double x0 = x[3 * c], x1 = x[3 * c + 1], x2 = x[3 * c + 2];
-                y0 += a0 * x0 + a1 * x1 + a2 * x2;
-                y1 += a3 * x0 + a4 * x1 + a5 * x2;
-                y2 += a6 * x0 + a7 * x1 + a8 * x2;
+                double a[9];
+                load9<VT>(vp, NT, a);
+                double x0 = x[3 * c], x1 = x[3 * c + 1], x2 = x[3 * c + 2];
+                if (vstream<VT>::FX) { x0 *= FX48_INV; x1 *= FX48_INV; x2 *= FX48_INV; }
+                y0 += a[0] * x0 + a[1] * x1 + a[2] * x2;
+                y1 += a[3] * x0 + a[4] * x1 + a[5] * x2;
+                y2 += a[6] * x0 + a[7] * x1 + a[8] * x2;
                 cp += 64;
-                vp += 9 * 64;
+                vp += vstream<VT>::STRIDE;
             }
         }
         if (row < nloc) {
@@ -274,15 +337,18 @@ k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
     if (slice < nslices) {
         const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
         const int32_t *cp = cols + (int64_t)k0 * 64 + lane;
-        const VT *vp = vals + (int64_t)k0 * 9 * 64 + lane;
+        const VT *vp = vals + (int64_t)k0 * vstream<VT>::STRIDE + lane;
 #pragma unroll 2
         for (int32_t k = k0; k < k1; k++) {
             const int64_t c = ld_stream(cp, true);
             double a[9];
-#pragma unroll
-            for (int j = 0; j < 9; j++) a[j] = (double)ld_stream(vp + j * 64, true);
-            const double x0 = x[3 * c], x1 = x[3 * c + 1], xx2 = x[3 * c + 2];
-            const double u0 = x2[3 * c], u1 = x2[3 * c + 1], u2 = x2[3 * c + 2];
+            load9<VT>(vp, true, a);
+            double x0 = x[3 * c], x1 = x[3 * c + 1], xx2 = x[3 * c + 2];
+            double u0 = x2[3 * c], u1 = x2[3 * c + 1], u2 = x2[3 * c + 2];
+            if (vstream<VT>::FX) {
+                x0 *= FX48_INV; x1 *= FX48_INV; xx2 *= FX48_INV;
+                u0 *= FX48_INV; u1 *= FX48_INV; u2 *= FX48_INV;
+            }
             y0 += a[0] * x0 + a[1] * x1 + a[2] * xx2;
             y1 += a[3] * x0 + a[4] * x1 + a[5] * xx2;
             yy2 += a[6] * x0 + a[7] * x1 + a[8] * xx2;
@@ -290,7 +356,7 @@ k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
             z1 += a[3] * u0 + a[4] * u1 + a[5] * u2;
             z2 += a[6] * u0 + a[7] * u1 + a[8] * u2;
             cp += 64;
-            vp += 9 * 64;
+            vp += vstream<VT>::STRIDE;
         }
         if (row < nloc) {
             y[3 * row] = y0; y[3 * row + 1] = y1; y[3 * row + 2] = yy2;
@@ -515,7 +581,10 @@ unsigned launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double
                            K->nloc, K->d_slot_ptr, K->d_cols, vals, x, y, partial, st, k,     \
                            slist, nlist, poff);                                               \
         break;
-    switch (ctx->spmv_variant) {
+    // auto (-1): 1 = non-temporal stream; 5 (+ unroll 4) for the FIXED-48 stream, whose
+    // iterations carry 21 % fewer bytes in flight: 1.011 vs 1.035 ms at 148^3 (tools/fx48_lab.py)
+    const int variant = ctx->spmv_variant >= 0 ? ctx->spmv_variant : (vstream<VT>::FX ? 5 : 1);
+    switch (variant) {
         SPMV_CASE(1) SPMV_CASE(2) SPMV_CASE(3) SPMV_CASE(4) SPMV_CASE(5) SPMV_CASE(6) SPMV_CASE(7)
         SPMV_CASE(8)
         default:
@@ -570,6 +639,25 @@ int stan_matrix_make_fp32(stan_ctx *ctx, stan_matrix *K) {
     return STAN_OK;
 }
 
+// FIXED-48 copy of the scaled values.  Returns STAN_OK with K->d_vals48 == nullptr when some
+// entry is not representable (K not SPD): the caller then streams the fp64 values.
+int stan_matrix_make_fx48(stan_ctx *ctx, stan_matrix *K) {
+    if (K->d_vals48 || K->fx48_refused) return STAN_OK;
+    if (K->nslots == 0) return STAN_OK;
+    uint32_t *out;
+    STANCHK(stan_dmalloc(ctx, &out, (size_t)K->nslots * 14 * 64));
+    unsigned long long *d_bad = (unsigned long long *)(ctx->d_status + 10);
+    HIPCHK(ctx, hipMemsetAsync(d_bad, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_to_fx48, dim3((unsigned)nblk(K->nslots * 64, 256)), dim3(256), 0, ctx->stream,
+                       K->nslots, K->d_vals, out, d_bad);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 10, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_status[10] != 0) { hipFree(out); K->fx48_refused = true; return STAN_OK; }
+    K->d_vals48 = out;
+    return STAN_OK;
+}
+
 // NOTE on the halo layout: vectors that are gathered by the SpMV (p, x) hold the owned
 // block rows first, padded to whole slices, then the halo block columns:
 //   [ 3*nslices*64 owned+pad | 3*nhalo ]
@@ -581,7 +669,8 @@ int stan_matrix_make_fp32(stan_ctx *ctx, stan_matrix *K) {
 int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_f,
                    int32_t max_its, int32_t precision_mode, double *d_U, int32_t *term_out,
                    int32_t *iters_out, double *rel_res_out) {
-    if (precision_mode != STAN_PREC_FP64 && precision_mode != STAN_PREC_MIXED) {
+    if (precision_mode != STAN_PREC_FP64 && precision_mode != STAN_PREC_MIXED &&
+        precision_mode != STAN_PREC_FIXED48) {
         ctx->err = "cg_solve: unknown precision_mode";
         return STAN_E_UNSUPPORTED;
     }
@@ -599,6 +688,8 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     STANCHK(ensure_scaled(ctx, K));
     const bool mixed = precision_mode == STAN_PREC_MIXED;
     if (mixed) STANCHK(stan_matrix_make_fp32(ctx, K));
+    if (precision_mode == STAN_PREC_FIXED48) STANCHK(stan_matrix_make_fx48(ctx, K));
+    const bool fx = precision_mode == STAN_PREC_FIXED48 && K->d_vals48 != nullptr;
     const bool dist = ctx->comm != nullptr || ctx->nranks > 1;  // collectives in the loop
 
     const int64_t n3 = 3 * K->nloc;
@@ -661,6 +752,9 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             if (mixed)
                 return dot ? launch_spmv<float, true>(ctx, K, K->d_vals32, x, y, partial, stt, k, which, s)
                            : launch_spmv<float, false>(ctx, K, K->d_vals32, x, y, partial, stt, k, which, s);
+            if (fx)
+                return dot ? launch_spmv<uint32_t, true>(ctx, K, K->d_vals48, x, y, partial, stt, k, which, s)
+                           : launch_spmv<uint32_t, false>(ctx, K, K->d_vals48, x, y, partial, stt, k, which, s);
             return dot ? launch_spmv<double, true>(ctx, K, K->d_vals, x, y, partial, stt, k, which, s)
                        : launch_spmv<double, false>(ctx, K, K->d_vals, x, y, partial, stt, k, which, s);
         };
@@ -689,6 +783,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             spmv2_ev.push_back(a); spmv2_ev.push_back(b);
         }
         auto go = [&](int which, hipStream_t s) -> unsigned {
+            if (fx) return launch_spmv2<uint32_t>(ctx, K, K->d_vals48, x, x2, v, w, partial, stt, k, which, s);
             return mixed ? launch_spmv2<float>(ctx, K, K->d_vals32, x, x2, v, w, partial, stt, k, which, s)
                          : launch_spmv2<double>(ctx, K, K->d_vals, x, x2, v, w, partial, stt, k, which, s);
         };
@@ -821,8 +916,9 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         hipEventDestroy(ev0); hipEventDestroy(ev1);
         ctx->prof.iterations = (int32_t)its;
         ctx->prof.termination_type = type;
-        const int64_t vb = mixed ? 4 : 8;
-        ctx->prof.spmv_bytes = K->nblocks * (9 * vb + 4) + 3 * K->nloc * 16 + K->nloc * 4;
+        const int64_t blk_bytes = fx ? 60 : mixed ? 40 : 76;
+        ctx->prof.spmv_bytes = K->nblocks * blk_bytes + 3 * K->nloc * 16 + K->nloc * 4;
+        ctx->prof.value_stream = fx ? STAN_PREC_FIXED48 : mixed ? STAN_PREC_MIXED : STAN_PREC_FP64;
         ctx->prof.cg_iteration_vector_bytes = 3 * K->nloc * 8 * 10;
     }
     return STAN_OK;
@@ -876,6 +972,12 @@ int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode
     hipStream_t st_ = ctx->stream;
     const bool mixed = precision_mode == STAN_PREC_MIXED;
     if (mixed) STANCHK(stan_matrix_make_fp32(ctx, K));
+    if (precision_mode == STAN_PREC_FIXED48) {
+        STANCHK(ensure_scaled(ctx, K));
+        STANCHK(stan_matrix_make_fx48(ctx, K));
+        if (!K->d_vals48) { ctx->err = "spmv_bench: matrix not representable in FIXED48"; return STAN_E_UNSUPPORTED; }
+    }
+    const bool fx = precision_mode == STAN_PREC_FIXED48;
     const int64_t npad = (int64_t)K->nslices * 64;
     const int64_t ng = 3 * ((npad > K->nloc + K->nhalo ? npad : K->nloc + K->nhalo));
     dev_bufs bufs;
@@ -891,6 +993,7 @@ int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode
     hipEventCreate(&a); hipEventCreate(&b);
     auto one = [&]() {
         if (mixed) launch_spmv<float, true>(ctx, K, K->d_vals32, x, y, partial, stt, 1);
+        else if (fx) launch_spmv<uint32_t, true>(ctx, K, K->d_vals48, x, y, partial, stt, 1);
         else launch_spmv<double, true>(ctx, K, K->d_vals, x, y, partial, stt, 1);
     };
     for (int i = 0; i < 3; i++) one();
@@ -915,5 +1018,7 @@ int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K) {
     HIPCHK(ctx, hipGetLastError());
     K->scaled = false;
     if (K->d_vals32) { hipFree(K->d_vals32); K->d_vals32 = nullptr; }
+    if (K->d_vals48) { hipFree(K->d_vals48); K->d_vals48 = nullptr; }
+    K->fx48_refused = false;
     return STAN_OK;
 }

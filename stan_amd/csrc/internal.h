@@ -64,7 +64,8 @@ struct stan_ctx {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     int assembly_mode = 0;     // 0 row-owner gather (default), 1 element-wave colour scatter
     int prof_colours = 0;
-    int spmv_variant = 1;  // non-temporal matrix stream: measured 1.124 vs 1.216 ms at 148^3 (profiles/r01)
+    int spmv_variant = -1; // -1 = auto: 1 (non-temporal matrix stream: 1.124 vs 1.216 ms at 148^3, profiles/r01)
+                           // for the fp64/fp32 streams, 5 (+ unroll 4) for FIXED-48
     // profiling
     bool profiling = false;
     stan_profile prof{};
@@ -88,6 +89,8 @@ struct stan_matrix {
     int32_t *d_cols = nullptr;      // [nslots][64] local block-column index
     double *d_vals = nullptr;       // [nslots][9][64]
     float *d_vals32 = nullptr;      // same layout, fp32 copy (mixed precision)
+    uint32_t *d_vals48 = nullptr;   // FIXED-48 stream of the scaled values, [slot][14][64] dwords
+    bool fx48_refused = false;      // some |a_ij| >= 2 after scaling (K not SPD): fp64 is streamed
     int32_t *d_red = nullptr;       // [n_dof] nDOF_reduction
     uint8_t *d_fixmask = nullptr;   // [nb_glob] bit m = DOF m of the node fixed
     double *d_scale = nullptr;      // [3*(nloc+nhalo)] s_i = 1/sqrt(K_ii)
@@ -133,6 +136,7 @@ int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode
                            double *avg_ms);
 int stan_spmv_local(stan_ctx *ctx, stan_matrix *K, const double *d_x, double *d_y);
 int stan_matrix_make_fp32(stan_ctx *ctx, stan_matrix *K);
+int stan_matrix_make_fx48(stan_ctx *ctx, stan_matrix *K);
 int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K);
 
 // ---- recovery.hip ---------------------------------------------------------------------------

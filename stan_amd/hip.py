@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STAN_HIP_LIB") or os.path.join(_HERE, "lib", "libstan_hip.so")
 
 HEX8_G1, HEX8_G2 = 1, 2
-PREC_FP64, PREC_MIXED = 0, 1
+PREC_FP64, PREC_MIXED, PREC_FIXED48 = 0, 1, 2
 OPT_CG_MERIT_STOP, OPT_CG_RUPDATE, OPT_SPMV_VARIANT, OPT_OVERLAP_HALO, OPT_ASSEMBLY_MODE = 1, 2, 3, 4, 5
 OPT_CG_FUSED_REFRESH = 6
 E_HIP, E_ARG, E_ALLOC, E_DETJ, E_DOF_LAYOUT, E_VALENCE, E_COMM, E_UNSUPPORTED = (
@@ -47,7 +47,7 @@ class Profile(C.Structure):
                 ("spmv_launches", C.c_int64), ("spmv_bytes", C.c_int64),
                 ("cg_iteration_vector_bytes", C.c_int64), ("iterations", C.c_int32),
                 ("termination_type", C.c_int32), ("assembly_colours", C.c_int32),
-                ("reserved", C.c_int32), ("spmv2_ms_total", C.c_double), ("spmv2_launches", C.c_int64)]
+                ("value_stream", C.c_int32), ("spmv2_ms_total", C.c_double), ("spmv2_launches", C.c_int64)]
 
 
 class StanHipError(RuntimeError):

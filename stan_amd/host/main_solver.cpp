@@ -7,7 +7,7 @@
 // (SolverFunctions.cs:18-20 throws when stdout is redirected) and no 10 s sleep at exit
 // (Solver.cs:67-68).  LinSolver "Cholesky"/"LU" (SolverFunctions.cs:332-516) are outside the
 // hot path: the driver reports them as unsupported instead of silently using CG.
-// Extra switches (never stored in the STdb): --device N, --mixed, --no-merit-stop, --packed,
+// Extra switches (never stored in the STdb): --device N, --mixed, --fixed48, --no-merit-stop, --packed,
 // --json (one JSON line with sizes, iterations, phase times and the SpMV's HBM rate).
 #include <chrono>
 #include <cstdio>
@@ -37,13 +37,14 @@ int main(int argc, char **argv) {
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--mixed")) precision = STAN_PREC_MIXED;
+        else if (!strcmp(argv[i], "--fixed48")) precision = STAN_PREC_FIXED48;
         else if (!strcmp(argv[i], "--no-merit-stop")) merit_stop = false;
         else if (!strcmp(argv[i], "--packed")) packed = true;
         else if (!strcmp(argv[i], "--json")) json = true;
         else path = argv[i];
     }
     if (path.empty()) {  // Path = path[0] -> IndexOutOfRangeException in the reference
-        fprintf(stderr, "usage: stan_solver [--device N] [--mixed] [--no-merit-stop] <model.STdb>\n");
+        fprintf(stderr, "usage: stan_solver [--device N] [--mixed|--fixed48] [--no-merit-stop] [--packed] [--json] <model.STdb>\n");
         return 2;
     }
     SolverOptions opt;

@@ -219,6 +219,57 @@ def test_cg_mixed_precision(gpu_ctx, oracle):
     K.free()
 
 
+def test_cg_fixed48_stream(gpu_ctx, oracle):
+    """STAN_PREC_FIXED48: fp64 arithmetic on the 48-bit fixed-point copy of S K S (|a| <= 1).
+    Entries move by <= 2^-47 of the unit diagonal, so U stays inside the north-star tolerance
+    with a wide margin and the iteration history is that of the fp64 stream."""
+    from stan_amd import hip
+    job = problem.cube_job(12, jitter=0.1)
+    job.elem_mat = (np.arange(job.conn.shape[0]) % 2).astype(np.int32)
+    job.mat_E_nu = np.array([[210000.0, 0.3], [7000.0, 0.33]])   # kappa(S K S) ~ 1.2e4
+    gpu_ctx.set_profiling(True)
+    gpu_ctx.set_option(hip.OPT_CG_MERIT_STOP, 0)   # converge both runs to the residual test
+    try:
+        K, A = _assemble_both(gpu_ctx, oracle, job)
+        U64, rep64 = K.cg_solve(job.F, 1e-12, 20000)
+        U48, rep48 = K.cg_solve(job.F, 1e-12, 20000, precision_mode=hip.PREC_FIXED48)
+        assert gpu_ctx.profile()["value_stream"] == hip.PREC_FIXED48
+        assert gpu_ctx.profile()["spmv_bytes"] < 0.8 * 76 * K.info()["n_blocks"] + 20 * job.n_red
+    finally:
+        gpu_ctx.set_profiling(False)
+        gpu_ctx.set_option(hip.OPT_CG_MERIT_STOP, 1)
+    assert rep48["terminationtype"] == rep64["terminationtype"] == 1
+    assert abs(rep48["iterations"] - rep64["iterations"]) <= max(2, rep64["iterations"] // 50)
+    # quantisation alone moves U by 4e-12 here (direct solves of both matrices on the CPU);
+    # the bound leaves room for the two CG runs' own kappa * 1e-12
+    assert np.abs(U48 - U64).max() <= 1e-8 * np.abs(U64).max()
+    Uo, _ = oracle.cg(A, job.F, 1e-12)
+    assert np.abs(U48 - Uo).max() <= 1e-6 * np.abs(Uo).max()
+    assert K.spmv_bench(3, hip.PREC_FIXED48) > 0
+    # the fp64 values are untouched: export still equals the oracle's matrix
+    rowptr, cols, vals = K.to_csr()
+    assert np.abs(vals - A.vals).max() <= 1e-12 * np.abs(A.vals).max()
+    K.free()
+
+
+def test_cg_fixed48_falls_back_when_not_spd(gpu_ctx):
+    """E < 0 makes K negative definite: the scaling leaves entries far outside [-1, 1], the
+    fixed-point copy is refused and the fp64 stream reports ALGLIB's -5 as before."""
+    from stan_amd import hip
+    job = problem.cube_job(4)
+    job.mat_E_nu = np.array([[-210000.0, 0.3]])
+    K = gpu_ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type,
+                              job.mat_E_nu, job.red)
+    gpu_ctx.set_profiling(True)
+    try:
+        U, rep = K.cg_solve(job.F, 1e-8, precision_mode=hip.PREC_FIXED48)
+        assert gpu_ctx.profile()["value_stream"] == hip.PREC_FP64
+    finally:
+        gpu_ctx.set_profiling(False)
+    assert rep["terminationtype"] == -5
+    K.free()
+
+
 def test_cg_is_bit_reproducible(gpu_ctx):
     job = problem.cube_job(8, jitter=0.1)
     res = []
@@ -579,6 +630,7 @@ def test_full_size_cube_properties(gpu_ctx):
     try:
         U, rep = K.cg_solve(job.F, 1e-8)
         Um, repm = K.cg_solve(job.F, 1e-8, precision_mode=hip.PREC_MIXED)
+        Ux, repx = K.cg_solve(job.F, 1e-8, precision_mode=hip.PREC_FIXED48)
     finally:
         gpu_ctx.set_option(hip.OPT_CG_MERIT_STOP, 1)
     assert rep["terminationtype"] == 1 and rep["rel_residual"] <= 1e-8
@@ -600,6 +652,13 @@ def test_full_size_cube_properties(gpu_ctx):
     mixed_err = np.abs(Um - U).max() / np.abs(U).max()
     print("mixed-precision relative deviation at 148^3: %.2e" % mixed_err)
     assert mixed_err <= 2e-2
+    # the 48-bit fixed-point stream perturbs entries by 7e-15 of the diagonal: same iteration
+    # count, solution inside the north-star's 1e-6 with orders of magnitude to spare
+    fx_err = np.abs(Ux - U).max() / np.abs(U).max()
+    print("fixed-48 relative deviation at 148^3: %.2e (%d vs %d iterations)"
+          % (fx_err, repx["iterations"], rep["iterations"]))
+    assert repx["terminationtype"] == 1 and abs(repx["iterations"] - rep["iterations"]) <= 15
+    assert fx_err <= 1e-7
     K.free(); K2.free()
 
 
