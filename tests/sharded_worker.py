@@ -22,10 +22,12 @@ ctx.set_option(hip.OPT_OVERLAP_HALO, overlap)
 K = ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
 info = K.info()
 res = {}
-for tag, eps, prec in (("fp64", 1e-6, hip.PREC_FP64), ("mixed", 1e-5, hip.PREC_MIXED)):
+for tag, eps, prec in (("fp64", 1e-6, hip.PREC_FP64), ("mixed", 1e-5, hip.PREC_MIXED),
+                       ("fixed48", 1e-6, hip.PREC_FIXED48)):
     U, rep = K.cg_solve(job.F, eps, precision_mode=prec)
     res[tag] = (U, rep)
 np.savez(os.path.join(out_dir, "rank%d.npz" % rank), U=res["fp64"][0], Um=res["mixed"][0],
+         Ux=res["fixed48"][0], its_x=res["fixed48"][1]["iterations"],
          its=res["fp64"][1]["iterations"], term=res["fp64"][1]["terminationtype"],
          rows=np.array([info["row_begin"], info["row_end"], info["n_halo"]]))
 K.free()
