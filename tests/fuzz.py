@@ -1,0 +1,108 @@
+"""Random linear-static jobs for the fuzz parity sweep (tests/test_gpu_parity.py::test_fuzz_* and
+tools/fuzz_parity.py): a box of hexes with elements knocked out, node and element wire order
+shuffled, jittered coordinates, two materials, HEX8_G1/G2 mixed, SPC entries with partial
+components, random point loads.  Only meshes Database.AssignDOF accepts (connected) are kept."""
+import numpy as np
+
+from stan_amd import host, problem
+
+
+def random_job(seed):
+    rng = np.random.default_rng(seed)
+    nx, ny, nz = (int(v) for v in rng.integers(1, 8, 3))
+    mx, my, mz = nx + 1, ny + 1, nz + 1
+    k, j, i = np.meshgrid(np.arange(mz), np.arange(my), np.arange(mx), indexing="ij")
+    xyz = np.stack([i.ravel(), j.ravel(), k.ravel()], axis=1).astype(np.float64)
+    xyz *= rng.uniform(0.3, 3.0, 3)                       # anisotropic spacing
+    xyz += rng.uniform(-0.12, 0.12, xyz.shape) * xyz.max(axis=0).clip(1e-9) / np.array([nx, ny, nz])
+
+    def nid(a, b, c):
+        return a + mx * (b + my * c)
+    ke, je, ie = (v.ravel() for v in np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij"))
+    conn = np.stack([nid(ie, je, ke), nid(ie + 1, je, ke), nid(ie + 1, je + 1, ke), nid(ie, je + 1, ke),
+                     nid(ie, je, ke + 1), nid(ie + 1, je, ke + 1), nid(ie + 1, je + 1, ke + 1),
+                     nid(ie, je + 1, ke + 1)], axis=1)
+    keep = rng.random(conn.shape[0]) > rng.choice([0.0, 0.15, 0.4])
+    if not keep.any():
+        keep[rng.integers(conn.shape[0])] = True
+    conn = conn[keep]
+    conn = conn[rng.permutation(conn.shape[0])]          # element wire order
+    used = np.unique(conn)
+    perm = rng.permutation(used.shape[0])                 # node wire order
+    new_of_old = np.full(xyz.shape[0], -1, dtype=np.int64)
+    new_of_old[used] = perm
+    xyz2 = np.empty((used.shape[0], 3))
+    xyz2[perm] = xyz[used]
+    conn = new_of_old[conn].astype(np.int32)
+    n_nodes = used.shape[0]
+    try:
+        host.assign_dof(n_nodes, conn)
+    except Exception:
+        return None                                       # disconnected: the reference loops forever
+    # BCs: clamp a random plane-ish subset fully, plus partial components elsewhere
+    axis = int(rng.integers(3))
+    lo = xyz2[:, axis] <= np.quantile(xyz2[:, axis], 0.15)
+    spc_nodes = np.nonzero(lo)[0]
+    spc_vals = np.ones((spc_nodes.shape[0], 3))
+    extra = rng.choice(n_nodes, size=min(n_nodes, int(rng.integers(0, 6))), replace=False)
+    extra_vals = rng.integers(0, 2, (extra.shape[0], 3)).astype(np.float64)
+    extra_vals[rng.random(extra_vals.shape) < 0.1] = 2.0   # "== 1 exactly" filter (Solver.cs:110-112)
+    spc_nodes = np.concatenate([spc_nodes, extra]).astype(np.int32)
+    spc_vals = np.concatenate([spc_vals, extra_vals])
+    ld = rng.choice(n_nodes, size=max(1, n_nodes // 5), replace=True).astype(np.int32)   # duplicates add up
+    lv = rng.standard_normal((ld.shape[0], 3)) * 10.0
+    job = problem.make_job(xyz2, conn, spc_nodes, spc_vals, ld, lv)
+    job.elem_mat = rng.integers(0, 2, conn.shape[0]).astype(np.int32)
+    job.mat_E_nu = np.array([[210000.0, 0.3], [float(rng.uniform(500, 70000)), float(rng.uniform(0.0, 0.42))]])
+    g1 = rng.random() < 0.3
+    job.elem_type = (rng.integers(1, 3, conn.shape[0]) if g1 else np.full(conn.shape[0], 2)).astype(np.uint8)
+    job.has_g1 = bool(g1 and (job.elem_type == 1).any())
+    return job
+
+
+def check_job(ctx, oracle, job, cg=True):
+    """Assembly pattern bit-exact, values to 1e-12, CG to the oracle's answer.  Returns a dict."""
+    K = ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+    rc, A = oracle.assemble(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+    assert rc == 0
+    out = {"n_red": int(job.n_red), "nnz": int(A.nnz)}
+    if job.n_red == 0:
+        K.free()
+        return out
+    rowptr, col, val = K.to_csr(upper_only=True)
+    assert np.array_equal(rowptr, A.ridx) and np.array_equal(col, A.idx)
+    out["k_err"] = float(np.abs(val - A.vals).max() / np.abs(A.vals).max())
+    assert out["k_err"] <= 1e-12
+    if cg and not job.has_g1:          # G1 elements leave hourglass modes: K may be singular
+        import scipy.sparse as sp
+        Au = sp.csr_matrix((A.vals, A.idx, A.ridx), shape=(A.n, A.n))
+        Af = Au + sp.triu(Au, 1).T
+        fn = np.linalg.norm(job.F)
+        # merit stop off on both sides: the type-7 stop lands wherever rounding lets the merit
+        # function tick up (residuals a decade apart between two correct runs); the residual
+        # test is the comparable end state
+        ctx.set_option(1, 0)   # STAN_OPT_CG_MERIT_STOP
+        try:
+            U, rep = K.cg_solve(job.F, 1e-9, 20000)
+            U48, rep48 = K.cg_solve(job.F, 1e-9, 20000, precision_mode=2)
+        finally:
+            ctx.set_option(1, 1)
+        Uo, repo = oracle.cg(A, job.F, 1e-9, 20000, merit_stop=False)
+        out["term"] = (rep["terminationtype"], repo["terminationtype"])
+        out["its"] = (rep["iterations"], repo["iterations"])
+        # a floating sub-structure (no SPC reaches it) makes K singular: neither side converges
+        # and the codes may differ; compare only where the oracle converged
+        if repo["terminationtype"] == 1 and fn > 0:
+            assert rep["terminationtype"] == 1, out
+            if repo["iterations"] <= job.n_red:   # beyond N iterations CG runs on rounding noise
+                assert abs(rep["iterations"] - repo["iterations"]) <= max(5, repo["iterations"] // 10), out
+            out["res"] = (float(np.linalg.norm(job.F - Af @ U) / fn), float(np.linalg.norm(job.F - Af @ Uo) / fn))
+            # independent residual in the UNSCALED norm; the stopping test is on the scaled one
+            assert out["res"][0] <= max(10 * out["res"][1], 1e-7), out
+            out["u_err"] = float(np.abs(U - Uo).max() / np.abs(Uo).max())
+            assert out["u_err"] <= 1e-5, out                          # kappa * 1e-9, two runs
+            assert rep48["terminationtype"] == 1, out
+            out["res48"] = float(np.linalg.norm(job.F - Af @ U48) / fn)
+            assert out["res48"] <= max(10 * out["res"][1], 1e-7), out
+    K.free()
+    return out

@@ -662,6 +662,21 @@ def test_full_size_cube_properties(gpu_ctx):
     K.free(); K2.free()
 
 
+def test_fuzz_random_jobs_against_oracle(gpu_ctx, oracle):
+    """Random sub-meshes with shuffled wire order, two materials, G1/G2 mixes, partial SPCs and
+    duplicate loads (tests/fuzz.py; tools/fuzz_parity.py runs the long sweep): pattern bit-exact,
+    values to 1e-12, CG checked through an independent residual."""
+    from tests import fuzz
+    checked = 0
+    for seed in range(40):
+        job = fuzz.random_job(seed)
+        if job is None:
+            continue
+        fuzz.check_job(gpu_ctx, oracle, job)
+        checked += 1
+    assert checked >= 25
+
+
 def test_more_ranks_than_slices(built_libs):
     """A 27-node mesh cut for 8 ranks: rank 7 owns the only slice, the others own nothing and
     must still assemble (empty shard) without an error."""

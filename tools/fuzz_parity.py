@@ -1,0 +1,32 @@
+"""Fuzz sweep of the hot path against the oracle (tests/fuzz.py): python tools/fuzz_parity.py [first] [count]"""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch  # noqa
+from stan_amd import hip
+from oracle import pyoracle as oracle
+from tests import fuzz
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+ctx = hip.Context(0)
+ok = skipped = 0
+worst = {"k_err": 0.0, "u_err": 0.0, "res": 0.0, "res48": 0.0}
+for seed in range(first, first + count):
+    job = fuzz.random_job(seed)
+    if job is None:
+        skipped += 1
+        continue
+    try:
+        out = fuzz.check_job(ctx, oracle, job)
+    except AssertionError as e:
+        print("seed %d FAILED: %s" % (seed, e))
+        raise
+    ok += 1
+    worst["k_err"] = max(worst["k_err"], out.get("k_err", 0.0))
+    worst["u_err"] = max(worst["u_err"], out.get("u_err", 0.0))
+    worst["res"] = max(worst["res"], out.get("res", (0.0, 0.0))[0])
+    worst["res48"] = max(worst["res48"], out.get("res48", 0.0))
+    if seed % 20 == 0:
+        print("seed %d: %s" % (seed, out), flush=True)
+print("fuzz: %d jobs checked, %d disconnected meshes skipped; worst %s" % (ok, skipped, worst))
