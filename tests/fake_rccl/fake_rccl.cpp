@@ -6,8 +6,10 @@
 // Selected only through the environment variable STAN_RCCL_LIB; the product default is the
 // real librccl.so.1.  Every call is synchronous (it drains the stream it is given).
 //
-// Semantics kept from NCCL: collectives are matched by call order; ncclSend/ncclRecv pair up
-// per (source, destination) in issue order inside a group; ncclAllReduce sums in rank order.
+// Semantics kept from NCCL: collectives (all-reduce, broadcast) are matched by call order and
+// need EVERY rank; ncclSend/ncclRecv involve only the two peers (a one-message mailbox per
+// ordered pair with produce/consume counters, so ranks without neighbours never take part) and
+// pair up per (source, destination) in issue order; ncclAllReduce sums in rank order.
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <sched.h>
@@ -23,7 +25,8 @@
 namespace {
 
 constexpr int MAXR = 16;
-constexpr size_t MAILBOX = 64u << 20;  // bytes per rank
+constexpr size_t MAILBOX = 64u << 20;  // bytes per rank (collectives)
+constexpr size_t PAIRBOX = 4u << 20;   // bytes per ordered pair (send/recv); shm pages are lazy
 constexpr int MAXOPS = 256;
 
 struct Desc { int peer; int kind; size_t off, bytes; };  // kind 0 = send to peer, 1 = broadcast
@@ -32,10 +35,13 @@ struct Header {
     int nranks;
     int nops[MAXR];
     Desc ops[MAXR][MAXOPS];
+    std::atomic<long> produced[MAXR][MAXR], consumed[MAXR][MAXR];  // [src][dst]
+    size_t pair_bytes[MAXR][MAXR];
 };
 struct Comm {
     Header *h;
-    char *box;  // nranks mailboxes
+    char *box;   // nranks mailboxes
+    char *pbox;  // nranks x nranks pair mailboxes
     int rank, nranks;
     int local_sense;
     char name[64];
@@ -56,45 +62,65 @@ void barrier(Comm *c) {
 }
 size_t tsize(int dt) { return dt == 1 ? 1 : 8; }  // ncclUint8 = 1; ncclInt64 = 4 and ncclFloat64 = 8 are 8 bytes
 
+char *pair_box(Comm *c, int src, int dst) { return c->pbox + ((size_t)src * c->nranks + dst) * PAIRBOX; }
+
 int flush_group(Comm *c) {
     if (!c) return 5;
     for (const Op &o : g_ops) hipStreamSynchronize(o.st);
-    // phase 1: publish what this rank sends / broadcasts
+    // point-to-point: all sends of the group first (one message in flight per ordered pair),
+    // then the receives -- only the two peers of a message ever wait for each other
+    for (const Op &o : g_ops) {
+        if (o.kind != 0) continue;
+        if (o.bytes > PAIRBOX) { fprintf(stderr, "fake_rccl: message larger than the pair mailbox\n"); return 5; }
+        std::atomic<long> &pr = c->h->produced[c->rank][o.peer], &co = c->h->consumed[c->rank][o.peer];
+        while (co.load() != pr.load()) sched_yield();   // previous message not yet taken
+        hipMemcpy(pair_box(c, c->rank, o.peer), o.src, o.bytes, hipMemcpyDeviceToHost);
+        c->h->pair_bytes[c->rank][o.peer] = o.bytes;
+        pr.fetch_add(1);
+    }
+    for (const Op &o : g_ops) {
+        if (o.kind != 1) continue;
+        std::atomic<long> &pr = c->h->produced[o.peer][c->rank], &co = c->h->consumed[o.peer][c->rank];
+        while (pr.load() == co.load()) sched_yield();
+        if (c->h->pair_bytes[o.peer][c->rank] != o.bytes) {
+            fprintf(stderr, "fake_rccl: rank %d expected %zu bytes from %d, message has %zu\n", c->rank, o.bytes,
+                    o.peer, c->h->pair_bytes[o.peer][c->rank]);
+            return 5;
+        }
+        hipMemcpy(o.dst, pair_box(c, o.peer, c->rank), o.bytes, hipMemcpyHostToDevice);
+        co.fetch_add(1);
+    }
+    bool any_bc = false;
+    for (const Op &o : g_ops) any_bc |= o.kind == 2;
+    if (!any_bc) { g_ops.clear(); return 0; }
+    // broadcasts (collective: every rank is here): phase 1, the roots publish
     size_t off = 0;
     int n = 0;
     char *mine = c->box + (size_t)c->rank * MAILBOX;
     for (const Op &o : g_ops) {
-        if (o.kind == 1) continue;
-        if (o.kind == 2 && o.peer != c->rank) continue;  // not the root of this broadcast
+        if (o.kind != 2 || o.peer != c->rank) continue;  // not the root of this broadcast
         if (off + o.bytes > MAILBOX || n >= MAXOPS) { fprintf(stderr, "fake_rccl: mailbox overflow\n"); return 5; }
         hipMemcpy(mine + off, o.src, o.bytes, hipMemcpyDeviceToHost);
-        c->h->ops[c->rank][n++] = Desc{o.kind == 0 ? o.peer : -1, o.kind == 0 ? 0 : 1, off, o.bytes};
+        c->h->ops[c->rank][n++] = Desc{-1, 1, off, o.bytes};
         off += o.bytes;
     }
     c->h->nops[c->rank] = n;
     barrier(c);
-    // phase 2: pick up what is addressed to this rank, matching in issue order per source
-    int taken_send[MAXR] = {0}, taken_bc[MAXR] = {0};
+    // phase 2: pick up, matching in issue order per root
+    int taken_bc[MAXR] = {0};
     for (const Op &o : g_ops) {
-        if (o.kind == 0) continue;
-        if (o.kind == 2 && o.peer == c->rank) {  // root: in place or copy to recv buffer
+        if (o.kind != 2) continue;
+        if (o.peer == c->rank) {  // root: in place or copy to recv buffer
             if (o.dst != o.src) hipMemcpy(o.dst, o.src, o.bytes, hipMemcpyDeviceToDevice);
-            taken_bc[c->rank]++;
             continue;
         }
         const int src = o.peer;
-        const int want_kind = o.kind == 1 ? 0 : 1;
-        int &taken = want_kind == 0 ? taken_send[src] : taken_bc[src];
-        int seen = 0;
-        const Desc *d = nullptr;
-        for (int i = 0; i < c->h->nops[src]; i++) {
-            const Desc &q = c->h->ops[src][i];
-            if (q.kind != want_kind || (want_kind == 0 && q.peer != c->rank)) continue;
-            if (seen++ == taken) { d = &q; break; }
+        if (taken_bc[src] >= c->h->nops[src] || c->h->ops[src][taken_bc[src]].bytes != o.bytes) {
+            fprintf(stderr, "fake_rccl: rank %d found no matching broadcast from %d\n", c->rank, src);
+            return 5;
         }
-        if (!d || d->bytes != o.bytes) { fprintf(stderr, "fake_rccl: rank %d found no matching message from %d\n", c->rank, src); return 5; }
-        hipMemcpy(o.dst, c->box + (size_t)src * MAILBOX + d->off, o.bytes, hipMemcpyHostToDevice);
-        taken++;
+        const Desc &d = c->h->ops[src][taken_bc[src]++];
+        hipMemcpy(o.dst, c->box + (size_t)src * MAILBOX + d.off, o.bytes, hipMemcpyHostToDevice);
     }
     barrier(c);
     g_ops.clear();
@@ -117,7 +143,7 @@ int ncclCommInitRank(void **comm, int nranks, nccl_uid id, int rank) {
     Comm *c = new Comm();
     c->rank = rank; c->nranks = nranks; c->local_sense = 0;
     strncpy(c->name, id.internal, 63);
-    c->bytes = sizeof(Header) + (size_t)nranks * MAILBOX;
+    c->bytes = sizeof(Header) + (size_t)nranks * MAILBOX + (size_t)nranks * nranks * PAIRBOX;
     int fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
     if (fd < 0 || ftruncate(fd, (off_t)c->bytes) != 0) return 2;
     void *p = mmap(nullptr, c->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
@@ -125,6 +151,7 @@ int ncclCommInitRank(void **comm, int nranks, nccl_uid id, int rank) {
     if (p == MAP_FAILED) return 2;
     c->h = (Header *)p;  // a fresh shm segment is zero-filled: arrived = sense = 0
     c->box = (char *)p + sizeof(Header);
+    c->pbox = c->box + (size_t)nranks * MAILBOX;
     c->h->nranks = nranks;
     c->h->init.fetch_add(1);
     while (c->h->init.load() < nranks) sched_yield();

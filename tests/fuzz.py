@@ -106,3 +106,32 @@ def check_job(ctx, oracle, job, cg=True):
             assert out["res48"] <= max(10 * out["res"][1], 1e-7), out
     K.free()
     return out
+
+
+def check_shards(ctx_factory, job, nranks):
+    """Detached ranks on one GPU: device halo plan == host plan, shard x [owned | halo] equals the
+    rows of the unsharded product bit for bit, interior/boundary slice lists cover every slice."""
+    from stan_amd import host
+    args = (job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+    ctx = ctx_factory()
+    K1 = ctx.assemble_hex8(*args)
+    x = np.random.default_rng(nranks).standard_normal(job.n_dof)
+    y_ref = K1.spmv_local(x)
+    K1.free()
+    covered = 0
+    for r in range(nranks):
+        ctx.comm_init(r, nranks, None)
+        K = ctx.assemble_hex8(*args)
+        dev, ref = K.plan(), host.partition_plan(job.node_index, job.conn, nranks, r)
+        assert np.array_equal(dev["row_starts"][:nranks + 1], ref["row_starts"])
+        for k in ("halo_glob", "nbr", "send_off", "recv_off", "send_rows"):
+            assert np.array_equal(dev[k], ref[k]), (k, r, nranks)
+        r0, r1 = dev["row_begin"], dev["row_end"]
+        xb = x.reshape(-1, 3)
+        x_local = np.concatenate([xb[r0:r1], xb[dev["halo_glob"]]]).ravel()
+        y = K.spmv_local(x_local)
+        assert np.array_equal(y, y_ref[3 * r0:3 * r1]), (r, nranks)
+        covered += r1 - r0
+        K.free()
+    assert covered == job.xyz.shape[0]
+    ctx.close()

@@ -10,10 +10,14 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 from stan_amd import hip, problem  # noqa: E402
 
-n, out_dir, overlap = int(sys.argv[1]), sys.argv[2], int(sys.argv[3])
+spec, out_dir, overlap = sys.argv[1], sys.argv[2], int(sys.argv[3])
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
-job = problem.cube_job(n, jitter=0.05)
+if spec.startswith("fuzz:"):   # tests/fuzz.py job: shuffled wire order, several neighbours, empty ranks
+    from tests import fuzz
+    job = fuzz.random_job(int(spec[5:]))
+else:
+    job = problem.cube_job(int(spec), jitter=0.05)
 ctx = hip.Context(0)
 box = [ctx.unique_id() if rank == 0 else None]
 dist.broadcast_object_list(box, 0)

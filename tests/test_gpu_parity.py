@@ -677,6 +677,23 @@ def test_fuzz_random_jobs_against_oracle(gpu_ctx, oracle):
     assert checked >= 25
 
 
+def test_fuzz_shards_of_random_jobs(built_libs):
+    """The partition / halo plan on shuffled, knocked-out meshes (row ranges far thinner than the
+    BFS levels, neighbours beyond rank+-1, empty ranks): device plan == host plan, shard products
+    bit-equal to the unsharded one."""
+    import torch  # noqa: F401
+    from stan_amd import hip
+    from tests import fuzz
+    checked = 0
+    for seed in range(100, 124):
+        job = fuzz.random_job(seed)
+        if job is None:
+            continue
+        fuzz.check_shards(lambda: hip.Context(0), job, 2 + seed % 6)
+        checked += 1
+    assert checked >= 15
+
+
 def test_more_ranks_than_slices(built_libs):
     """A 27-node mesh cut for 8 ranks: rank 7 owns the only slice, the others own nothing and
     must still assemble (empty shard) without an error."""

@@ -31,13 +31,19 @@ def _torchrun(nproc, script_args, env_extra):
     return subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
 
 
-@pytest.mark.parametrize("world,overlap", [(2, 1), (3, 1), (3, 0)])
-def test_sharded_solve_matches_oracle(built_libs, oracle, tmp_path, world, overlap):
+@pytest.mark.parametrize("world,overlap,spec", [(2, 1, "12"), (3, 1, "12"), (3, 0, "12"),
+                                                (6, 1, "fuzz:124"), (7, 1, "fuzz:101")])
+def test_sharded_solve_matches_oracle(built_libs, oracle, tmp_path, world, overlap, spec):
+    """fuzz:124 = 383 shuffled nodes on 6 ranks (up to 4 neighbours per rank); fuzz:101 = 191 nodes
+    on 7 ranks, four of which own no rows."""
     assert os.path.exists(FAKE), "run __graft_entry__.build()"
-    n = 12
-    out = _torchrun(world, [os.path.join(ROOT, "tests", "sharded_worker.py"), str(n), str(tmp_path), str(overlap)], {})
+    out = _torchrun(world, [os.path.join(ROOT, "tests", "sharded_worker.py"), spec, str(tmp_path), str(overlap)], {})
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
-    job = problem.cube_job(n, jitter=0.05)
+    if spec.startswith("fuzz:"):
+        from tests import fuzz
+        job = fuzz.random_job(int(spec[5:]))
+    else:
+        job = problem.cube_job(int(spec), jitter=0.05)
     rc, A = oracle.assemble(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
     Uo, rep = oracle.cg(A, job.F, 1e-6)   # above the type-7 floor (1.7e-7 here)
     Ux, _ = oracle.cg(A, job.F, 1e-12)
@@ -53,7 +59,8 @@ def test_sharded_solve_matches_oracle(built_libs, oracle, tmp_path, world, overl
         assert abs(int(d["its_x"]) - int(d["its"])) <= 1
         assert np.array_equal(d["U"], r0["U"])                            # every rank gets the same U
         rows.append(d["rows"])
-    assert rows[0][0] == 0 and rows[-1][1] == job.xyz.shape[0] and all(r[2] > 0 for r in rows)
+    assert rows[0][0] == 0 and rows[-1][1] == job.xyz.shape[0]
+    assert all(r[2] > 0 for r in rows if r[1] > r[0])     # every rank that owns rows has a halo
 
 
 def test_bench_multi_rank_code_path(built_libs):
