@@ -49,3 +49,19 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(base, f)).read()
                 assert "pyoracle" not in src and "stan_oracle" not in src, f  # test guards itself
+
+
+def test_plain_c_consumer_builds_and_fails_loudly_without_a_gpu(built_libs):
+    """tests/c_abi/consumer.c is compiled with -std=c99 -pedantic -Werror against include/ only
+    (the headers are C, not C++-only) and drives the host steps; without a GPU the device entry
+    point refuses with a message instead of computing anything on the CPU."""
+    import subprocess
+    import torch
+    exe = os.path.join(ROOT, "tests", "c_abi", "consumer")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_parity.py::test_plain_c_consumer_end_to_end")
+    out = subprocess.run([exe, "2"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 3, out.stdout + out.stderr
+    assert "nodes 27 elements 8 nDOF 81 fixed 27 N 54" in out.stdout     # SURVEY.md Appendix E, n = 2
+    assert "stan_hip_init failed" in out.stderr

@@ -406,6 +406,25 @@ def test_native_console_driver_end_to_end(built_libs, oracle, tmp_path):
     assert open(path, "rb").read() == before
 
 
+def test_plain_c_consumer_end_to_end(built_libs, oracle, tmp_path):
+    """A C99 program written against include/*.h only (tests/c_abi/consumer.c) runs AssignDOF ->
+    reduction -> assemble -> CG -> write-back -> stress recovery; its displacements equal the
+    oracle's."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "c_abi", "consumer")
+    n = 6
+    out = subprocess.run([exe, str(n), str(tmp_path / "disp.bin")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "NORMAL" in out.stdout
+    disp = np.fromfile(str(tmp_path / "disp.bin"), dtype=np.float64).reshape(-1, 3)
+    job = problem.cube_job(n)
+    rc, A = oracle.assemble(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+    Uo, rep = oracle.cg(A, job.F, 1e-10)
+    full = oracle.include_bc(job.red, Uo)
+    assert np.abs(disp - full[job.node_dof]).max() <= 1e-6 * np.abs(Uo).max()
+
+
 @pytest.mark.parametrize("nranks", [2, 3, 8])
 def test_shards_and_halo_plan_on_one_gpu(built_libs, nranks):
     """Every rank's shard, assembled as a DETACHED rank on this GPU: the device-derived halo
