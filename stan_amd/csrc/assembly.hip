@@ -309,8 +309,8 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
     for (int i = tid; i < 16 * sw; i += 256) {
         const int r16 = i & 15, k = i >> 4;
         const int32_t lc = A.cols[((int64_t)k0 + k) * 64 + q * 16 + r16];
-        colsl[r16 * W + k] = lc;
         const int64_t g = lc < A.nloc ? A.r0 + lc : (int64_t)A.halo_glob[lc - A.nloc];
+        colsl[r16 * W + k] = (int32_t)g;  // GLOBAL block column: ascending along the row
         cfix[r16 * W + k] = A.fixmask[g];
     }
     __syncthreads();
@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
         const int64_t p0 = P0[i];
         const int deg = DEG[i];
         const int rl = RL[i];
-        for (int c0 = 0; c0 < deg; c0 += 8) {
+        for (int c0 = 0; c0 < (STAN_ABL == 6 ? 0 : deg); c0 += 8) {
             const bool valid = c0 + s < deg;
             int32_t e = 0, a = 0, type = STAN_HEX8_G2, colg = 0;
             double lam = 0, G = 0;
@@ -403,7 +403,12 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
             if (valid) {
                 // phase A: this lane = Gauss point b of incidence s
                 double o[10];
+#if STAN_ABL == 5
+                double det = 1.0;
+                for (int j = 0; j < 10; j++) o[j] = xsw[s * 24 + j];
+#else
                 const double det = hex8_gp_setup(xsw + s * 24, type, b, o);
+#endif
                 if (det == 0.0 && hex8_gauss_weight(type, b) != 0.0)
                     atomicMin(A.bad_elem, (long long)e);
 #pragma unroll
@@ -421,16 +426,21 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
 #else
                 hex8_block_ab(gpw + s * 10, 8 * 10, type, a, b, lam, G, kb);
 #endif
-                // phase C: slot of column colg in this row (columns ascending)
-                const int32_t lc = (colg >= A.r0 && colg < A.r1)
-                                       ? (int32_t)(colg - A.r0)
-                                       : (int32_t)(A.nloc + A.halo_rank[colg]);
+                // phase C: slot of column colg in this row.  The row's columns ascend in GLOBAL
+                // index (the symbolic phase sorted them), so a binary search over the global
+                // indices staged in LDS finds it in log2(rl) steps, the same for every lane
+                // (a linear scan made the wave wait for its slowest lane: 3.6 -> 0.9 ms at 148^3).
                 const int32_t *cl = colsl + r16 * W;
-                // columns ascend in GLOBAL index; halo columns below r0 sort first globally
-                // but last locally, so the local list is not monotone: search linearly
-                // (rows are ~27 long).
-                for (int k = 0; k < rl; k++)
-                    if (cl[k] == lc) { pos = k; break; }
+#if STAN_ABL == 4
+                pos = (lane * 7) % rl; (void)cl;
+#else
+                int lo = 0, hi = rl;  // invariant: cl[lo-1] < colg <= cl[hi]
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (cl[mid] < colg) lo = mid + 1; else hi = mid;
+                }
+                pos = (lo < rl && cl[lo] == colg) ? lo : -1;
+#endif
             }
             // phase D: ordered accumulation, incidence by incidence (ascending element index)
             int isdup = 0;
@@ -503,23 +513,33 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
     __syncthreads();
 
     // write-out with the essential BCs applied: 16 consecutive lanes = one full 128-B line
-    for (int t = tid; t < (STAN_ABL == 3 ? 16 : 16 * sw * 9); t += 256) {
-        const int r16 = t & 15, kc = t >> 4;
-        const int comp = kc % 9, k = kc / 9;
+    // a thread keeps its row (t & 15 is loop-invariant) and walks (k, comp) by 16 per step
+    {
+        const int r16 = tid & 15;
         const int64_t row = row_base + r16;
-        double v = 0.0;
-        if (row < A.nloc) {
-            v = acc[(r16 * W + k) * 9 + comp];
-            const int m = comp / 3, n = comp - 3 * m;
-            const int rfix = A.fixmask[A.r0 + row];
-            const int cf = cfix[r16 * W + k];
-            const bool fixed = ((rfix >> m) & 1) || ((cf >> n) & 1);
-            if (k >= A.rowlen[row])
-                v = 0.0;
-            else if (fixed)
-                v = (colsl[r16 * W + k] == (int32_t)row && m == n) ? 1.0 : 0.0;
+        const bool live = row < A.nloc;
+        const int rfix = live ? A.fixmask[A.r0 + row] : 0;
+        const int rlen = live ? A.rowlen[row] : 0;
+        const int32_t grow = (int32_t)(A.r0 + row);
+        int kc = tid >> 4;                 // = k * 9 + comp
+        int k = kc / 9, comp = kc - 9 * k;
+        double *out = A.vals + (int64_t)k0 * 9 * 64 + q * 16 + r16;
+        const int kc_end = STAN_ABL == 3 ? 1 : sw * 9;
+        for (; kc < kc_end; kc += 16) {
+            double v = 0.0;
+            if (k < rlen) {
+                const int m = comp >= 6 ? 2 : comp >= 3 ? 1 : 0, n = comp - 3 * m;
+                const int cf = cfix[r16 * W + k];
+                if (((rfix >> m) & 1) || ((cf >> n) & 1))
+                    v = (colsl[r16 * W + k] == grow && m == n) ? 1.0 : 0.0;
+                else
+                    v = acc[(r16 * W + k) * 9 + comp];
+            }
+            out[(int64_t)kc * 64] = v;
+            comp += 16 - 9;                // 16 = 9 + 7
+            k += 1;
+            if (comp >= 9) { comp -= 9; k += 1; }
         }
-        A.vals[(((int64_t)k0 + k) * 9 + comp) * 64 + q * 16 + r16] = v;
     }
 }
 
