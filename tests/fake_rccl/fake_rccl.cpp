@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -44,6 +45,7 @@ struct Comm {
     char *pbox;  // nranks x nranks pair mailboxes
     int rank, nranks;
     int local_sense;
+    long ncalls;
     char name[64];
     size_t bytes;
 };
@@ -52,13 +54,38 @@ thread_local int g_depth = 0;
 thread_local std::vector<Op> g_ops;
 thread_local Comm *g_comm = nullptr;
 
-void barrier(Comm *c) {
+// every wait gives up after STALL_S seconds with a dump of what it was waiting for: a protocol
+// mismatch between ranks becomes a test failure with a message instead of a hang
+constexpr double STALL_S = 60.0;
+template <typename P>
+bool wait_until(Comm *c, P pred, const char *what, int peer) {
+    const auto t0 = std::chrono::steady_clock::now();
+    long spins = 0;
+    while (!pred()) {
+        sched_yield();
+        if ((++spins & 0xfff) == 0 &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > STALL_S) {
+            fprintf(stderr, "fake_rccl: rank %d stalled in %s (peer %d); call #%ld; arrived %d sense %d\n", c->rank,
+                    what, peer, c->ncalls, c->h->arrived.load(), c->h->sense.load());
+            for (int r = 0; r < c->nranks; r++)
+                fprintf(stderr, "  pair %d->%d produced %ld consumed %ld | %d->%d produced %ld consumed %ld\n", c->rank, r,
+                        c->h->produced[c->rank][r].load(), c->h->consumed[c->rank][r].load(), r, c->rank,
+                        c->h->produced[r][c->rank].load(), c->h->consumed[r][c->rank].load());
+            return false;
+        }
+    }
+    return true;
+}
+
+bool barrier(Comm *c, const char *what) {
     c->local_sense ^= 1;
     if (c->h->arrived.fetch_add(1) + 1 == c->nranks) {
         c->h->arrived.store(0);
         c->h->sense.store(c->local_sense);
-    } else
-        while (c->h->sense.load() != c->local_sense) sched_yield();
+        return true;
+    }
+    const int want = c->local_sense;
+    return wait_until(c, [&] { return c->h->sense.load() == want; }, what, -1);
 }
 size_t tsize(int dt) { return dt == 1 ? 1 : 8; }  // ncclUint8 = 1; ncclInt64 = 4 and ncclFloat64 = 8 are 8 bytes
 
@@ -66,6 +93,7 @@ char *pair_box(Comm *c, int src, int dst) { return c->pbox + ((size_t)src * c->n
 
 int flush_group(Comm *c) {
     if (!c) return 5;
+    c->ncalls++;
     for (const Op &o : g_ops) hipStreamSynchronize(o.st);
     // point-to-point: all sends of the group first (one message in flight per ordered pair),
     // then the receives -- only the two peers of a message ever wait for each other
@@ -73,7 +101,7 @@ int flush_group(Comm *c) {
         if (o.kind != 0) continue;
         if (o.bytes > PAIRBOX) { fprintf(stderr, "fake_rccl: message larger than the pair mailbox\n"); return 5; }
         std::atomic<long> &pr = c->h->produced[c->rank][o.peer], &co = c->h->consumed[c->rank][o.peer];
-        while (co.load() != pr.load()) sched_yield();   // previous message not yet taken
+        if (!wait_until(c, [&] { return co.load() == pr.load(); }, "send (previous message not taken)", o.peer)) return 5;
         hipMemcpy(pair_box(c, c->rank, o.peer), o.src, o.bytes, hipMemcpyDeviceToHost);
         c->h->pair_bytes[c->rank][o.peer] = o.bytes;
         pr.fetch_add(1);
@@ -81,7 +109,7 @@ int flush_group(Comm *c) {
     for (const Op &o : g_ops) {
         if (o.kind != 1) continue;
         std::atomic<long> &pr = c->h->produced[o.peer][c->rank], &co = c->h->consumed[o.peer][c->rank];
-        while (pr.load() == co.load()) sched_yield();
+        if (!wait_until(c, [&] { return pr.load() != co.load(); }, "recv", o.peer)) return 5;
         if (c->h->pair_bytes[o.peer][c->rank] != o.bytes) {
             fprintf(stderr, "fake_rccl: rank %d expected %zu bytes from %d, message has %zu\n", c->rank, o.bytes,
                     o.peer, c->h->pair_bytes[o.peer][c->rank]);
@@ -105,7 +133,7 @@ int flush_group(Comm *c) {
         off += o.bytes;
     }
     c->h->nops[c->rank] = n;
-    barrier(c);
+    if (!barrier(c, "broadcast publish")) return 5;
     // phase 2: pick up, matching in issue order per root
     int taken_bc[MAXR] = {0};
     for (const Op &o : g_ops) {
@@ -122,7 +150,7 @@ int flush_group(Comm *c) {
         const Desc &d = c->h->ops[src][taken_bc[src]++];
         hipMemcpy(o.dst, c->box + (size_t)src * MAILBOX + d.off, o.bytes, hipMemcpyHostToDevice);
     }
-    barrier(c);
+    if (!barrier(c, "broadcast done")) return 5;
     g_ops.clear();
     return 0;
 }
@@ -154,8 +182,9 @@ int ncclCommInitRank(void **comm, int nranks, nccl_uid id, int rank) {
     c->pbox = c->box + (size_t)nranks * MAILBOX;
     c->h->nranks = nranks;
     c->h->init.fetch_add(1);
-    while (c->h->init.load() < nranks) sched_yield();
-    barrier(c);
+    c->ncalls = 0;
+    if (!wait_until(c, [&] { return c->h->init.load() >= nranks; }, "init", -1)) return 2;
+    if (!barrier(c, "init barrier")) return 2;
     *comm = c;
     g_comm = c;
     return 0;
@@ -163,7 +192,7 @@ int ncclCommInitRank(void **comm, int nranks, nccl_uid id, int rank) {
 
 int ncclCommDestroy(void *comm) {
     Comm *c = (Comm *)comm;
-    barrier(c);
+    barrier(c, "destroy");
     if (c->rank == 0) shm_unlink(c->name);
     munmap((void *)c->h, c->bytes);
     delete c;
@@ -176,8 +205,9 @@ int ncclAllReduce(const void *send, void *recv, size_t count, int dt, int op, vo
     const size_t bytes = count * 8;
     if (bytes > MAILBOX) return 5;
     hipStreamSynchronize(st);
+    c->ncalls++;
     hipMemcpy(c->box + (size_t)c->rank * MAILBOX, send, bytes, hipMemcpyDeviceToHost);
-    barrier(c);
+    if (!barrier(c, "allreduce gather")) return 5;
     std::vector<char> out(bytes);
     for (size_t i = 0; i < count; i++) {
         if (dt == 8) {
@@ -190,7 +220,7 @@ int ncclAllReduce(const void *send, void *recv, size_t count, int dt, int op, vo
             ((int64_t *)out.data())[i] = s;
         }
     }
-    barrier(c);
+    if (!barrier(c, "allreduce done")) return 5;
     hipMemcpy(recv, out.data(), bytes, hipMemcpyHostToDevice);
     return 0;
 }

@@ -5,6 +5,7 @@ assembly, halo plan, the CG loop with its exchanges, the two-stream overlap, the
 and bench.py's N > 1 code path."""
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -25,10 +26,25 @@ def _port():
 
 
 def _torchrun(nproc, script_args, env_extra):
-    env = dict(os.environ, STAN_RCCL_LIB=FAKE, **env_extra)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
-           "--master-addr", "127.0.0.1", "--master-port", str(_port())] + script_args
-    return subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    """Several ranks sharing ONE GPU through the shared-memory RCCL stand-in.  The stand-in gives up
+    after 60 s of waiting with a dump of its counters (tests/fake_rccl); one such stall was seen in
+    ~40 runs of the 6-rank case and never reproduced, so a timed-out attempt is repeated once and
+    its output is shown."""
+    for attempt in (1, 2):
+        env = dict(os.environ, STAN_RCCL_LIB=FAKE, **env_extra)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+               "--master-addr", "127.0.0.1", "--master-port", str(_port())] + script_args
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
+                                cwd=ROOT, start_new_session=True)   # own process group: launcher + ranks
+        try:
+            out, err = proc.communicate(timeout=240)
+            return subprocess.CompletedProcess(cmd, proc.returncode, out, err)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)                      # exactly the group started above
+            out, err = proc.communicate()
+            print("sharded run timed out (attempt %d):\n%s" % (attempt, (err or "")[-3000:]))
+            if attempt == 2:
+                raise
 
 
 @pytest.mark.parametrize("world,overlap,spec", [(2, 1, "12"), (3, 1, "12"), (3, 0, "12"),
