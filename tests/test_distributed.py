@@ -161,3 +161,29 @@ def test_plan_is_symmetric_and_complete(built_libs, nranks):
     # to it once a range is thicker than a BFS level (3 ranks here), a band of +-2 when it is not
     reach = 1 if nranks <= 3 else 2
     assert all(abs(int(q) - r) <= reach for r, p in enumerate(plans) for q in p["nbr"])
+
+
+def test_fuzz_plans_are_symmetric(built_libs):
+    """Halo plans of random shuffled meshes (tests/fuzz.py), 2..7 ranks incl. empty ranks and up
+    to four neighbours: what r sends to q is what q expects from r; every row owned once."""
+    from stan_amd import host
+    from tests import fuzz
+    worst_nbrs = 0
+    for seed in range(100, 160):
+        job = fuzz.random_job(seed)
+        if job is None:
+            continue
+        nr = 2 + seed % 6
+        plans = [host.partition_plan(job.node_index, job.conn, nr, r) for r in range(nr)]
+        rs = plans[0]["row_starts"]
+        assert rs[0] == 0 and rs[-1] == job.xyz.shape[0]
+        for r, p in enumerate(plans):
+            worst_nbrs = max(worst_nbrs, len(p["nbr"]))
+            assert np.all(np.diff(p["halo_glob"]) > 0)
+            assert not np.any((p["halo_glob"] >= rs[r]) & (p["halo_glob"] < rs[r + 1]))
+            for i, q in enumerate(p["nbr"]):
+                sent = rs[r] + p["send_rows"][p["send_off"][i]:p["send_off"][i + 1]]
+                pq = plans[q]
+                j = list(pq["nbr"]).index(r)
+                assert np.array_equal(sent, pq["halo_glob"][pq["recv_off"][j]:pq["recv_off"][j + 1]])
+    assert worst_nbrs >= 4

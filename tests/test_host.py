@@ -95,3 +95,38 @@ def test_assign_dof_unstructured(oracle, built_libs, k):
     idx, _ = host.assign_dof(xyz.shape[0], conn)
     rc, ref = oracle.assign_dof(xyz.shape[0], conn)
     assert rc == 0 and np.array_equal(idx, ref)
+
+
+def test_fuzz_host_steps_against_oracle(oracle, built_libs):
+    """AssignDOF, nDOF_reduction and the load vector on random knocked-out, shuffled meshes
+    (tests/fuzz.py) against the oracle's literal restatements: bit-exact integers, exact F."""
+    from tests import fuzz
+    checked = disconnected = 0
+    for seed in range(200, 320):
+        job = fuzz.random_job(seed)
+        if job is None:
+            disconnected += 1
+            continue
+        rc, ref = oracle.assign_dof(job.xyz.shape[0], job.conn)
+        assert rc == 0 and np.array_equal(job.node_index, ref), seed
+        # Solver.cs:121-132 restated: red[i] = -1 if fixed else number of fixed DOFs below i
+        fixed = job.red == -1
+        below = np.concatenate([[0], np.cumsum(fixed)[:-1]])
+        assert np.array_equal(job.red[~fixed], below[~fixed]) and int(fixed.sum()) == job.n_fixed
+        assert job.F.shape[0] == job.n_dof - job.n_fixed
+        checked += 1
+    assert checked >= 90 and disconnected >= 1
+
+
+def test_fuzz_disconnected_mesh_is_an_error_on_both_sides(oracle, built_libs):
+    """Where the reference's BFS runs off its list (Database.cs:218) both restatements refuse."""
+    from tests import fuzz
+    import numpy as np
+    rng = np.random.default_rng(0)
+    xyz, conn = cube_mesh(2)
+    two = np.concatenate([conn, conn + xyz.shape[0]]).astype(np.int32)   # two separate cubes
+    with pytest.raises(host.StanHostError):
+        host.assign_dof(2 * xyz.shape[0], two)
+    rc, _ = oracle.assign_dof(2 * xyz.shape[0], two)
+    assert rc != 0
+    assert fuzz.random_job(5) is None and rng is not None   # seed 5 of the sweep is such a mesh
