@@ -75,7 +75,29 @@ def cpu_baseline(n, eps):
     return base, base_all
 
 
+def ensure_built():
+    """The native libraries normally arrive prebuilt in the tree; from a bare checkout local rank 0
+    compiles them (hipcc, ~2 min) while the other ranks wait for the files.  No fallback: without
+    them nothing runs."""
+    need = [os.path.join(ROOT, "stan_amd", "lib", "libstan_hip.so"),
+            os.path.join(ROOT, "stan_amd", "lib", "libstan_host.so"),
+            os.path.join(ROOT, "oracle", "libstan_oracle.so")]
+    if all(os.path.exists(f) for f in need):
+        return
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        import __graft_entry__ as g
+        g.build()
+    else:
+        t0 = time.time()
+        while not all(os.path.exists(f) for f in need):
+            if time.time() - t0 > 900:
+                raise SystemExit("bench.py: native libraries were not built within 15 min")
+            time.sleep(2.0)
+        time.sleep(5.0)   # let the linker finish writing
+
+
 def main():
+    ensure_built()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
