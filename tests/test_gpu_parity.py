@@ -197,6 +197,33 @@ def test_cg_termination_codes(gpu_ctx, oracle):
     K.free()
 
 
+def test_cg_type7_on_a_slender_model_like_the_reference_screenshot(gpu_ctx, oracle):
+    """images/Solver.PNG: the reference's own 43 650-DOF run ends with type 7 at tolerance 1e-6.
+    A slender 115 x 10 x 10 cantilever (42 108 DOF) does the same here and in the oracle: the
+    merit-function rule fires before the residual test, and U is returned regardless."""
+    nx, ny, nz = 115, 10, 10
+    mx, my, mz = nx + 1, ny + 1, nz + 1
+    k, j, i = np.meshgrid(np.arange(mz), np.arange(my), np.arange(mx), indexing="ij")
+    xyz = np.stack([i.ravel(), j.ravel(), k.ravel()], axis=1).astype(np.float64)
+    ke, je, ie = (v.ravel() for v in np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij"))
+    nid = lambda a, b, c: a + mx * (b + my * c)  # noqa: E731
+    conn = np.stack([nid(ie, je, ke), nid(ie + 1, je, ke), nid(ie + 1, je + 1, ke), nid(ie, je + 1, ke),
+                     nid(ie, je, ke + 1), nid(ie + 1, je, ke + 1), nid(ie + 1, je + 1, ke + 1),
+                     nid(ie, je + 1, ke + 1)], axis=1).astype(np.int32)
+    spc = np.nonzero(xyz[:, 0] == 0)[0].astype(np.int32)
+    ld = np.nonzero(xyz[:, 0] == nx)[0].astype(np.int32)
+    job = problem.make_job(xyz, conn, spc, np.ones((len(spc), 3)), ld, np.tile([0.0, 0.0, 50.0], (len(ld), 1)))
+    K, A = _assemble_both(gpu_ctx, oracle, job)
+    U, rep = K.cg_solve(job.F, 1e-6)
+    Uo, repo = oracle.cg(A, job.F, 1e-6)
+    assert rep["terminationtype"] == repo["terminationtype"] == 7
+    assert rep["rel_residual"] > 1e-6 and np.isfinite(U).all() and np.abs(U).max() > 0
+    # where exactly the merit function first ticks up is decided by rounding (different summation
+    # orders on the two sides): same order of iterations, both short of the tolerance
+    assert 0.5 <= rep["iterations"] / repo["iterations"] <= 2.0
+    K.free()
+
+
 def test_cg_not_spd_is_reported_not_raised(gpu_ctx):
     # E < 0 makes K negative definite: ALGLIB reports -5 and STAN still returns U
     job = problem.cube_job(3, E=-210000.0)

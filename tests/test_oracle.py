@@ -232,3 +232,32 @@ def test_cg_restatement_tracks_textbook_jacobi_pcg(oracle):
     assert info == 0 and rep["terminationtype"] == 1
     assert abs(its[0] - rep["iterations"]) <= max(2, rep["iterations"] // 50)
     assert np.abs(s * y - U).max() <= 1e-5 * np.abs(U).max()
+
+
+def test_soft_pin_screenshot_run_ends_with_type_7(oracle):
+    """The only published run of the reference (images/Solver.PNG: 43 650 DOF, default tolerance
+    1e-6, Analysis.cs:19) ends with ALGLIB termination type 7, i.e. lincg's merit-function rule
+    fires BEFORE ||r|| <= 1e-6 ||b|| on a model of that size.  Example1 itself is not in the
+    checkout; a slender 115 x 10 x 10 cantilever of the same size class (42 108 DOF) shows the
+    restated rule doing the same, while a compact 24^3 cube (46 875 DOF) converges with type 1.
+    A soft pin of Appendix C's recall, not a golden vector."""
+    def box(nx, ny, nz):
+        mx, my, mz = nx + 1, ny + 1, nz + 1
+        k, j, i = np.meshgrid(np.arange(mz), np.arange(my), np.arange(mx), indexing="ij")
+        xyz = np.stack([i.ravel(), j.ravel(), k.ravel()], axis=1).astype(np.float64)
+        ke, je, ie = (v.ravel() for v in np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij"))
+        nid = lambda a, b, c: a + mx * (b + my * c)  # noqa: E731
+        conn = np.stack([nid(ie, je, ke), nid(ie + 1, je, ke), nid(ie + 1, je + 1, ke), nid(ie, je + 1, ke),
+                         nid(ie, je, ke + 1), nid(ie + 1, je, ke + 1), nid(ie + 1, je + 1, ke + 1),
+                         nid(ie, je + 1, ke + 1)], axis=1).astype(np.int32)
+        spc = np.nonzero(xyz[:, 0] == 0)[0].astype(np.int32)
+        ld = np.nonzero(xyz[:, 0] == nx)[0].astype(np.int32)
+        return problem.make_job(xyz, conn, spc, np.ones((len(spc), 3)), ld, np.tile([0.0, 0.0, 50.0], (len(ld), 1)))
+    out = {}
+    for dims in ((115, 10, 10), (24, 24, 24)):
+        job = box(*dims)
+        rc, A = oracle.assemble(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+        U, rep = oracle.cg(A, job.F, 1e-6)
+        out[dims] = (job.n_dof, rep["terminationtype"], rep["rel_residual"])
+    assert out[(115, 10, 10)][0] == 42108 and out[(115, 10, 10)][1] == 7 and out[(115, 10, 10)][2] > 1e-6
+    assert out[(24, 24, 24)][0] == 46875 and out[(24, 24, 24)][1] == 1
