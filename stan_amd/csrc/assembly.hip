@@ -41,7 +41,7 @@ __global__ void k_perm(int64_t n_nodes, int64_t nb_glob, const int32_t *node_dof
     const int32_t d0 = node_dof[3 * i], d1 = node_dof[3 * i + 1], d2 = node_dof[3 * i + 2];
     // Node.cs:218-223 SetDOF: DOF = {3*index, 3*index+1, 3*index+2}
     if (d0 < 0 || d0 % 3 != 0 || d1 != d0 + 1 || d2 != d0 + 2 || d0 / 3 >= nb_glob) {
-        atomicOr((unsigned long long *)&status[0], (unsigned long long)ERR_DOF_LAYOUT);
+        atomicOr((unsigned long long *)&status[SS_ERRBITS], (unsigned long long)ERR_DOF_LAYOUT);
         perm[i] = 0;
         return;
     }
@@ -62,7 +62,7 @@ __global__ void k_count_incident(int64_t n_elem, int64_t n_nodes, const int32_t 
     if (t >= n_elem * 8) return;
     const int32_t nd = conn[t];
     if (nd < 0 || nd >= n_nodes) {
-        atomicOr((unsigned long long *)&status[0], (unsigned long long)ERR_CONN_RANGE);
+        atomicOr((unsigned long long *)&status[SS_ERRBITS], (unsigned long long)ERR_CONN_RANGE);
         return;
     }
     const int64_t row = perm[nd];
@@ -146,7 +146,7 @@ k_symbolic(int64_t nloc, int64_t r0, int64_t r1, const int64_t *ptr, int32_t *li
     const int64_t p0 = ptr[row];
     int deg = (int)(ptr[row + 1] - p0);
     if (deg > STAN_MAX_INCIDENT) {
-        if (lane == 0) atomicOr((unsigned long long *)&status[0], (unsigned long long)ERR_VALENCE);
+        if (lane == 0) atomicOr((unsigned long long *)&status[SS_ERRBITS], (unsigned long long)ERR_VALENCE);
         deg = STAN_MAX_INCIDENT;
     }
     // incidence entries ascending (= ascending element index, then local node)
@@ -203,7 +203,7 @@ k_symbolic(int64_t nloc, int64_t r0, int64_t r1, const int64_t *ptr, int32_t *li
     } else if (lane == 0) {
         rowlen[row] = base;
         if (base > STAN_MAX_ROW_BLOCKS)
-            atomicOr((unsigned long long *)&status[0], (unsigned long long)ERR_ROWLEN);
+            atomicOr((unsigned long long *)&status[SS_ERRBITS], (unsigned long long)ERR_ROWLEN);
     }
 }
 
@@ -628,16 +628,16 @@ int stan_ke_batch_device(stan_ctx *ctx, int64_t n, const double *d_xyz8, double 
     double lam, G;
     stan_lame(E, nu, &lam, &G);
     long long init = 0x7fffffffffffffffLL;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_status + 8, &init, 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_status + SS_BAD_ELEM, &init, 8, hipMemcpyHostToDevice, ctx->stream));
     if (n > 0)
         hipLaunchKernelGGL(k_ke_batch, dim3((unsigned)n), dim3(64), 0, ctx->stream, n, d_xyz8, lam,
-                           G, d_type, d_out, (long long *)(ctx->d_status + 8));
+                           G, d_type, d_out, (long long *)(ctx->d_status + SS_BAD_ELEM));
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 8, ctx->d_status + 8, 8, hipMemcpyDeviceToHost,
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_BAD_ELEM, ctx->d_status + SS_BAD_ELEM, 8, hipMemcpyDeviceToHost,
                                ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->h_status[8] != init) {
-        ctx->bad_elem = ctx->h_status[8];
+    if (ctx->h_status[SS_BAD_ELEM] != init) {
+        ctx->bad_elem = ctx->h_status[SS_BAD_ELEM];
         ctx->err = "det J == 0 in element " + std::to_string(ctx->bad_elem) +
                    " (MatrixST.Inverse would throw)";
         return STAN_E_DETJ;
@@ -694,7 +694,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     HIPCHK(ctx, hipMemsetAsync(d_status, 0, 8 * 8, st));
     {
         long long init = 0x7fffffffffffffffLL;
-        HIPCHK(ctx, hipMemcpyAsync(d_status + 8, &init, 8, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(d_status + SS_BAD_ELEM, &init, 8, hipMemcpyHostToDevice, st));
     }
 
     // materials -> (lambda, G)
@@ -719,18 +719,18 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         hipLaunchKernelGGL(k_count_incident, dim3(nblk(n_elem * 8, 256)), dim3(256), 0, st, n_elem,
                            n_nodes, d_conn, d_perm, r0, r1, d_cnt, d_status);
     STANCHK(stan_scan_exclusive(ctx, d_cnt, d_ptr, nrows_pad));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status, d_status, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 1, d_ptr + nrows_pad, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_ERRBITS, d_status + SS_ERRBITS, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_H_NINC, d_ptr + nrows_pad, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
-    if (ctx->h_status[0] & ERR_DOF_LAYOUT) {
+    if (ctx->h_status[SS_ERRBITS] & ERR_DOF_LAYOUT) {
         ctx->err = "assemble: Node.DOF is not {3i,3i+1,3i+2} with 3i < n_dof (Node.cs:218-223)";
         return STAN_E_DOF_LAYOUT;
     }
-    if (ctx->h_status[0] & ERR_CONN_RANGE) {
+    if (ctx->h_status[SS_ERRBITS] & ERR_CONN_RANGE) {
         ctx->err = "assemble: connectivity references a node index outside [0,n_nodes)";
         return STAN_E_ARG;
     }
-    const int64_t n_inc = ctx->h_status[1];
+    const int64_t n_inc = ctx->h_status[SS_H_NINC];
     int32_t *d_list; STANCHK(stan_dmalloc(ctx, &d_list, (size_t)n_inc)); tmp.own(d_list);
     HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, ((size_t)nrows_pad + 1) * 4, st));
     if (n_elem > 0)
@@ -754,9 +754,9 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     K->nhalo = 0;
     if (ctx->nranks > 1) {
         STANCHK(stan_scan_exclusive(ctx, d_refflag, d_halo_rank, nb));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 2, d_halo_rank + nb, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_H_NHALO, d_halo_rank + nb, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
-        K->nhalo = ctx->h_status[2];
+        K->nhalo = ctx->h_status[SS_H_NHALO];
         STANCHK(stan_dmalloc(ctx, &K->d_halo_glob, (size_t)K->nhalo));
         hipLaunchKernelGGL(k_compact_flags, dim3(nblk(nb, 256)), dim3(256), 0, st, d_refflag,
                            d_halo_rank, K->d_halo_glob, nb);
@@ -764,26 +764,26 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     // slice widths -> slot pointers
     int32_t *d_width; STANCHK(stan_dmalloc(ctx, &d_width, (size_t)K->nslices + 1)); tmp.own(d_width);
     int64_t *d_sp64; STANCHK(stan_dmalloc(ctx, &d_sp64, (size_t)K->nslices + 2)); tmp.own(d_sp64);
-    HIPCHK(ctx, hipMemsetAsync(d_status + 16, 0, 16, st));
+    HIPCHK(ctx, hipMemsetAsync(d_status + SS_WIDTH_SUM, 0, 16, st));
     if (K->nslices > 0)
         hipLaunchKernelGGL(k_slice_width, dim3(nblk(K->nslices, 4)), dim3(256), 0, st, K->nslices, K->d_rowlen,
-                           d_width, (unsigned long long *)(d_status + 16), (int32_t *)(d_status + 17));
+                           d_width, (unsigned long long *)(d_status + SS_WIDTH_SUM), (int32_t *)(d_status + SS_WIDTH_MAX));
     STANCHK(stan_scan_exclusive(ctx, d_width, d_sp64, K->nslices));
     STANCHK(stan_dmalloc(ctx, &K->d_slot_ptr, (size_t)K->nslices + 1));
     hipLaunchKernelGGL(k_i64_to_i32, dim3(nblk(K->nslices + 1, 256)), dim3(256), 0, st, d_sp64,
                        K->d_slot_ptr, (int64_t)K->nslices + 1);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status, d_status, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 3, d_sp64 + K->nslices, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 4, d_status + 16, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_ERRBITS, d_status + SS_ERRBITS, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_H_NSLOTS, d_sp64 + K->nslices, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_H_NBLOCKS, d_status + SS_WIDTH_SUM, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
-    if (ctx->h_status[0] & (ERR_VALENCE | ERR_ROWLEN)) {
+    if (ctx->h_status[SS_ERRBITS] & (ERR_VALENCE | ERR_ROWLEN)) {
         ctx->err = "assemble: a node is shared by more than 64 (element, local node) pairs or "
                    "couples to more than " + std::to_string(STAN_MAX_ROW_BLOCKS) + " nodes";
         return STAN_E_VALENCE;
     }
-    K->nslots = ctx->h_status[3];
-    K->nblocks = ctx->h_status[4];
-    K->max_row_blocks = (int32_t)(ctx->h_status[5] & 0xffffffff);
+    K->nslots = ctx->h_status[SS_H_NSLOTS];
+    K->nblocks = ctx->h_status[SS_H_NBLOCKS];
+    K->max_row_blocks = (int32_t)(ctx->h_status[SS_H_MAXROW] & 0xffffffff);
     if (K->nslots * 64 >= (int64_t)1 << 31) {
         // cols index fits, but keep slot arithmetic in int32 honest
         ctx->err = "assemble: more than 2^31 ELL entries on one rank";
@@ -802,7 +802,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     if (ctx->assembly_mode == 1) {
         if (ctx->nranks > 1) { ctx->err = "assembly mode 1 (colour scatter) is single-rank only"; return STAN_E_UNSUPPORTED; }
         STANCHK(stan_assemble_colour_scatter(ctx, K, n_elem, d_conn, d_perm, d_xyz, d_elem_mat, d_elem_type,
-                                             d_lamG, d_ptr, d_list, (long long *)(d_status + 8)));
+                                             d_lamG, d_ptr, d_list, (long long *)(d_status + SS_BAD_ELEM)));
     } else {
         ctx->prof_colours = 0;
         numeric_args A;
@@ -811,7 +811,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         A.elem_mat = d_elem_mat; A.elem_type = d_elem_type; A.mat_lamG = d_lamG;
         A.fixmask = K->d_fixmask; A.halo_glob = K->d_halo_glob; A.halo_rank = d_halo_rank;
         A.rowlen = K->d_rowlen; A.slot_ptr = K->d_slot_ptr; A.cols = K->d_cols; A.vals = K->d_vals;
-        A.bad_elem = (long long *)(d_status + 8);
+        A.bad_elem = (long long *)(d_status + SS_BAD_ELEM);
         A.wmax = K->max_row_blocks > 0 ? K->max_row_blocks : 1;
         const size_t lds = (size_t)16 * A.wmax * 9 * 8 + (size_t)4 * 8 * 8 * 3 * 8 +
                            (size_t)4 * 8 * 8 * 10 * 8 + (size_t)2 * 16 * A.wmax * 4;
@@ -822,10 +822,10 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
             hipLaunchKernelGGL(k_numeric, dim3((unsigned)K->nslices * 4), dim3(256), lds, st, A);
     }
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemsetAsync(d_status + 9, 0, 8, st));
+    HIPCHK(ctx, hipMemsetAsync(d_status + SS_AUX, 0, 8, st));
     hipLaunchKernelGGL(k_count_fixed, dim3(nblk(n_dof, 256) > 2048 ? 2048 : nblk(n_dof, 256)), dim3(256), 0, st, n_dof, d_red,
-                       (unsigned long long *)(d_status + 9));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 8, d_status + 8, 16, hipMemcpyDeviceToHost, st));
+                       (unsigned long long *)(d_status + SS_AUX));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_BAD_ELEM, d_status + SS_BAD_ELEM, 16, hipMemcpyDeviceToHost, st));
 
     // interior / boundary slice lists for the overlapped SpMV (also built for a 1-rank
     // communicator, where every slice is interior, so that the two-stream path can be tested)
@@ -839,11 +839,11 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
                            K->d_rowlen, K->d_slot_ptr, K->d_cols, d_fb, d_fi);
         STANCHK(stan_scan_exclusive(ctx, d_fb, d_sb, K->nslices));
         STANCHK(stan_scan_exclusive(ctx, d_fi, d_si, K->nslices));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 6, d_sb + K->nslices, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 7, d_si + K->nslices, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_H_COUNT_A, d_sb + K->nslices, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_H_COUNT_B, d_si + K->nslices, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
-        K->n_sl_bnd = (int32_t)ctx->h_status[6];
-        K->n_sl_int = (int32_t)ctx->h_status[7];
+        K->n_sl_bnd = (int32_t)ctx->h_status[SS_H_COUNT_A];
+        K->n_sl_int = (int32_t)ctx->h_status[SS_H_COUNT_B];
         STANCHK(stan_dmalloc(ctx, &K->d_sl_bnd, (size_t)K->n_sl_bnd));
         STANCHK(stan_dmalloc(ctx, &K->d_sl_int, (size_t)K->n_sl_int));
         hipLaunchKernelGGL(k_compact_flags, dim3(nblk(K->nslices, 256)), dim3(256), 0, st, d_fb, d_sb,
@@ -873,9 +873,9 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
             hipLaunchKernelGGL(k_row_rankflag, dim3(nblk(nloc, 256)), dim3(256), 0, st, nloc,
                                K->d_rowlen, K->d_slot_ptr, K->d_cols, K->d_halo_glob, q0, q1, d_flag);
             STANCHK(stan_scan_exclusive(ctx, d_flag, d_rk, nloc));
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 6, d_rk + nloc, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_H_COUNT_A, d_rk + nloc, 8, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
-            const int64_t ns = ctx->h_status[6];
+            const int64_t ns = ctx->h_status[SS_H_COUNT_A];
             int32_t *d_l; STANCHK(stan_dmalloc(ctx, &d_l, (size_t)ns)); tmp.own(d_l);
             hipLaunchKernelGGL(k_compact_flags, dim3(nblk(nloc, 256)), dim3(256), 0, st, d_flag, d_rk,
                                d_l, nloc);
@@ -899,13 +899,13 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     }
     if (ctx->profiling) hipEventRecord(ev2, st);
     HIPCHK(ctx, hipStreamSynchronize(st));
-    if (ctx->h_status[8] != 0x7fffffffffffffffLL) {
-        ctx->bad_elem = ctx->h_status[8];
+    if (ctx->h_status[SS_BAD_ELEM] != 0x7fffffffffffffffLL) {
+        ctx->bad_elem = ctx->h_status[SS_BAD_ELEM];
         ctx->err = "det J == 0 in element " + std::to_string(ctx->bad_elem) +
                    " (MatrixST.Inverse would throw, MatrixST.cs:315-318)";
         return STAN_E_DETJ;
     }
-    K->n_red = n_dof - ctx->h_status[9];
+    K->n_red = n_dof - ctx->h_status[SS_AUX];
     if (ctx->profiling) {
         float a = 0, b = 0;
         hipEventElapsedTime(&a, ev0, ev1);

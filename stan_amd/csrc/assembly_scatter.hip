@@ -35,7 +35,7 @@ __global__ void k_col_tentative(int64_t n_elem, const int32_t *conn, const int32
             if (e2 != e && colour[e2] >= 0) forbid |= 1ull << colour[e2];
         }
     }
-    if (~forbid == 0ull) { atomicOr((unsigned long long *)&status[0], 16ull); tent[e] = 63; return; }
+    if (~forbid == 0ull) { atomicOr((unsigned long long *)&status[SS_ERRBITS], 16ull); tent[e] = 63; return; }
     tent[e] = __ffsll((long long)~forbid) - 1;
 }
 
@@ -204,13 +204,13 @@ int stan_assemble_colour_scatter(stan_ctx *ctx, stan_matrix *K, int64_t n_elem, 
             hipLaunchKernelGGL(k_col_resolve, dim3(nblk(n_elem, 256)), dim3(256), 0, st, n_elem, d_conn,
                                d_perm, d_ptr, d_list, d_col[cur], d_tent, d_col[cur ^ 1], d_rem);
             cur ^= 1;
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 10, d_rem, 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 11, ctx->d_status, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_COUNTER, d_rem, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_H_ERRCOPY, ctx->d_status + SS_ERRBITS, 8, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
-            if (ctx->h_status[11] & 16) { ctx->err = "colouring needs more than 64 colours"; return STAN_E_VALENCE; }
-            if (ctx->h_status[10] == 0) break;
+            if (ctx->h_status[SS_H_ERRCOPY] & 16) { ctx->err = "colouring needs more than 64 colours"; return STAN_E_VALENCE; }
+            if (ctx->h_status[SS_COUNTER] == 0) break;
         }
-        if (ctx->h_status[10] != 0) { ctx->err = "element colouring did not converge"; return STAN_E_HIP; }
+        if (ctx->h_status[SS_COUNTER] != 0) { ctx->err = "element colouring did not converge"; return STAN_E_HIP; }
         // elements grouped by colour
         HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 192 * 4, st));
         hipLaunchKernelGGL(k_col_count, dim3(nblk(n_elem, 256)), dim3(256), 0, st, n_elem, d_col[cur], d_cnt);

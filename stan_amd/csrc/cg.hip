@@ -646,14 +646,14 @@ int stan_matrix_make_fx48(stan_ctx *ctx, stan_matrix *K) {
     if (K->nslots == 0) return STAN_OK;
     uint32_t *out;
     STANCHK(stan_dmalloc(ctx, &out, (size_t)K->nslots * 14 * 64));
-    unsigned long long *d_bad = (unsigned long long *)(ctx->d_status + 10);
+    unsigned long long *d_bad = (unsigned long long *)(ctx->d_status + SS_COUNTER);
     HIPCHK(ctx, hipMemsetAsync(d_bad, 0, 8, ctx->stream));
     hipLaunchKernelGGL(k_to_fx48, dim3((unsigned)nblk(K->nslots * 64, 256)), dim3(256), 0, ctx->stream,
                        K->nslots, K->d_vals, out, d_bad);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + 10, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_COUNTER, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->h_status[10] != 0) { hipFree(out); K->fx48_refused = true; return STAN_OK; }
+    if (ctx->h_status[SS_COUNTER] != 0) { hipFree(out); K->fx48_refused = true; return STAN_OK; }
     K->d_vals48 = out;
     return STAN_OK;
 }
@@ -804,7 +804,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         return STAN_OK;
     };
 
-    int64_t *h_st = ctx->h_status + 16;  // pinned
+    int64_t *h_st = ctx->h_status + SS_H_CG_STATUS;  // pinned
     hipEvent_t poll[2];
     hipEventCreateWithFlags(&poll[0], hipEventDisableTiming);
     hipEventCreateWithFlags(&poll[1], hipEventDisableTiming);
@@ -863,7 +863,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     if (rc) return rc;
     if (e != hipSuccess) { ctx->err = std::string("cg: ") + hipGetErrorString(e); return STAN_E_HIP; }
     HIPCHK(ctx, hipMemcpyAsync(h_st, stt, T_NSTAT * 8, hipMemcpyDeviceToHost, st_));
-    double *h_sc = (double *)(ctx->h_status + 40);
+    double *h_sc = (double *)(ctx->h_status + SS_H_CG_SCALARS);
     HIPCHK(ctx, hipMemcpyAsync(h_sc, sc, S_NSCAL * 8, hipMemcpyDeviceToHost, st_));
     HIPCHK(ctx, hipStreamSynchronize(st_));
     int type = (int)h_st[T_TYPE];

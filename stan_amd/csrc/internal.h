@@ -45,6 +45,28 @@ struct rccl_api {
     const char *(*GetErrorString)(int) = nullptr;
 };
 
+// Slots of stan_ctx::d_status (device) and ::h_status (pinned host mirror), 64 x int64 each.
+// Device and host copies of a slot are not always the same quantity: the host side also parks
+// scan totals it copies back (SS_H_*).
+enum stan_status_slot {
+    SS_ERRBITS = 0,      // device: ERR_* bit mask raised by the assembly kernels
+    SS_H_NINC = 1,       // host: total node-element incidences
+    SS_H_NHALO = 2,      // host: halo block columns of this rank
+    SS_H_NSLOTS = 3,     // host: ELL slots (slot_ptr total)
+    SS_H_NBLOCKS = 4,    // host: blocks, followed by
+    SS_H_MAXROW = 5,     //       the longest row (copied as a pair from SS_WIDTH_SUM / SS_WIDTH_MAX)
+    SS_H_COUNT_A = 6,    // host: scan totals (boundary slices, send rows ...)
+    SS_H_COUNT_B = 7,    // host: scan totals (interior slices)
+    SS_BAD_ELEM = 8,     // min element index with det J == 0 (LLONG_MAX = none)
+    SS_AUX = 9,          // fixed-DOF count (assembly) / first HEX8_G1 element (recovery)
+    SS_COUNTER = 10,     // FIXED-48 overflow count; colouring: elements still uncoloured (host)
+    SS_H_ERRCOPY = 11,   // host: copy of SS_ERRBITS during the colouring rounds
+    SS_WIDTH_SUM = 16,   // device: sum of row lengths, followed by
+    SS_WIDTH_MAX = 17,   //         the longest row (k_slice_width)
+    SS_H_CG_STATUS = 16, // host: two 8-word copies of the CG status words (chunk polling)
+    SS_H_CG_SCALARS = 40 // host: the CG scalars at the end of a solve
+};
+
 struct stan_ctx {
     int device = 0;
     hipStream_t stream = nullptr;

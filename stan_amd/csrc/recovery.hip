@@ -147,31 +147,31 @@ int stan_recover_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz, con
     hipStream_t st = ctx->stream;
     long long init[2] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL};
     hipError_t e1 = hipMemcpyAsync(d_lamG, lamG.data(), lamG.size() * 8, hipMemcpyHostToDevice, st);
-    hipError_t e2 = hipMemcpyAsync(ctx->d_status + 8, init, 16, hipMemcpyHostToDevice, st);
+    hipError_t e2 = hipMemcpyAsync(ctx->d_status + SS_BAD_ELEM, init, 16, hipMemcpyHostToDevice, st);
     const int64_t nthreads = n_elem * 8;
     const dim3 grid((unsigned)((nthreads + 255) / 256)), block(256);
     if (forces)
         hipLaunchKernelGGL(k_recover<true>, grid, block, 0, st, n_elem, d_xyz, d_disp, d_conn, d_elem_mat,
-                           d_elem_type, d_lamG, d_strain, d_stress, (long long *)(ctx->d_status + 8),
-                           (long long *)(ctx->d_status + 9), d_node_dof, d_elem_forces, d_R);
+                           d_elem_type, d_lamG, d_strain, d_stress, (long long *)(ctx->d_status + SS_BAD_ELEM),
+                           (long long *)(ctx->d_status + SS_AUX), d_node_dof, d_elem_forces, d_R);
     else
         hipLaunchKernelGGL(k_recover<false>, grid, block, 0, st, n_elem, d_xyz, d_disp, d_conn, d_elem_mat,
-                           d_elem_type, d_lamG, d_strain, d_stress, (long long *)(ctx->d_status + 8),
-                           (long long *)(ctx->d_status + 9), nullptr, nullptr, nullptr);
+                           d_elem_type, d_lamG, d_strain, d_stress, (long long *)(ctx->d_status + SS_BAD_ELEM),
+                           (long long *)(ctx->d_status + SS_AUX), nullptr, nullptr, nullptr);
     hipError_t e3 = hipGetLastError();
-    hipError_t e4 = hipMemcpyAsync(ctx->h_status + 8, ctx->d_status + 8, 16, hipMemcpyDeviceToHost, st);
+    hipError_t e4 = hipMemcpyAsync(ctx->h_status + SS_BAD_ELEM, ctx->d_status + SS_BAD_ELEM, 16, hipMemcpyDeviceToHost, st);
     hipError_t e5 = hipStreamSynchronize(st);
     hipFree(d_lamG);
     for (hipError_t e : {e1, e2, e3, e4, e5})
         if (e != hipSuccess) { ctx->err = std::string("recover: ") + hipGetErrorString(e); return STAN_E_HIP; }
-    if (ctx->h_status[9] != init[0]) {
-        ctx->bad_elem = ctx->h_status[9];
+    if (ctx->h_status[SS_AUX] != init[0]) {
+        ctx->bad_elem = ctx->h_status[SS_AUX];
         ctx->err = "stress recovery: element " + std::to_string(ctx->bad_elem) +
                    " is HEX8_G1 (the reference throws: N has one row, Element.cs:242)";
         return STAN_E_UNSUPPORTED;
     }
-    if (ctx->h_status[8] != init[0]) {
-        ctx->bad_elem = ctx->h_status[8];
+    if (ctx->h_status[SS_BAD_ELEM] != init[0]) {
+        ctx->bad_elem = ctx->h_status[SS_BAD_ELEM];
         ctx->err = "det J == 0 in element " + std::to_string(ctx->bad_elem);
         return STAN_E_DETJ;
     }
