@@ -549,6 +549,17 @@ inline unsigned vec_grid(int64_t n) {
     return (unsigned)(b > VEC_BLOCKS ? VEC_BLOCKS : b);
 }
 
+// events owned by one solve: destroyed on every exit path
+struct event_bag {
+    std::vector<hipEvent_t> ev;
+    hipEvent_t make(unsigned flags = hipEventDefault) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, flags) == hipSuccess) ev.push_back(e);
+        return e;
+    }
+    ~event_bag() { for (hipEvent_t e : ev) hipEventDestroy(e); }
+};
+
 struct dev_bufs {
     std::vector<void *> p;
     ~dev_bufs() {
@@ -680,9 +691,10 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     }
     if (eps_f == 0 && max_its == 0) eps_f = 1.0e-6;  // lincgsetcond
     hipStream_t st_ = ctx->stream;
+    event_bag events;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ctx->profiling) {
-        hipEventCreate(&ev0); hipEventCreate(&ev1);
+        ev0 = events.make(); ev1 = events.make();
         hipEventRecord(ev0, st_);
     }
     STANCHK(ensure_scaled(ctx, K));
@@ -743,8 +755,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     // y = A^ x (x gets its halo filled first when sharded); returns 0 or an error code
     auto spmv = [&](double *x, double *y, bool dot, int64_t k) -> int {
         if (ctx->profiling) {
-            hipEvent_t a, b;
-            hipEventCreate(&a); hipEventCreate(&b);
+            hipEvent_t a = events.make(), b = events.make();
             hipEventRecord(a, st_);
             spmv_ev.push_back(a); spmv_ev.push_back(b);
         }
@@ -777,8 +788,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     // v = A^ x and w = A^ x2 in one matrix pass (fused residual refresh)
     auto spmv2 = [&](double *x, double *x2, int64_t k) -> int {
         if (ctx->profiling) {
-            hipEvent_t a, b;
-            hipEventCreate(&a); hipEventCreate(&b);
+            hipEvent_t a = events.make(), b = events.make();
             hipEventRecord(a, st_);
             spmv2_ev.push_back(a); spmv2_ev.push_back(b);
         }
@@ -805,9 +815,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     };
 
     int64_t *h_st = ctx->h_status + SS_H_CG_STATUS;  // pinned
-    hipEvent_t poll[2];
-    hipEventCreateWithFlags(&poll[0], hipEventDisableTiming);
-    hipEventCreateWithFlags(&poll[1], hipEventDisableTiming);
+    hipEvent_t poll[2] = {events.make(hipEventDisableTiming), events.make(hipEventDisableTiming)};
     int64_t k = 1;
     int chunk_id = 0;
     bool done = false;
@@ -859,7 +867,6 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         chunk_id++;
     }
     hipError_t e = hipStreamSynchronize(st_);
-    hipEventDestroy(poll[0]); hipEventDestroy(poll[1]);
     if (rc) return rc;
     if (e != hipSuccess) { ctx->err = std::string("cg: ") + hipGetErrorString(e); return STAN_E_HIP; }
     HIPCHK(ctx, hipMemcpyAsync(h_st, stt, T_NSTAT * 8, hipMemcpyDeviceToHost, st_));
@@ -903,7 +910,6 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         }
         ctx->prof.spmv_ms_total = tot;
         ctx->prof.spmv_launches = (int64_t)(spmv_ev.size() / 2);
-        for (hipEvent_t ev : spmv_ev) hipEventDestroy(ev);
         double tot2 = 0;
         for (size_t i = 0; i + 1 < spmv2_ev.size(); i += 2) {
             float t = 0;
@@ -912,8 +918,6 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         }
         ctx->prof.spmv2_ms_total = tot2;
         ctx->prof.spmv2_launches = (int64_t)(spmv2_ev.size() / 2);
-        for (hipEvent_t ev : spmv2_ev) hipEventDestroy(ev);
-        hipEventDestroy(ev0); hipEventDestroy(ev1);
         ctx->prof.iterations = (int32_t)its;
         ctx->prof.termination_type = type;
         const int64_t blk_bytes = fx ? 60 : mixed ? 40 : 76;
