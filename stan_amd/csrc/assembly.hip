@@ -660,9 +660,10 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         return STAN_E_ARG;
     }
     hipStream_t st = ctx->stream;
+    event_bag events;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     if (ctx->profiling) {
-        hipEventCreate(&ev0); hipEventCreate(&ev1); hipEventCreate(&ev2);
+        ev0 = events.make(); ev1 = events.make(); ev2 = events.make();
         hipEventRecord(ev0, st);
     }
     tmp_free tmp;
@@ -913,7 +914,6 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         ctx->prof.symbolic_ms = a;
         ctx->prof.numeric_ms = b;
         ctx->prof.assemble_ms = a + b;
-        hipEventDestroy(ev0); hipEventDestroy(ev1); hipEventDestroy(ev2);
     }
     g.ok = true;
     *outK = K;

@@ -549,17 +549,6 @@ inline unsigned vec_grid(int64_t n) {
     return (unsigned)(b > VEC_BLOCKS ? VEC_BLOCKS : b);
 }
 
-// events owned by one solve: destroyed on every exit path
-struct event_bag {
-    std::vector<hipEvent_t> ev;
-    hipEvent_t make(unsigned flags = hipEventDefault) {
-        hipEvent_t e = nullptr;
-        if (hipEventCreateWithFlags(&e, flags) == hipSuccess) ev.push_back(e);
-        return e;
-    }
-    ~event_bag() { for (hipEvent_t e : ev) hipEventDestroy(e); }
-};
-
 struct dev_bufs {
     std::vector<void *> p;
     ~dev_bufs() {
@@ -993,8 +982,8 @@ int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode
     int64_t init[T_NSTAT] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0, 0, 0, 0, 0, 0};
     HIPCHK(ctx, hipMemcpyAsync(stt, init, sizeof(init), hipMemcpyHostToDevice, st_));
     hipLaunchKernelGGL(k_fill, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, x, ng, 1.0);
-    hipEvent_t a, b;
-    hipEventCreate(&a); hipEventCreate(&b);
+    event_bag events;
+    hipEvent_t a = events.make(), b = events.make();
     auto one = [&]() {
         if (mixed) launch_spmv<float, true>(ctx, K, K->d_vals32, x, y, partial, stt, 1);
         else if (fx) launch_spmv<uint32_t, true>(ctx, K, K->d_vals48, x, y, partial, stt, 1);
@@ -1007,7 +996,6 @@ int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode
     HIPCHK(ctx, hipEventSynchronize(b));
     float ms = 0;
     hipEventElapsedTime(&ms, a, b);
-    hipEventDestroy(a); hipEventDestroy(b);
     *avg_ms = reps > 0 ? ms / reps : 0;
     HIPCHK(ctx, hipGetLastError());
     return STAN_OK;

@@ -83,7 +83,8 @@ extern "C" int stan_hip_csr_spmv_bench(stan_ctx *ctx, stan_matrix *K, int32_t re
     for (size_t i = 0; i < hx.size(); i++) hx[i] = 1.0 + (double)(i % 7);
     HIPCHK(ctx, hipMemcpyAsync(x, hx.data(), hx.size() * 8, hipMemcpyHostToDevice, st));
     hipEvent_t a, b;
-    hipEventCreate(&a); hipEventCreate(&b);
+    event_bag events;
+    a = events.make(); b = events.make();
     for (int i = 0; i < 3; i++)
         hipLaunchKernelGGL(k_csr_spmv, dim3(nblk(n3, 8)), dim3(256), 0, st, n3, rp, ci, cv, x, y);
     hipEventRecord(a, st);
@@ -93,7 +94,6 @@ extern "C" int stan_hip_csr_spmv_bench(stan_ctx *ctx, stan_matrix *K, int32_t re
     HIPCHK(ctx, hipEventSynchronize(b));
     float ms = 0;
     hipEventElapsedTime(&ms, a, b);
-    hipEventDestroy(a); hipEventDestroy(b);
     *avg_ms = ms / reps;
     if (bytes_per_launch) *bytes_per_launch = nnz * 12 + n3 * 8 /* rowptr (int64 here) */ + n3 * 16;
     // agreement with the BSELL-64 product on the same vector

@@ -45,6 +45,17 @@ struct rccl_api {
     const char *(*GetErrorString)(int) = nullptr;
 };
 
+// events owned by one call: destroyed on every exit path
+struct event_bag {
+    std::vector<hipEvent_t> ev;
+    hipEvent_t make(unsigned flags = hipEventDefault) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, flags) == hipSuccess) ev.push_back(e);
+        return e;
+    }
+    ~event_bag() { for (hipEvent_t e : ev) hipEventDestroy(e); }
+};
+
 // Slots of stan_ctx::d_status (device) and ::h_status (pinned host mirror), 64 x int64 each.
 // Device and host copies of a slot are not always the same quantity: the host side also parks
 // scan totals it copies back (SS_H_*).
