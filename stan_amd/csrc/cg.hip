@@ -257,14 +257,24 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
        int32_t poff) {
     __shared__ double sh[4];
     if (stopped(st, kiter)) return;
-    constexpr bool NT = (VAR & 1) != 0 && VAR != 8;
-    constexpr bool XCD = (VAR & 2) != 0 && VAR != 8;
-    constexpr int UNR = ((VAR & 4) != 0 && VAR != 8) ? 4 : 2;
+    constexpr bool NT = ((VAR & 1) != 0 && VAR < 8) || VAR >= 9;
+    constexpr bool XCD = (VAR & 2) != 0 && VAR < 8;
+    constexpr int UNR = (((VAR & 4) != 0 && VAR < 8) || VAR == 12) ? 4 : 2;
+    // VAR 9/10/11: XCD-chunked mapping.  Workgroups go round-robin to the 8 XCDs; here every
+    // window of 8*C consecutive workgroups is dealt so that each XCD gets C CONSECUTIVE ones
+    // (C = 32 / 8 / 128): an XCD's L2 then holds the x window of one contiguous run of rows
+    // while the chip as a whole still sweeps the matrix front to back.
+    constexpr int CH = (VAR == 9 || VAR == 12) ? 32 : VAR == 10 ? 8 : VAR == 11 ? 128 : 0;  // 12 = 9 + unroll 4
     const int lane = threadIdx.x & 63;
     int64_t bid = blockIdx.x;
     if (XCD) {
         const int64_t g = gridDim.x, cpx = g >> 3, rem = g & 7, xcd = bid & 7;
         bid = xcd * cpx + (xcd < rem ? xcd : rem) + (bid >> 3);
+    }
+    if (CH > 0) {
+        const int64_t win = 8 * CH, grp = bid / win, within = bid - grp * win;
+        if ((grp + 1) * win <= (int64_t)gridDim.x)   // the ragged tail keeps the identity mapping
+            bid = grp * win + (within & 7) * CH + (within >> 3);
     }
     int64_t slice = bid * 4 + (threadIdx.x >> 6);
     if (slist) slice = slice < nlist ? (int64_t)slist[slice] : (int64_t)nslices;  // interior / boundary list
@@ -274,7 +284,7 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
         const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
         const int32_t *cp = cols + (int64_t)k0 * 64 + lane;
         const VT *vp = vals + (int64_t)k0 * vstream<VT>::STRIDE + lane;
-        if (VAR == 8 && !vstream<VT>::FX) {
+        if (VAR == 8 && !vstream<VT>::FX) {  // timing only
             typedef VT v2 __attribute__((ext_vector_type(2)));
             const v2 *vq = (const v2 *)(vals + (int64_t)k0 * 9 * 64) + lane;
             for (int32_t k = k0; k + 1 < k1; k += 2) {
@@ -581,12 +591,15 @@ unsigned launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double
                            K->nloc, K->d_slot_ptr, K->d_cols, vals, x, y, partial, st, k,     \
                            slist, nlist, poff);                                               \
         break;
-    // auto (-1): 1 = non-temporal stream; 5 (+ unroll 4) for the FIXED-48 stream, whose
-    // iterations carry 21 % fewer bytes in flight: 1.011 vs 1.035 ms at 148^3 (tools/fx48_lab.py)
-    const int variant = ctx->spmv_variant >= 0 ? ctx->spmv_variant : (vstream<VT>::FX ? 5 : 1);
+    // auto (-1): non-temporal stream + XCD-chunked workgroup mapping for fp64 (variant 9: -0.8..-1.0 %
+    // on three boxes against variant 1), the same with the loop unrolled by 4 for the FIXED-48
+    // stream, whose iterations carry 21 % fewer bytes in flight (variant 12), plain non-temporal
+    // for the fp32 copy (variant 1) -- tools/fx48_variants.py, profiles/r01/spmv_lab_n148_xcd_chunked.txt
+    const int variant = ctx->spmv_variant >= 0 ? ctx->spmv_variant
+                        : vstream<VT>::FX ? 12 : sizeof(VT) == 8 ? 9 : 1;
     switch (variant) {
         SPMV_CASE(1) SPMV_CASE(2) SPMV_CASE(3) SPMV_CASE(4) SPMV_CASE(5) SPMV_CASE(6) SPMV_CASE(7)
-        SPMV_CASE(8)
+        SPMV_CASE(8) SPMV_CASE(9) SPMV_CASE(10) SPMV_CASE(11) SPMV_CASE(12)
         default:
         SPMV_CASE(0)
     }

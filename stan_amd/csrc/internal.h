@@ -97,8 +97,7 @@ struct stan_ctx {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     int assembly_mode = 0;     // 0 row-owner gather (default), 1 element-wave colour scatter
     int prof_colours = 0;
-    int spmv_variant = -1; // -1 = auto: 1 (non-temporal matrix stream: 1.124 vs 1.216 ms at 148^3, profiles/r01)
-                           // for the fp64/fp32 streams, 5 (+ unroll 4) for FIXED-48
+    int spmv_variant = -1; // -1 = auto (launch_spmv picks per value stream); >= 0: A/B lab
     // profiling
     bool profiling = false;
     stan_profile prof{};
