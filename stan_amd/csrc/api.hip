@@ -83,7 +83,7 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
     else if (option == STAN_OPT_ASSEMBLY_MODE && (value == 0 || value == 1)) ctx->assembly_mode = (int)value;
     else if (option == STAN_OPT_CG_FUSED_REFRESH) ctx->cg_fused_refresh = value != 0;
     else if (option == STAN_OPT_OVERLAP_HALO) ctx->overlap_halo = value != 0;
-    else if (option == STAN_OPT_SPMV_VARIANT && value >= -1 && value <= 12) ctx->spmv_variant = (int)value;
+    else if (option == STAN_OPT_SPMV_VARIANT && value >= -1 && value <= 13) ctx->spmv_variant = (int)value;
     else { ctx->err = "set_option: unknown option or bad value"; return STAN_E_ARG; }
     return STAN_OK;
 }

@@ -211,9 +211,14 @@ __global__ void k_init_scalars(double *sc, int64_t *st, double epsf) {
 //          contiguous run of slices so that its L2 holds one window of x, not eight copies)
 //   bit 2: unroll the block loop by 4 instead of 2
 //   VAR 8: timing only -- reads the same bytes as 16-B (dwordx4) accesses; results are wrong
-template <typename T>
-__device__ __forceinline__ T ld_stream(const T *p, bool nt) {
-    return nt ? __builtin_nontemporal_load(p) : *p;
+// NT must be a compile-time choice: with a run-time flag, `nt ? __builtin_nontemporal_load(p) : *p`
+// is two loads of one address that the optimiser merges into ONE plain load inside this helper,
+// before it is inlined anywhere -- the non-temporal hint never reached the ISA (no `nt` bit on any
+// global_load of the first builds; found by reading the disassembly).
+template <bool NT, typename T>
+__device__ __forceinline__ T ld_stream(const T *p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
 }
 
 // Value streams of the matrix.  double / float: vals[slot][9][64].
@@ -229,22 +234,22 @@ __device__ __forceinline__ T ld_stream(const T *p, bool nt) {
 template <typename VT> struct vstream { static constexpr int STRIDE = 9 * 64; static constexpr bool FX = false; };
 template <> struct vstream<uint32_t> { static constexpr int STRIDE = 14 * 64; static constexpr bool FX = true; };
 
-template <typename VT>
-__device__ __forceinline__ void load9(const VT *vp, bool nt, double a[9]) {
+template <bool NT, typename VT>
+__device__ __forceinline__ void load9(const VT *vp, double a[9]) {
+    if constexpr (vstream<VT>::FX) {
+        uint32_t lo[9], hw[5];
 #pragma unroll
-    for (int j = 0; j < 9; j++) a[j] = (double)ld_stream(vp + j * 64, nt);
-}
-template <>
-__device__ __forceinline__ void load9<uint32_t>(const uint32_t *vp, bool nt, double a[9]) {
-    uint32_t lo[9], hw[5];
+        for (int j = 0; j < 9; j++) lo[j] = ld_stream<NT>(vp + j * 64);
 #pragma unroll
-    for (int j = 0; j < 9; j++) lo[j] = ld_stream(vp + j * 64, nt);
+        for (int m = 0; m < 5; m++) hw[m] = ld_stream<NT>(vp + (9 + m) * 64);
 #pragma unroll
-    for (int m = 0; m < 5; m++) hw[m] = ld_stream(vp + (9 + m) * 64, nt);
+        for (int j = 0; j < 9; j++) {
+            const uint32_t h = (j & 1) ? (hw[j >> 1] >> 16) : (hw[j >> 1] & 0xffffu);
+            a[j] = __hiloint2double((int)(0x43300000u | h), (int)lo[j]) - FX48_BIAS;
+        }
+    } else {
 #pragma unroll
-    for (int j = 0; j < 9; j++) {
-        const uint32_t h = (j & 1) ? (hw[j >> 1] >> 16) : (hw[j >> 1] & 0xffffu);
-        a[j] = __hiloint2double((int)(0x43300000u | h), (int)lo[j]) - FX48_BIAS;
+        for (int j = 0; j < 9; j++) a[j] = (double)ld_stream<NT>(vp + j * 64);
     }
 }
 
@@ -257,14 +262,14 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
        int32_t poff) {
     __shared__ double sh[4];
     if (stopped(st, kiter)) return;
-    constexpr bool NT = ((VAR & 1) != 0 && VAR < 8) || VAR >= 9;
+    constexpr bool NT = ((VAR & 1) != 0 && VAR < 8) || (VAR >= 9 && VAR != 13);  // 13 = 9 without the hint
     constexpr bool XCD = (VAR & 2) != 0 && VAR < 8;
     constexpr int UNR = (((VAR & 4) != 0 && VAR < 8) || VAR == 12) ? 4 : 2;
     // VAR 9/10/11: XCD-chunked mapping.  Workgroups go round-robin to the 8 XCDs; here every
     // window of 8*C consecutive workgroups is dealt so that each XCD gets C CONSECUTIVE ones
     // (C = 32 / 8 / 128): an XCD's L2 then holds the x window of one contiguous run of rows
     // while the chip as a whole still sweeps the matrix front to back.
-    constexpr int CH = (VAR == 9 || VAR == 12) ? 32 : VAR == 10 ? 8 : VAR == 11 ? 128 : 0;  // 12 = 9 + unroll 4
+    constexpr int CH = (VAR == 9 || VAR == 12 || VAR == 13) ? 32 : VAR == 10 ? 8 : VAR == 11 ? 128 : 0;  // 12 = 9 + unroll 4
     const int lane = threadIdx.x & 63;
     int64_t bid = blockIdx.x;
     if (XCD) {
@@ -303,9 +308,9 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
         } else {
 #pragma unroll UNR
             for (int32_t k = k0; k < k1; k++) {
-                const int64_t c = ld_stream(cp, NT);
+                const int64_t c = ld_stream<NT>(cp);
                 double a[9];
-                load9<VT>(vp, NT, a);
+                load9<NT, VT>(vp, a);
                 double x0 = x[3 * c], x1 = x[3 * c + 1], x2 = x[3 * c + 2];
                 if (vstream<VT>::FX) { x0 *= FX48_INV; x1 *= FX48_INV; x2 *= FX48_INV; }
                 y0 += a[0] * x0 + a[1] * x1 + a[2] * x2;
@@ -350,9 +355,9 @@ k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
         const VT *vp = vals + (int64_t)k0 * vstream<VT>::STRIDE + lane;
 #pragma unroll 2
         for (int32_t k = k0; k < k1; k++) {
-            const int64_t c = ld_stream(cp, true);
+            const int64_t c = ld_stream<true>(cp);
             double a[9];
-            load9<VT>(vp, true, a);
+            load9<true, VT>(vp, a);
             double x0 = x[3 * c], x1 = x[3 * c + 1], xx2 = x[3 * c + 2];
             double u0 = x2[3 * c], u1 = x2[3 * c + 1], u2 = x2[3 * c + 2];
             if (vstream<VT>::FX) {
@@ -591,15 +596,15 @@ unsigned launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double
                            K->nloc, K->d_slot_ptr, K->d_cols, vals, x, y, partial, st, k,     \
                            slist, nlist, poff);                                               \
         break;
-    // auto (-1): non-temporal stream + XCD-chunked workgroup mapping for fp64 (variant 9: -0.8..-1.0 %
-    // on three boxes against variant 1), the same with the loop unrolled by 4 for the FIXED-48
-    // stream, whose iterations carry 21 % fewer bytes in flight (variant 12), plain non-temporal
-    // for the fp32 copy (variant 1) -- tools/fx48_variants.py, profiles/r01/spmv_lab_n148_xcd_chunked.txt
-    const int variant = ctx->spmv_variant >= 0 ? ctx->spmv_variant
-                        : vstream<VT>::FX ? 12 : sizeof(VT) == 8 ? 9 : 1;
+    // auto (-1): non-temporal matrix stream + XCD-chunked workgroup mapping (variant 9), with the
+    // loop unrolled by 4 for the FIXED-48 stream, whose iterations carry 21 % fewer bytes in
+    // flight (variant 12).  One process, one box (tools/fx48_variants.py, min of 3 x 20 launches):
+    // fp64 plain 1.181 / nt 1.102 / nt+chunk 1.100 ms; FIXED-48 1.003 / 0.955 / nt+unroll4 0.925;
+    // fp32 0.636 / 0.583 / 0.580.
+    const int variant = ctx->spmv_variant >= 0 ? ctx->spmv_variant : vstream<VT>::FX ? 12 : 9;
     switch (variant) {
         SPMV_CASE(1) SPMV_CASE(2) SPMV_CASE(3) SPMV_CASE(4) SPMV_CASE(5) SPMV_CASE(6) SPMV_CASE(7)
-        SPMV_CASE(8) SPMV_CASE(9) SPMV_CASE(10) SPMV_CASE(11) SPMV_CASE(12)
+        SPMV_CASE(8) SPMV_CASE(9) SPMV_CASE(10) SPMV_CASE(11) SPMV_CASE(12) SPMV_CASE(13)
         default:
         SPMV_CASE(0)
     }
