@@ -345,7 +345,13 @@ k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
     __shared__ double sh[4];
     if (stopped(st, kiter)) return;
     const int lane = threadIdx.x & 63;
-    int64_t slice = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int64_t bid = blockIdx.x;
+    {   // XCD-chunked workgroup mapping, as in k_spmv (variant 9)
+        constexpr int CH = 32;
+        const int64_t win = 8 * CH, grp = bid / win, within = bid - grp * win;
+        if ((grp + 1) * win <= (int64_t)gridDim.x) bid = grp * win + (within & 7) * CH + (within >> 3);
+    }
+    int64_t slice = bid * 4 + (threadIdx.x >> 6);
     if (slist) slice = slice < nlist ? (int64_t)slist[slice] : (int64_t)nslices;
     double y0 = 0, y1 = 0, yy2 = 0, z0 = 0, z1 = 0, z2 = 0;
     const int64_t row = slice * 64 + lane;
