@@ -293,10 +293,10 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
             typedef VT v2 __attribute__((ext_vector_type(2)));
             const v2 *vq = (const v2 *)(vals + (int64_t)k0 * 9 * 64) + lane;
             for (int32_t k = k0; k + 1 < k1; k += 2) {
-                const int64_t c = cp[0], c2 = cp[64];
+                const int64_t c = __builtin_nontemporal_load(cp), c2 = __builtin_nontemporal_load(cp + 64);
                 double a[9], b[9];
 #pragma unroll
-                for (int j = 0; j < 9; j++) { const v2 t = vq[j * 64]; a[j] = (double)t.x; b[j] = (double)t.y; }
+                for (int j = 0; j < 9; j++) { const v2 t = __builtin_nontemporal_load(vq + j * 64); a[j] = (double)t.x; b[j] = (double)t.y; }
                 const double x0 = x[3 * c], x1 = x[3 * c + 1], x2 = x[3 * c + 2];
                 const double z0 = x[3 * c2], z1 = x[3 * c2 + 1], z2 = x[3 * c2 + 2];
                 y0 += a[0] * x0 + a[1] * x1 + a[2] * x2 + b[0] * z0 + b[1] * z1 + b[2] * z2;
