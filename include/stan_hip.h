@@ -88,6 +88,9 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
 #define STAN_OPT_CG_FUSED_REFRESH 6 /* 1 (default): on refresh iterations A x and A p come from ONE
                                      matrix pass and r = b - (A x + a A p); 0: ALGLIB's literal
                                      second product A (x + a p).  Same value up to rounding. */
+#define STAN_OPT_POOL 7 /* 1 (default): device blocks >= 8 MB freed by the library stay with the
+                           context and are reused by its next allocations (a hipMalloc of tens of GB
+                           costs 0.4-1.8 s here); 0: release them now, plain hipMalloc/hipFree from then on */
 #define STAN_OPT_SPMV_VARIANT 3 /* tuning variants of the SpMV kernel (cg.hip), A/B runs only; -1 = auto (default) */
 int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value);
 

@@ -11,13 +11,15 @@ thread_local std::string g_err;  // errors raised before a context exists
 template <typename T>
 struct dbuf {  // RAII device buffer filled from host memory
     T *p = nullptr;
-    ~dbuf() { if (p) hipFree(p); }
+    stan_ctx *owner = nullptr;
+    ~dbuf() { stan_dfree(owner, p); }
     int upload(stan_ctx *ctx, const T *h, size_t n) {
+        owner = ctx;
         STANCHK(stan_dmalloc(ctx, &p, n));
         if (n) HIPCHK(ctx, hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
         return STAN_OK;
     }
-    int alloc(stan_ctx *ctx, size_t n) { return stan_dmalloc(ctx, &p, n); }
+    int alloc(stan_ctx *ctx, size_t n) { owner = ctx; return stan_dmalloc(ctx, &p, n); }
 };
 }  // namespace
 
@@ -56,6 +58,7 @@ void stan_hip_destroy(stan_ctx *ctx) {
     if (ctx->side) hipStreamDestroy(ctx->side);
     if (ctx->ev_a) hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) hipEventDestroy(ctx->ev_b);
+    ctx->pool.flush();
     if (ctx->h_status) hipHostFree(ctx->h_status);
     if (ctx->d_status) hipFree(ctx->d_status);
     delete ctx;
@@ -82,6 +85,14 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
     else if (option == STAN_OPT_CG_RUPDATE && value >= 0 && value < (1 << 30)) ctx->cg_rupdate = (int)value;
     else if (option == STAN_OPT_ASSEMBLY_MODE && (value == 0 || value == 1)) ctx->assembly_mode = (int)value;
     else if (option == STAN_OPT_CG_FUSED_REFRESH) ctx->cg_fused_refresh = value != 0;
+    else if (option == STAN_OPT_POOL) {
+        ctx->pool.enabled = value != 0;
+        if (!ctx->pool.enabled) {
+            hipSetDevice(ctx->device);
+            hipStreamSynchronize(ctx->stream);
+            ctx->pool.flush();
+        }
+    }
     else if (option == STAN_OPT_OVERLAP_HALO) ctx->overlap_halo = value != 0;
     else if (option == STAN_OPT_SPMV_VARIANT && value >= -1 && value <= 13) ctx->spmv_variant = (int)value;
     else { ctx->err = "set_option: unknown option or bad value"; return STAN_E_ARG; }
@@ -148,10 +159,13 @@ int stan_hip_assemble_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz,
 void stan_hip_matrix_free(stan_matrix *K) {
     if (!K) return;
     if (K->ctx) hipSetDevice(K->ctx->device);
-    hipFree(K->d_slot_ptr); hipFree(K->d_rowlen); hipFree(K->d_cols); hipFree(K->d_vals);
-    hipFree(K->d_vals32); hipFree(K->d_vals48); hipFree(K->d_red); hipFree(K->d_fixmask); hipFree(K->d_scale);
-    hipFree(K->d_send_rows); hipFree(K->d_halo_glob); hipFree(K->d_sendbuf);
-    hipFree(K->d_sl_int); hipFree(K->d_sl_bnd);
+    // the solves that used these buffers have been synchronised by their own calls; the blocks go
+    // back to the context's pool (stan_pool) or to the driver
+    for (void *q : {(void *)K->d_slot_ptr, (void *)K->d_rowlen, (void *)K->d_cols, (void *)K->d_vals,
+                    (void *)K->d_vals32, (void *)K->d_vals48, (void *)K->d_red, (void *)K->d_fixmask,
+                    (void *)K->d_scale, (void *)K->d_send_rows, (void *)K->d_halo_glob, (void *)K->d_sendbuf,
+                    (void *)K->d_sl_int, (void *)K->d_sl_bnd})
+        stan_dfree(K->ctx, q);
     delete K;
 }
 

@@ -611,11 +611,11 @@ k_ke_batch(int64_t n, const double *xyz8, double lam, double G, const uint8_t *t
 
 inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
 
-struct tmp_free {  // frees device temporaries on every exit path
+struct tmp_free {  // releases device temporaries on every exit path (to the context's pool)
+    stan_ctx *ctx = nullptr;
     std::vector<void *> p;
     ~tmp_free() {
-        for (void *q : p)
-            if (q) hipFree(q);
+        for (void *q : p) stan_dfree(ctx, q);
     }
     template <typename T>
     void own(T *q) { p.push_back((void *)q); }
@@ -667,6 +667,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         hipEventRecord(ev0, st);
     }
     tmp_free tmp;
+    tmp.ctx = ctx;
     stan_matrix *K = new stan_matrix();
     K->ctx = ctx;
     struct guard {

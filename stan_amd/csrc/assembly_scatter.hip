@@ -191,7 +191,7 @@ int stan_assemble_colour_scatter(stan_ctx *ctx, stan_matrix *K, int64_t n_elem, 
         unsigned long long *d_rem;
         std::vector<void *> owned;
         auto A = [&](auto **p, size_t n) { int rc = stan_dmalloc(ctx, p, n); if (!rc) owned.push_back((void *)*p); return rc; };
-        struct F { std::vector<void *> &v; ~F() { for (void *q : v) hipFree(q); } } fr{owned};
+        struct F { stan_ctx *c; std::vector<void *> &v; ~F() { for (void *q : v) stan_dfree(c, q); } } fr{ctx, owned};
         STANCHK(A(&d_col[0], (size_t)n_elem)); STANCHK(A(&d_col[1], (size_t)n_elem));
         STANCHK(A(&d_tent, (size_t)n_elem)); STANCHK(A(&d_cnt, 192)); STANCHK(A(&d_order, (size_t)n_elem));
         STANCHK(A(&d_rem, 1));

@@ -571,14 +571,15 @@ inline unsigned vec_grid(int64_t n) {
 }
 
 struct dev_bufs {
+    stan_ctx *ctx = nullptr;
     std::vector<void *> p;
     ~dev_bufs() {
-        for (void *q : p)
-            if (q) hipFree(q);
+        for (void *q : p) stan_dfree(ctx, q);
     }
 };
 template <typename T>
 int alloc(stan_ctx *ctx, dev_bufs &b, T **p, size_t n) {
+    b.ctx = ctx;
     int rc = stan_dmalloc(ctx, p, n);
     if (rc == STAN_OK) b.p.push_back((void *)*p);
     return rc;
@@ -677,7 +678,7 @@ int stan_matrix_make_fx48(stan_ctx *ctx, stan_matrix *K) {
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_COUNTER, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->h_status[SS_COUNTER] != 0) { hipFree(out); K->fx48_refused = true; return STAN_OK; }
+    if (ctx->h_status[SS_COUNTER] != 0) { stan_dfree(ctx, out); K->fx48_refused = true; return STAN_OK; }
     K->d_vals48 = out;
     return STAN_OK;
 }
@@ -1045,8 +1046,8 @@ int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K) {
                            K->nslices, K->d_slot_ptr, K->d_cols, K->d_vals, K->d_scale, 1);
     HIPCHK(ctx, hipGetLastError());
     K->scaled = false;
-    if (K->d_vals32) { hipFree(K->d_vals32); K->d_vals32 = nullptr; }
-    if (K->d_vals48) { hipFree(K->d_vals48); K->d_vals48 = nullptr; }
+    if (K->d_vals32) { stan_dfree(ctx, K->d_vals32); K->d_vals32 = nullptr; }
+    if (K->d_vals48) { stan_dfree(ctx, K->d_vals48); K->d_vals48 = nullptr; }
     K->fx48_refused = false;
     return STAN_OK;
 }

@@ -69,7 +69,7 @@ extern "C" int stan_hip_csr_spmv_bench(stan_ctx *ctx, stan_matrix *K, int32_t re
     int64_t *stt = nullptr;
     std::vector<void *> own;
     auto A = [&](auto **p, size_t n) { int rc = stan_dmalloc(ctx, p, n); if (!rc) own.push_back((void *)*p); return rc; };
-    struct F { std::vector<void *> &v; ~F() { for (void *q : v) hipFree(q); } } fr{own};
+    struct F { stan_ctx *c; std::vector<void *> &v; ~F() { for (void *q : v) stan_dfree(c, q); } } fr{ctx, own};
     const int64_t npad3 = 3 * (int64_t)K->nslices * 64;
     STANCHK(A(&len3, (size_t)n3 + 1)); STANCHK(A(&rp, (size_t)n3 + 2)); STANCHK(A(&ci, (size_t)nnz));
     STANCHK(A(&cv, (size_t)nnz)); STANCHK(A(&x, (size_t)npad3)); STANCHK(A(&y, (size_t)npad3));

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/stan_hip.h"
@@ -43,6 +44,26 @@ struct rccl_api {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+};
+
+// Device blocks of 8 MB and more are kept by the context when they are freed and handed out again
+// to the next request they fit (best fit, at most 1.5x the size asked for): on this stack a
+// hipMalloc of tens of GB right after the hipFree of as much takes 0.4-1.8 s, erratically -- at
+// 200^3 more than the whole assembly (12 + 32 ms) and 10-25 % of a step (tools/alloc_probe.py).
+// Reuse is ordered by the context's stream, so no synchronisation is needed; a failed hipMalloc
+// flushes the pool and retries; STAN_OPT_POOL = 0 flushes and disables; destroy frees everything.
+struct stan_pool {
+    static constexpr size_t MIN_BYTES = 8u << 20;
+    struct blk { void *p; size_t cap; };
+    std::vector<blk> avail;
+    std::unordered_map<void *, size_t> live;  // pooled-class blocks currently handed out
+    bool enabled = true;
+    size_t bytes_avail = 0;
+    void flush() {
+        for (blk &b : avail) hipFree(b.p);
+        avail.clear();
+        bytes_avail = 0;
+    }
 };
 
 // events owned by one call: destroyed on every exit path
@@ -101,6 +122,7 @@ struct stan_ctx {
     // profiling
     bool profiling = false;
     stan_profile prof{};
+    stan_pool pool;
     // small pinned host + device scratch for status words
     int64_t *h_status = nullptr;  // pinned, 64 words
     int64_t *d_status = nullptr;  // device, 64 words
@@ -185,16 +207,58 @@ int stan_comm_allreduce_sum_f64(stan_ctx *ctx, double *d_buf, size_t count);
 int stan_comm_halo_exchange(stan_ctx *ctx, stan_matrix *K, double *d_vec);
 int stan_comm_allgather_rows(stan_ctx *ctx, stan_matrix *K, double *d_full_blockvec);
 
-// device memory helpers
-template <typename T>
-static inline int stan_dmalloc(stan_ctx *ctx, T **p, size_t count) {
+// device memory helpers (see stan_pool)
+static inline int stan_dmalloc_bytes(stan_ctx *ctx, void **p, size_t bytes) {
     *p = nullptr;
-    if (count == 0) count = 1;
-    hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+    if (bytes == 0) bytes = 8;
+    stan_pool &pool = ctx->pool;
+    const bool pooled = pool.enabled && bytes >= stan_pool::MIN_BYTES;
+    if (pooled) {
+        int best = -1;
+        for (int i = 0; i < (int)pool.avail.size(); i++) {
+            const size_t cap = pool.avail[i].cap;
+            if (cap >= bytes && cap <= bytes + bytes / 2 && (best < 0 || cap < pool.avail[best].cap)) best = i;
+        }
+        if (best >= 0) {
+            *p = pool.avail[best].p;
+            pool.live[*p] = pool.avail[best].cap;
+            pool.bytes_avail -= pool.avail[best].cap;
+            pool.avail.erase(pool.avail.begin() + best);
+            return STAN_OK;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess && !pool.avail.empty()) {  // make room and try once more
+        (void)hipGetLastError();
+        pool.flush();
+        e = hipMalloc(p, bytes);
+    }
     if (e != hipSuccess) {
-        ctx->err = std::string("hipMalloc(") + std::to_string(count * sizeof(T)) +
-                   " B): " + hipGetErrorString(e);
+        (void)hipGetLastError();
+        *p = nullptr;
+        ctx->err = std::string("hipMalloc(") + std::to_string(bytes) + " B): " + hipGetErrorString(e);
         return STAN_E_ALLOC;
     }
+    if (pooled) pool.live[*p] = bytes;
     return STAN_OK;
+}
+template <typename T>
+static inline int stan_dmalloc(stan_ctx *ctx, T **p, size_t count) {
+    return stan_dmalloc_bytes(ctx, (void **)p, count * sizeof(T));
+}
+static inline void stan_dfree(stan_ctx *ctx, void *p) {
+    if (!p) return;
+    if (ctx) {
+        auto it = ctx->pool.live.find(p);
+        if (it != ctx->pool.live.end()) {
+            const size_t cap = it->second;
+            ctx->pool.live.erase(it);
+            if (ctx->pool.enabled) {
+                ctx->pool.avail.push_back({p, cap});
+                ctx->pool.bytes_avail += cap;
+                return;
+            }
+        }
+    }
+    hipFree(p);
 }
