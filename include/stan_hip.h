@@ -93,6 +93,8 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
                            costs 0.4-1.8 s here); 0: release them now, plain hipMalloc/hipFree from then on */
 #define STAN_OPT_SPMV_VARIANT 3 /* tuning variants of the SpMV kernel (cg.hip), A/B runs only; -1 = auto (default) */
 int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value);
+/* What STAN_OPT_POOL currently keeps: bytes and number of parked device blocks (either may be NULL). */
+int stan_hip_pool_info(stan_ctx *ctx, int64_t *bytes_parked, int64_t *blocks_parked);
 
 /* ---- multi-GPU (RCCL over xGMI) -------------------------------------------------------- */
 /* Rank 0 creates the 128-byte id, the host distributes it (torch.distributed broadcast,

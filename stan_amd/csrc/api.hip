@@ -99,6 +99,13 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
     return STAN_OK;
 }
 
+int stan_hip_pool_info(stan_ctx *ctx, int64_t *bytes_parked, int64_t *blocks_parked) {
+    if (!ctx) return STAN_E_ARG;
+    if (bytes_parked) *bytes_parked = (int64_t)ctx->pool.bytes_avail;
+    if (blocks_parked) *blocks_parked = (int64_t)ctx->pool.avail.size();
+    return STAN_OK;
+}
+
 int stan_hip_set_profiling(stan_ctx *ctx, int32_t enabled) {
     if (!ctx) return STAN_E_ARG;
     ctx->profiling = enabled != 0;

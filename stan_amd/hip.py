@@ -30,7 +30,7 @@ EXPORTS = [
     "stan_hip_cg_solve", "stan_hip_cg_solve_dev", "stan_hip_matrix_info", "stan_hip_ke_hex8",
     "stan_hip_ke_hex8_batch", "stan_hip_matrix_to_csr", "stan_hip_spmv", "stan_hip_spmv_bench",
     "stan_hip_set_profiling", "stan_hip_get_profile", "stan_hip_set_option", "stan_hip_recover_hex8", "stan_hip_recover_hex8_dev",
-    "stan_hip_nodal_forces_hex8",
+    "stan_hip_nodal_forces_hex8", "stan_hip_pool_info",
     "stan_hip_matrix_plan", "stan_hip_spmv_local", "stan_hip_csr_spmv_bench",
 ]
 
@@ -140,6 +140,12 @@ class Context:
         p = Profile()
         self._chk(self.lib.stan_hip_get_profile(self.h, C.byref(p)))
         return {k: getattr(p, k) for k, _ in Profile._fields_}
+
+    def pool_info(self):
+        """(bytes, blocks) of device memory the context keeps parked for reuse (OPT_POOL)."""
+        b, n = C.c_int64(0), C.c_int64(0)
+        self._chk(self.lib.stan_hip_pool_info(self.h, C.byref(b), C.byref(n)))
+        return b.value, n.value
 
     # -- multi-GPU -----------------------------------------------------------------
     def unique_id(self):

@@ -301,26 +301,28 @@ def test_block_pool_reuses_and_releases_device_memory(built_libs):
     """STAN_OPT_POOL: blocks >= 8 MB freed by the library stay with the context and are handed out
     again (a hipMalloc of tens of GB costs 0.4-1.8 s on this stack); switching the option off gives
     the memory back; results do not depend on it."""
-    import torch
+    import torch  # noqa: F401
     from stan_amd import hip
     job = problem.cube_job(40)
     args = (job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
-    free0 = torch.cuda.mem_get_info(0)[0]
     ctx = hip.Context(0)
-    res = []
+    assert ctx.pool_info() == (0, 0)
+    res, parked = [], []
     for i in range(3):
         K = ctx.assemble_hex8(*args)
         res.append(K.cg_solve(job.F, 1e-8))
+        assert ctx.pool_info()[0] < 64e6 or i > 0       # while K lives, its big blocks are out of the pool
         K.free()
-    held = free0 - torch.cuda.mem_get_info(0)[0]
-    assert held > 100e6                                # the 128 MB value array (and friends) is parked
+        parked.append(ctx.pool_info())
+    assert parked[0][0] > 130e6                        # the 134 MB value array and friends are parked
+    assert parked[1] == parked[0] and parked[2] == parked[0]   # cycles 2 and 3 allocated nothing new
     assert all(np.array_equal(res[0][0], r[0]) and res[0][1] == r[1] for r in res[1:])
     ctx.set_option(hip.OPT_POOL, 0)                    # flush + plain hipMalloc/hipFree from here on
-    assert free0 - torch.cuda.mem_get_info(0)[0] < 64e6
+    assert ctx.pool_info() == (0, 0)
     K = ctx.assemble_hex8(*args)
     U, rep = K.cg_solve(job.F, 1e-8)
     K.free()
-    assert np.array_equal(U, res[0][0]) and free0 - torch.cuda.mem_get_info(0)[0] < 64e6
+    assert np.array_equal(U, res[0][0]) and ctx.pool_info() == (0, 0)
     ctx.close()
 
 
