@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--etype", type=int, default=2, help="2 = HEX8_G2, 1 = HEX8_G1")
     ap.add_argument("--cpu-n", type=int, default=56, help="cube edge of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--placement-tries", type=int, default=4,
+                    help="STAN_OPT_PLACEMENT_TRIES: allocate the value array of K by trial in the first "
+                         "(warm-up) assembly; 1 = plain allocation (the library default)")
     args = ap.parse_args()
 
     import numpy as np
@@ -146,6 +149,7 @@ def main():
         dist.broadcast(uid, 0)
         ctx.comm_init(rank, world, bytes(uid.cpu().tolist()))
     ctx.set_option(hip.OPT_CG_MERIT_STOP, 0)
+    ctx.set_option(hip.OPT_PLACEMENT_TRIES, max(1, min(8, args.placement_tries)))
     ctx.set_profiling(True)
 
     # inputs resident in HBM before the timed region
@@ -246,6 +250,9 @@ def main():
                                         ("fp32" if args.mixed else "48-bit fixed-point" if args.fixed48
                                          else "fp64"),
                        "parallelism": "rows sharded x%d" % world,
+                       # the block pool keeps K's arrays between steps; with tries > 1 the first
+                       # assembly picks the fastest-streaming of several hipMalloc blocks
+                       "placement_tries": args.placement_tries,
                        # SURVEY section 8d assembly bytes: coords + connectivity read, K written once
                        "assembly_GBs": (job.conn.shape[0] * (192 + 32) + info["n_slots"] * 64 * 72)
                                        / (asm_ms / args.steps * 1e-3) / 1e9 if asm_ms > 0 else None,

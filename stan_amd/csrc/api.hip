@@ -94,6 +94,7 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
         }
     }
     else if (option == STAN_OPT_OVERLAP_HALO) ctx->overlap_halo = value != 0;
+    else if (option == STAN_OPT_PLACEMENT_TRIES && value >= 1 && value <= 8) ctx->placement_tries = (int)value;
     else if (option == STAN_OPT_SPMV_VARIANT && value >= -1 && value <= 13) ctx->spmv_variant = (int)value;
     else { ctx->err = "set_option: unknown option or bad value"; return STAN_E_ARG; }
     return STAN_OK;
@@ -168,7 +169,7 @@ void stan_hip_matrix_free(stan_matrix *K) {
     if (K->ctx) hipSetDevice(K->ctx->device);
     // the solves that used these buffers have been synchronised by their own calls; the blocks go
     // back to the context's pool (stan_pool) or to the driver
-    for (void *q : {(void *)K->d_slot_ptr, (void *)K->d_rowlen, (void *)K->d_cols, (void *)K->d_vals,
+    for (void *q : {(void *)K->d_slot_ptr, (void *)K->d_rowlen, (void *)K->d_cols, (void *)K->d_vals_base,
                     (void *)K->d_vals32, (void *)K->d_vals48, (void *)K->d_red, (void *)K->d_fixmask,
                     (void *)K->d_scale, (void *)K->d_send_rows, (void *)K->d_halo_glob, (void *)K->d_sendbuf,
                     (void *)K->d_sl_int, (void *)K->d_sl_bnd})

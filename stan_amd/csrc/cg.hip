@@ -1038,6 +1038,39 @@ int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode
     return STAN_OK;
 }
 
+// Time of the fp64 SpMV of K streaming its values from `vals` (any contents: only the addresses
+// matter), median of 3 launches after a warm-up.  Used by the allocation-by-trial of placement.hip.
+int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const double *vals, float *ms_out) {
+    hipStream_t st_ = ctx->stream;
+    *ms_out = 0;
+    if (K->nslices <= 0) return STAN_OK;
+    const int64_t npad = (int64_t)K->nslices * 64;
+    const int64_t ng = 3 * ((npad > K->nloc + K->nhalo ? npad : K->nloc + K->nhalo));
+    dev_bufs bufs;
+    double *x, *y, *partial; int64_t *stt;
+    STANCHK(alloc(ctx, bufs, &x, (size_t)ng));
+    STANCHK(alloc(ctx, bufs, &y, (size_t)ng));
+    STANCHK(alloc(ctx, bufs, &partial, (size_t)nblk(K->nslices, 4) + 1));
+    STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
+    int64_t init[T_NSTAT] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0, 0, 0, 0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(stt, init, sizeof(init), hipMemcpyHostToDevice, st_));
+    hipLaunchKernelGGL(k_fill, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, x, ng, 1.0);
+    event_bag ev;
+    float t[3] = {0, 0, 0};
+    for (int r = 0; r < 4; r++) {
+        hipEvent_t a = ev.make(), b = ev.make();
+        hipEventRecord(a, st_);
+        launch_spmv<double, true>(ctx, K, vals, x, y, partial, stt, 1);
+        hipEventRecord(b, st_);
+        HIPCHK(ctx, hipEventSynchronize(b));
+        if (r > 0) hipEventElapsedTime(&t[r - 1], a, b);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    const float lo = t[0] < t[1] ? t[0] : t[1], hi = t[0] < t[1] ? t[1] : t[0];
+    *ms_out = t[2] < lo ? lo : (t[2] > hi ? hi : t[2]);
+    return STAN_OK;
+}
+
 // un-scale on export
 int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K) {
     if (!K->scaled) return STAN_OK;

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <functional>
 #include <unordered_map>
 #include <vector>
 
@@ -117,6 +118,8 @@ struct stan_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     int assembly_mode = 0;     // 0 row-owner gather (default), 1 element-wave colour scatter
+    int placement_tries = 1;   // > 1: allocate the value stream by trial (placement.hip)
+    float prof_placement_ms_best = 0, prof_placement_ms_worst = 0;
     int prof_colours = 0;
     int spmv_variant = -1; // -1 = auto (launch_spmv picks per value stream); >= 0: A/B lab
     // profiling
@@ -142,6 +145,7 @@ struct stan_matrix {
     int32_t *d_rowlen = nullptr;    // [nslices*64] blocks per row
     int32_t *d_cols = nullptr;      // [nslots][64] local block-column index
     double *d_vals = nullptr;       // [nslots][9][64]
+    double *d_vals_base = nullptr;  // the allocation d_vals lives in (lab hook STAN_LAB_VALS_OFFSET shifts d_vals)
     float *d_vals32 = nullptr;      // same layout, fp32 copy (mixed precision)
     uint32_t *d_vals48 = nullptr;   // FIXED-48 stream of the scaled values, [slot][14][64] dwords
     bool fx48_refused = false;      // some |a_ij| >= 2 after scaling (K not SPD): fp64 is streamed
@@ -262,3 +266,9 @@ static inline void stan_dfree(stan_ctx *ctx, void *p) {
     }
     hipFree(p);
 }
+
+// placement.hip
+int stan_probe_block(stan_ctx *ctx, const void *p, size_t bytes, float *ms_out);
+int stan_dmalloc_streamed(stan_ctx *ctx, void **p, size_t bytes,
+                          const std::function<int(const void *, float *)> &probe);
+int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const double *vals, float *ms_out);

@@ -1,0 +1,98 @@
+// placement.hip -- where a big device block lands physically decides how fast it streams.
+//
+// Measured on MI355X (tools/placement_probe*.py): the SAME SpMV over the SAME 6.4 GB matrix takes
+// 1.02 ms from one hipMalloc'ed block and 1.15 ms from the next one, steadily, for the life of the
+// block; moving the data inside a block changes nothing.  (Physical contiguity / page-table
+// fragment size of the allocation is the likely cause; the runtime gives no handle on it.)
+// So the value stream of K may be allocated by trial: up to STAN_OPT_PLACEMENT_TRIES blocks are
+// allocated side by side, the SpMV itself is timed on each (the column indices exist by then; the
+// values are whatever the block holds, only the addresses matter), the fastest is kept and the
+// others are freed.  (A plain front-to-back read of the block, k_probe below, tells the bad blocks
+// from the rest but does not rank the rest: tools/placement_probe3.py.)  Off by default (1 try): the search costs `tries` allocations once per context
+// and size -- the block pool keeps the chosen block for the following assemblies.
+#include <functional>
+
+#include "internal.h"
+
+namespace {
+
+constexpr int64_t PROBE_RUN = 15552;  // doubles per wavefront run = 27 slots x 9 x 64 (124 416 B)
+
+__global__ void __launch_bounds__(256)
+k_probe(const double *__restrict__ p, int64_t n, double *sink) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t b0 = wave * PROBE_RUN;
+    if (b0 >= n) return;
+    const int64_t b1 = b0 + PROBE_RUN < n ? b0 + PROBE_RUN : n;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int64_t i = b0 + lane;
+    for (; i + 192 < b1; i += 256) {
+        a0 += __builtin_nontemporal_load(p + i);
+        a1 += __builtin_nontemporal_load(p + i + 64);
+        a2 += __builtin_nontemporal_load(p + i + 128);
+        a3 += __builtin_nontemporal_load(p + i + 192);
+    }
+    for (; i < b1; i += 64) a0 += __builtin_nontemporal_load(p + i);
+    const double s = (a0 + a1) + (a2 + a3);
+    if (s == 0.1234567890123) sink[0] = s;  // keeps the loads alive; practically never taken
+}
+
+}  // namespace
+
+// time of one front-to-back read of the block (median of 3 after 1 warm-up), in ms
+int stan_probe_block(stan_ctx *ctx, const void *p, size_t bytes, float *ms_out) {
+    const int64_t n = (int64_t)(bytes / 8);
+    *ms_out = 0;
+    if (n <= 0) return STAN_OK;
+    const int64_t waves = (n + PROBE_RUN - 1) / PROBE_RUN;
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+    event_bag ev;
+    float t[3] = {0, 0, 0};
+    for (int r = 0; r < 4; r++) {
+        hipEvent_t a = ev.make(), b = ev.make();
+        hipEventRecord(a, ctx->stream);
+        hipLaunchKernelGGL(k_probe, dim3(grid), dim3(256), 0, ctx->stream, (const double *)p, n,
+                           (double *)(ctx->d_status + SS_AUX));
+        hipEventRecord(b, ctx->stream);
+        HIPCHK(ctx, hipEventSynchronize(b));
+        if (r > 0) hipEventElapsedTime(&t[r - 1], a, b);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    const float lo = t[0] < t[1] ? t[0] : t[1], hi = t[0] < t[1] ? t[1] : t[0];
+    *ms_out = t[2] < lo ? lo : (t[2] > hi ? hi : t[2]);
+    return STAN_OK;
+}
+
+// Allocation by trial for a block that will be streamed many times (see the header comment).
+int stan_dmalloc_streamed(stan_ctx *ctx, void **p, size_t bytes,
+                          const std::function<int(const void *, float *)> &probe) {
+    const int tries = ctx->placement_tries;
+    if (tries <= 1 || bytes < ((size_t)256 << 20)) return stan_dmalloc_bytes(ctx, p, bytes);
+    // a parked block of the right size was chosen by an earlier search: take it
+    for (const stan_pool::blk &b : ctx->pool.avail)
+        if (b.cap >= bytes && b.cap <= bytes + bytes / 2) return stan_dmalloc_bytes(ctx, p, bytes);
+    std::vector<void *> cand;
+    std::vector<float> ms;
+    for (int i = 0; i < tries; i++) {
+        void *q = nullptr;
+        if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        float t = 0;
+        const int rc = probe ? probe(q, &t) : stan_probe_block(ctx, q, bytes, &t);
+        if (rc) { hipFree(q); for (void *c : cand) hipFree(c); return rc; }
+        cand.push_back(q);
+        ms.push_back(t);
+    }
+    if (cand.empty()) return stan_dmalloc_bytes(ctx, p, bytes);  // reports the allocation failure
+    size_t best = 0;
+    for (size_t i = 1; i < cand.size(); i++)
+        if (ms[i] < ms[best]) best = i;
+    for (size_t i = 0; i < cand.size(); i++)
+        if (i != best) hipFree(cand[i]);
+    *p = cand[best];
+    if (ctx->pool.enabled) ctx->pool.live[*p] = bytes;
+    ctx->prof_placement_ms_best = ms[best];
+    ctx->prof_placement_ms_worst = ms[0];
+    for (float t : ms) if (t > ctx->prof_placement_ms_worst) ctx->prof_placement_ms_worst = t;
+    return STAN_OK;
+}

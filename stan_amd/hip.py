@@ -20,6 +20,7 @@ PREC_FP64, PREC_MIXED, PREC_FIXED48 = 0, 1, 2
 OPT_CG_MERIT_STOP, OPT_CG_RUPDATE, OPT_SPMV_VARIANT, OPT_OVERLAP_HALO, OPT_ASSEMBLY_MODE = 1, 2, 3, 4, 5
 OPT_CG_FUSED_REFRESH = 6
 OPT_POOL = 7
+OPT_PLACEMENT_TRIES = 8
 E_HIP, E_ARG, E_ALLOC, E_DETJ, E_DOF_LAYOUT, E_VALENCE, E_COMM, E_UNSUPPORTED = (
     -1, -2, -3, -4, -5, -6, -7, -8)
 

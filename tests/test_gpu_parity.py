@@ -326,6 +326,31 @@ def test_block_pool_reuses_and_releases_device_memory(built_libs):
     ctx.close()
 
 
+def test_allocation_by_trial_does_not_change_results(built_libs, oracle):
+    """STAN_OPT_PLACEMENT_TRIES > 1 (placement.hip): K's value array is the fastest-streaming of
+    several hipMalloc blocks; the matrix and the solution are the same bits as with plain allocation."""
+    import torch  # noqa: F401
+    from stan_amd import hip
+    job = problem.cube_job(72, jitter=0.05)       # value array 0.74 GB: above the 256 MB threshold
+    args = (job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+    out = []
+    for tries in (1, 3):
+        ctx = hip.Context(0)
+        ctx.set_option(hip.OPT_PLACEMENT_TRIES, tries)
+        K = ctx.assemble_hex8(*args)
+        U, rep = K.cg_solve(job.F, 1e-8)
+        y = K.spmv_local(np.arange(job.n_dof, dtype=np.float64) % 7 - 3.0)
+        out.append((U, rep, y))
+        K.free()
+        K = ctx.assemble_hex8(*args)              # second assembly: the pooled winner, no new search
+        assert np.array_equal(K.spmv_local(np.arange(job.n_dof, dtype=np.float64) % 7 - 3.0), y)
+        K.free()
+        ctx.close()
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] and np.array_equal(out[0][2], out[1][2])
+    with pytest.raises(hip.StanHipError):
+        hip.Context(0).set_option(hip.OPT_PLACEMENT_TRIES, 99)
+
+
 def test_cg_is_bit_reproducible(gpu_ctx):
     job = problem.cube_job(8, jitter=0.1)
     res = []

@@ -6,7 +6,7 @@ i=0
 for FLAGS in "$@"; do
   i=$((i+1))
   rm -rf build_lab; mkdir -p build_lab
-  for f in api assembly assembly_scatter cg scan comm recovery csr_lab; do
+  for f in api assembly assembly_scatter placement cg scan comm recovery csr_lab; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -ffp-contract=fast $FLAGS -c $f.hip -o build_lab/$f.o &
   done; wait
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libstan_lab_$i.so build_lab/*.o -ldl
