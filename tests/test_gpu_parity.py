@@ -338,8 +338,8 @@ def test_allocation_by_trial_does_not_change_results(built_libs, oracle):
         ctx = hip.Context(0)
         ctx.set_option(hip.OPT_PLACEMENT_TRIES, tries)
         K = ctx.assemble_hex8(*args)
+        y = K.spmv_local(np.arange(job.n_dof, dtype=np.float64) % 7 - 3.0)   # before the CG scales K
         U, rep = K.cg_solve(job.F, 1e-8)
-        y = K.spmv_local(np.arange(job.n_dof, dtype=np.float64) % 7 - 3.0)
         out.append((U, rep, y))
         K.free()
         K = ctx.assemble_hex8(*args)              # second assembly: the pooled winner, no new search
