@@ -804,7 +804,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         // (after the FILL pass: an allocation by trial times the SpMV itself, which needs the columns)
         STANCHK(stan_dmalloc_streamed(ctx, (void **)&K->d_vals_base, ((size_t)K->nslots * 9 * 64 + pad) * 8,
                                       [&](const void *q, float *ms) {
-                                          return stan_spmv_probe(ctx, K, (const double *)q + shift, ms);
+                                          return stan_spmv_probe(ctx, K, (const double *)q + shift, STAN_PREC_FP64, ms);
                                       }));
         K->d_vals = K->d_vals_base + shift;
     }

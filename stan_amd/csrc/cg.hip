@@ -657,7 +657,10 @@ static int ensure_scaled(stan_ctx *ctx, stan_matrix *K) {
 int stan_matrix_make_fp32(stan_ctx *ctx, stan_matrix *K) {
     if (K->d_vals32) return STAN_OK;
     const int64_t n = K->nslots * 9 * 64;
-    STANCHK(stan_dmalloc(ctx, &K->d_vals32, (size_t)n));
+    STANCHK(stan_dmalloc_streamed(ctx, (void **)&K->d_vals32, (size_t)n * 4,
+                                  [&](const void *q, float *ms) {
+                                      return stan_spmv_probe(ctx, K, q, STAN_PREC_MIXED, ms);
+                                  }));
     hipLaunchKernelGGL(k_to_fp32, dim3(vec_grid(n) * 4), dim3(VEC_T), 0, ctx->stream, K->d_vals,
                        K->d_vals32, n);
     HIPCHK(ctx, hipGetLastError());
@@ -670,7 +673,10 @@ int stan_matrix_make_fx48(stan_ctx *ctx, stan_matrix *K) {
     if (K->d_vals48 || K->fx48_refused) return STAN_OK;
     if (K->nslots == 0) return STAN_OK;
     uint32_t *out;
-    STANCHK(stan_dmalloc(ctx, &out, (size_t)K->nslots * 14 * 64));
+    STANCHK(stan_dmalloc_streamed(ctx, (void **)&out, (size_t)K->nslots * 14 * 64 * 4,
+                                  [&](const void *q, float *ms) {
+                                      return stan_spmv_probe(ctx, K, q, STAN_PREC_FIXED48, ms);
+                                  }));
     unsigned long long *d_bad = (unsigned long long *)(ctx->d_status + SS_COUNTER);
     HIPCHK(ctx, hipMemsetAsync(d_bad, 0, 8, ctx->stream));
     hipLaunchKernelGGL(k_to_fx48, dim3((unsigned)nblk(K->nslots * 64, 256)), dim3(256), 0, ctx->stream,
@@ -1040,7 +1046,7 @@ int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode
 
 // Time of the fp64 SpMV of K streaming its values from `vals` (any contents: only the addresses
 // matter), median of 3 launches after a warm-up.  Used by the allocation-by-trial of placement.hip.
-int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const double *vals, float *ms_out) {
+int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, int32_t precision, float *ms_out) {
     hipStream_t st_ = ctx->stream;
     *ms_out = 0;
     if (K->nslices <= 0) return STAN_OK;
@@ -1060,7 +1066,12 @@ int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const double *vals, float *ms
     for (int r = 0; r < 4; r++) {
         hipEvent_t a = ev.make(), b = ev.make();
         hipEventRecord(a, st_);
-        launch_spmv<double, true>(ctx, K, vals, x, y, partial, stt, 1);
+        if (precision == STAN_PREC_FIXED48)
+            launch_spmv<uint32_t, true>(ctx, K, (const uint32_t *)vals, x, y, partial, stt, 1);
+        else if (precision == STAN_PREC_MIXED)
+            launch_spmv<float, true>(ctx, K, (const float *)vals, x, y, partial, stt, 1);
+        else
+            launch_spmv<double, true>(ctx, K, (const double *)vals, x, y, partial, stt, 1);
         hipEventRecord(b, st_);
         HIPCHK(ctx, hipEventSynchronize(b));
         if (r > 0) hipEventElapsedTime(&t[r - 1], a, b);

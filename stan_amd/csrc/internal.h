@@ -271,4 +271,4 @@ static inline void stan_dfree(stan_ctx *ctx, void *p) {
 int stan_probe_block(stan_ctx *ctx, const void *p, size_t bytes, float *ms_out);
 int stan_dmalloc_streamed(stan_ctx *ctx, void **p, size_t bytes,
                           const std::function<int(const void *, float *)> &probe);
-int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const double *vals, float *ms_out);
+int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, int32_t precision, float *ms_out);

@@ -38,7 +38,7 @@ def _torchrun(nproc, script_args, env_extra):
         proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
                                 cwd=ROOT, start_new_session=True)   # own process group: launcher + ranks
         try:
-            out, err = proc.communicate(timeout=90)
+            out, err = proc.communicate(timeout=300)
             return subprocess.CompletedProcess(cmd, proc.returncode, out, err)
         except subprocess.TimeoutExpired:
             os.killpg(proc.pid, signal.SIGKILL)                      # exactly the group started above
