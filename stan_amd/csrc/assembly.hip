@@ -797,17 +797,11 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
                            d_ptr, d_list, d_conn, d_perm, K->d_rowlen, (int32_t *)nullptr,
                            (const int64_t *)d_halo_rank, (const int32_t *)K->d_slot_ptr, K->d_cols,
                            d_status);
-    {   // lab hook (tools/placement_probe.py): shift the value stream inside its allocation
-        const char *off = getenv("STAN_LAB_VALS_OFFSET");
-        const size_t shift = off ? (size_t)atoll(off) / 8 : 0;
-        const size_t pad = off ? ((size_t)8 << 20) / 8 : 0;   // same block size for every offset <= 8 MB
-        // (after the FILL pass: an allocation by trial times the SpMV itself, which needs the columns)
-        STANCHK(stan_dmalloc_streamed(ctx, (void **)&K->d_vals_base, ((size_t)K->nslots * 9 * 64 + pad) * 8,
-                                      [&](const void *q, float *ms) {
-                                          return stan_spmv_probe(ctx, K, (const double *)q + shift, STAN_PREC_FP64, ms);
-                                      }));
-        K->d_vals = K->d_vals_base + shift;
-    }
+    // (after the FILL pass: an allocation by trial times the SpMV itself, which needs the columns)
+    STANCHK(stan_dmalloc_streamed(ctx, (void **)&K->d_vals, (size_t)K->nslots * 9 * 64 * 8,
+                                  [&](const void *q, float *ms) {
+                                      return stan_spmv_probe(ctx, K, q, STAN_PREC_FP64, ms);
+                                  }));
     if (ctx->profiling) hipEventRecord(ev1, st);
 
     // numeric

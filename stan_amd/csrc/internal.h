@@ -145,7 +145,6 @@ struct stan_matrix {
     int32_t *d_rowlen = nullptr;    // [nslices*64] blocks per row
     int32_t *d_cols = nullptr;      // [nslots][64] local block-column index
     double *d_vals = nullptr;       // [nslots][9][64]
-    double *d_vals_base = nullptr;  // the allocation d_vals lives in (lab hook STAN_LAB_VALS_OFFSET shifts d_vals)
     float *d_vals32 = nullptr;      // same layout, fp32 copy (mixed precision)
     uint32_t *d_vals48 = nullptr;   // FIXED-48 stream of the scaled values, [slot][14][64] dwords
     bool fx48_refused = false;      // some |a_ij| >= 2 after scaling (K not SPD): fp64 is streamed

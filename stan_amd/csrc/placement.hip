@@ -2,8 +2,9 @@
 //
 // Measured on MI355X (tools/placement_probe*.py): the SAME SpMV over the SAME 6.4 GB matrix takes
 // 1.02 ms from one hipMalloc'ed block and 1.15 ms from the next one, steadily, for the life of the
-// block; moving the data inside a block changes nothing.  (Physical contiguity / page-table
-// fragment size of the allocation is the likely cause; the runtime gives no handle on it.)
+// block; moving the data inside a block (offsets of 256 B ... 4 MB) changes nothing, and asking
+// for a physically contiguous block (hipExtMallocWithFlags, hipDeviceMallocContiguous) does not
+// remove the lottery either (both tried with lab hooks that are no longer in the tree).
 // So the value stream of K may be allocated by trial: up to STAN_OPT_PLACEMENT_TRIES blocks are
 // allocated side by side, the SpMV itself is timed on each (the column indices exist by then; the
 // values are whatever the block holds, only the addresses matter), the fastest is kept and the
