@@ -55,6 +55,7 @@ struct rccl_api {
 // flushes the pool and retries; STAN_OPT_POOL = 0 flushes and disables; destroy frees everything.
 struct stan_pool {
     static constexpr size_t MIN_BYTES = 8u << 20;
+    static constexpr size_t MAX_BLOCKS = 64;   // parked blocks; one assemble + solve parks ~30
     struct blk { void *p; size_t cap; };
     std::vector<blk> avail;
     std::unordered_map<void *, size_t> live;  // pooled-class blocks currently handed out
@@ -259,6 +260,11 @@ static inline void stan_dfree(stan_ctx *ctx, void *p) {
             if (ctx->pool.enabled) {
                 ctx->pool.avail.push_back({p, cap});
                 ctx->pool.bytes_avail += cap;
+                if (ctx->pool.avail.size() > stan_pool::MAX_BLOCKS) {  // a host cycling through
+                    hipFree(ctx->pool.avail.front().p);               // many sizes: drop the oldest
+                    ctx->pool.bytes_avail -= ctx->pool.avail.front().cap;
+                    ctx->pool.avail.erase(ctx->pool.avail.begin());
+                }
                 return;
             }
         }
