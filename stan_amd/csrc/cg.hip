@@ -391,6 +391,9 @@ k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
 }
 
 // ---- CG step kernels ----------------------------------------------------------------------------
+#ifndef STAN_VEC_NT
+#define STAN_VEC_NT 1
+#endif
 struct step_args {
     int64_t n3;           // 3 * owned block rows
     int64_t k;            // iteration number (1-based)
@@ -430,11 +433,21 @@ __global__ void __launch_bounds__(VEC_T) k_step(step_args a) {
     double s_r2 = 0, s_mf = 0;
     const int64_t stride = (int64_t)gridDim.x * VEC_T;
     for (int64_t i = (int64_t)blockIdx.x * VEC_T + threadIdx.x; i < a.n3; i += stride) {
+#if STAN_VEC_NT  // the iterate vectors pass through once per kernel: keep them out of the caches p lives in
+        const double pi = __builtin_nontemporal_load(a.p + i);
+        const double cx = __builtin_nontemporal_load(a.xcur + i) + alpha * pi;
+        __builtin_nontemporal_store(cx, a.xnext + i);
+#else
         const double pi = a.p[i];
         const double cx = a.xcur[i] + alpha * pi;
         a.xnext[i] = cx;
+#endif
         if (a.refresh == 0) {
+#if STAN_VEC_NT
+            const double cr = __builtin_nontemporal_load(a.r + i) - alpha * __builtin_nontemporal_load(a.v + i);
+#else
             const double cr = a.r[i] - alpha * a.v[i];
+#endif
             a.r[i] = cr;
             s_r2 += cr * cr;
             if (a.merit) s_mf -= (cr + a.bh[i]) * cx;
@@ -514,7 +527,11 @@ k_update(int64_t n3, int64_t k, double *sc, int64_t *st, double epsf, int64_t ma
     if (type) return;
     const int64_t stride = (int64_t)gridDim.x * VEC_T;
     for (int64_t i = (int64_t)blockIdx.x * VEC_T + threadIdx.x; i < n3; i += stride)
+#if STAN_VEC_NT >= 2
+        p[i] = __builtin_nontemporal_load(r + i) + beta * __builtin_nontemporal_load(p + i);  // the new p stays cacheable
+#else
         p[i] = r[i] + beta * p[i];
+#endif
 }
 
 // U[d - red[d]] = s_d * x^_d on free DOFs (SolverFunctions.cs:305 lincgresults + un-scaling)
