@@ -22,6 +22,14 @@
 
 #include "internal.h"
 
+// lab switches (tools/lib_lab.sh): non-temporal policy of the vector traffic
+#ifndef STAN_VEC_NT
+#define STAN_VEC_NT 1
+#endif
+#ifndef STAN_Y_NT
+#define STAN_Y_NT 1
+#endif
+
 namespace {
 
 constexpr int VEC_BLOCKS = 2048;  // grid of the streaming vector kernels (8 blocks per CU)
@@ -321,7 +329,13 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
             }
         }
         if (row < nloc) {
-            y[3 * row] = y0; y[3 * row + 1] = y1; y[3 * row + 2] = y2;
+#if STAN_Y_NT  // A p is read exactly once, by k_step
+            if (NT) {
+                __builtin_nontemporal_store(y0, y + 3 * row); __builtin_nontemporal_store(y1, y + 3 * row + 1);
+                __builtin_nontemporal_store(y2, y + 3 * row + 2);
+            } else
+#endif
+            { y[3 * row] = y0; y[3 * row + 1] = y1; y[3 * row + 2] = y2; }
         }
     }
     if (DOT) {
@@ -391,9 +405,7 @@ k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
 }
 
 // ---- CG step kernels ----------------------------------------------------------------------------
-#ifndef STAN_VEC_NT
-#define STAN_VEC_NT 1
-#endif
+
 struct step_args {
     int64_t n3;           // 3 * owned block rows
     int64_t k;            // iteration number (1-based)
