@@ -69,6 +69,9 @@ int64_t stan_hip_last_bad_element(stan_ctx *ctx) { return ctx ? ctx->bad_elem : 
 
 int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream) {
     if (!ctx) return STAN_E_ARG;
+    hipSetDevice(ctx->device);
+    // parked blocks of the pool are reused in stream order: drain the old stream before switching
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     ctx->own_stream = false;
     ctx->stream = (hipStream_t)hip_stream;
