@@ -58,6 +58,9 @@ void stan_hip_destroy(stan_ctx *ctx) {
     if (ctx->side) hipStreamDestroy(ctx->side);
     if (ctx->ev_a) hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) hipEventDestroy(ctx->ev_b);
+    // matrices that outlive their context keep working memory-wise: they are detached and their
+    // buffers go straight back to the driver when they are freed
+    for (stan_matrix *K : ctx->matrices) K->ctx = nullptr;
     ctx->pool.flush();
     if (ctx->h_status) hipHostFree(ctx->h_status);
     if (ctx->d_status) hipFree(ctx->d_status);
@@ -169,7 +172,12 @@ int stan_hip_assemble_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz,
 
 void stan_hip_matrix_free(stan_matrix *K) {
     if (!K) return;
-    if (K->ctx) hipSetDevice(K->ctx->device);
+    if (K->ctx) {
+        hipSetDevice(K->ctx->device);
+        auto &v = K->ctx->matrices;
+        for (size_t i = 0; i < v.size(); i++)
+            if (v[i] == K) { v.erase(v.begin() + i); break; }
+    }
     // the solves that used these buffers have been synchronised by their own calls; the blocks go
     // back to the context's pool (stan_pool) or to the driver
     for (void *q : {(void *)K->d_slot_ptr, (void *)K->d_rowlen, (void *)K->d_cols, (void *)K->d_vals,

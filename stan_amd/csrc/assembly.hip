@@ -670,6 +670,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     tmp.ctx = ctx;
     stan_matrix *K = new stan_matrix();
     K->ctx = ctx;
+    ctx->matrices.push_back(K);
     struct guard {
         stan_matrix *k; bool ok = false;
         ~guard() { if (!ok) stan_hip_matrix_free(k); }

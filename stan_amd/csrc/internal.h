@@ -101,6 +101,7 @@ enum stan_status_slot {
     SS_H_CG_SCALARS = 40 // host: the CG scalars at the end of a solve
 };
 
+struct stan_matrix;
 struct stan_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -127,6 +128,7 @@ struct stan_ctx {
     bool profiling = false;
     stan_profile prof{};
     stan_pool pool;
+    std::vector<stan_matrix *> matrices;  // alive matrices of this context (detached when it is destroyed)
     // small pinned host + device scratch for status words
     int64_t *h_status = nullptr;  // pinned, 64 words
     int64_t *d_status = nullptr;  // device, 64 words

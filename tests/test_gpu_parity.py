@@ -351,6 +351,23 @@ def test_allocation_by_trial_does_not_change_results(built_libs, oracle):
         hip.Context(0).set_option(hip.OPT_PLACEMENT_TRIES, 99)
 
 
+def test_matrix_may_outlive_its_context(built_libs):
+    """Destroying a context detaches its matrices: freeing them afterwards is safe (their buffers
+    go straight back to the driver)."""
+    import torch  # noqa: F401
+    from stan_amd import hip
+    job = problem.cube_job(6)
+    ctx = hip.Context(0)
+    K = ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+    K2 = ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+    K2.free()
+    lib, h = ctx.lib, ctx.h
+    lib.stan_hip_destroy(h)      # the context goes first
+    ctx.h = None
+    lib.stan_hip_matrix_free(K.k)
+    K.k = None
+
+
 def test_cg_is_bit_reproducible(gpu_ctx):
     job = problem.cube_job(8, jitter=0.1)
     res = []
