@@ -394,8 +394,15 @@ k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
             vp += vstream<VT>::STRIDE;
         }
         if (row < nloc) {
+#if STAN_Y_NT  // both products are read exactly once, by k_step
+            __builtin_nontemporal_store(y0, y + 3 * row); __builtin_nontemporal_store(y1, y + 3 * row + 1);
+            __builtin_nontemporal_store(yy2, y + 3 * row + 2);
+            __builtin_nontemporal_store(z0, y2 + 3 * row); __builtin_nontemporal_store(z1, y2 + 3 * row + 1);
+            __builtin_nontemporal_store(z2, y2 + 3 * row + 2);
+#else
             y[3 * row] = y0; y[3 * row + 1] = y1; y[3 * row + 2] = yy2;
             y2[3 * row] = z0; y2[3 * row + 1] = z1; y2[3 * row + 2] = z2;
+#endif
         }
     }
     double d = 0;
