@@ -4,7 +4,9 @@
 // 1.02 ms from one hipMalloc'ed block and 1.15 ms from the next one, steadily, for the life of the
 // block; moving the data inside a block (offsets of 256 B ... 4 MB) changes nothing, and asking
 // for a physically contiguous block (hipExtMallocWithFlags, hipDeviceMallocContiguous) does not
-// remove the lottery either (both tried with lab hooks that are no longer in the tree).
+// remove the lottery either, nor does rounding the sizes to 2 MB (all tried with lab hooks that are
+// no longer in the tree).  For a given sequence of allocations the outcome repeats from process to
+// process: it is a property of the addresses the allocator hands out.
 // So the value stream of K may be allocated by trial: up to STAN_OPT_PLACEMENT_TRIES blocks are
 // allocated side by side, the SpMV itself is timed on each (the column indices exist by then; the
 // values are whatever the block holds, only the addresses matter), the fastest is kept and the
