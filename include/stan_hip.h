@@ -89,10 +89,11 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
                                      matrix pass and r = b - (A x + a A p); 0: ALGLIB's literal
                                      second product A (x + a p).  Same value up to rounding. */
 #define STAN_OPT_PLACEMENT_TRIES 8 /* 1 (default): plain allocation.  n = 2..8: the value array of K is
-                           allocated by trial -- n blocks side by side, each read front to back like the
-                           SpMV reads, the fastest kept (placement.hip: the same matrix streams 10 % faster
-                           from some hipMalloc blocks than from others).  Costs n allocations once per
-                           context and size; the block pool keeps the winner. */
+                           allocated by trial -- n blocks side by side, the SpMV timed on each, the fastest
+                           kept (placement.hip: the same matrix streams 10 % faster from some hipMalloc
+                           blocks than from others).  Costs n allocations once per context and size; the
+                           block pool keeps the winner.  Destroying a context detaches its matrices: they
+                           may be freed afterwards. */
 #define STAN_OPT_POOL 7 /* 1 (default): device blocks >= 8 MB freed by the library stay with the
                            context and are reused by its next allocations (a hipMalloc of tens of GB
                            costs 0.4-1.8 s here); 0: release them now, plain hipMalloc/hipFree from then on */
