@@ -6,7 +6,8 @@
 // for a physically contiguous block (hipExtMallocWithFlags, hipDeviceMallocContiguous) does not
 // remove the lottery either, nor does rounding the sizes to 2 MB (all tried with lab hooks that are
 // no longer in the tree).  For a given sequence of allocations the outcome repeats from process to
-// process: it is a property of the addresses the allocator hands out.
+// process: it is a property of the addresses the allocator hands out.  The column array's placement
+// does not matter (eight fresh copies of cols under one value array: 1.112-1.121 ms).
 // So the value stream of K may be allocated by trial: up to STAN_OPT_PLACEMENT_TRIES blocks are
 // allocated side by side, the SpMV itself is timed on each (the column indices exist by then; the
 // values are whatever the block holds, only the addresses matter), the fastest is kept and the
