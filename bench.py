@@ -93,7 +93,7 @@ def ensure_built():
             if time.time() - t0 > 900:
                 raise SystemExit("bench.py: native libraries were not built within 15 min")
             time.sleep(2.0)
-        time.sleep(5.0)   # let the linker finish writing
+        # (the Makefiles link to a temporary name and rename: a file that exists is complete)
 
 
 def main():
@@ -108,6 +108,10 @@ def main():
     ap.add_argument("--fixed48", action="store_true",
                     help="fp64 arithmetic on the 48-bit fixed-point stream of the scaled matrix")
     ap.add_argument("--etype", type=int, default=2, help="2 = HEX8_G2, 1 = HEX8_G1")
+    ap.add_argument("--max-its", type=int, default=0,
+                    help="LinSolverIterMax; a capped run reports per-iteration timings only (value null)")
+    ap.add_argument("--single-reduce", action="store_true",
+                    help="STAN_OPT_CG_SINGLE_REDUCE: Chronopoulos-Gear loop (not the oracle's recurrences)")
     ap.add_argument("--cpu-n", type=int, default=56, help="cube edge of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--placement-tries", type=int, default=4,
@@ -150,6 +154,8 @@ def main():
         ctx.comm_init(rank, world, bytes(uid.cpu().tolist()))
     ctx.set_option(hip.OPT_CG_MERIT_STOP, 0)
     ctx.set_option(hip.OPT_PLACEMENT_TRIES, max(1, min(8, args.placement_tries)))
+    if args.single_reduce:
+        ctx.set_option(hip.OPT_CG_SINGLE_REDUCE, 1)
     ctx.set_profiling(True)
 
     # inputs resident in HBM before the timed region
@@ -168,7 +174,7 @@ def main():
         K = ctx.assemble_hex8_dev(job.xyz.shape[0], d_xyz.data_ptr(), d_dof.data_ptr(),
                                   job.conn.shape[0], d_conn.data_ptr(), d_mat.data_ptr(),
                                   d_typ.data_ptr(), job.mat_E_nu, job.n_dof, d_red.data_ptr())
-        rep = K.cg_solve_dev(d_F.data_ptr(), d_U.data_ptr(), args.eps, 0, prec)
+        rep = K.cg_solve_dev(d_F.data_ptr(), d_U.data_ptr(), args.eps, args.max_its, prec)
         prof = ctx.profile()
         info = K.info()
         K.free()
@@ -218,14 +224,26 @@ def main():
         avg_ms = spmv_ms / max(spmv_n, 1)
         # HBM traffic per launch from the committed PMC passes (tools/pmc_run.sh), if one exists
         # for this workload; counters cannot be collected from inside this process
-        traffic = None
+        traffic = traffic_source = None
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_spmv*.json"))):
             d = json.load(open(f))
             if (d.get("workload_n") == args.n and world == 1 and
                     d.get("value_stream", 0) == prof["value_stream"]):
                 traffic = d["traffic_bytes_per_launch"]
+                traffic_source = os.path.relpath(f, ROOT)
         achieved = prof["spmv_bytes"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # SURVEY section 8d prices the REDUCED system (fixed DOFs squeezed out); this library keeps
+        # them as identity rows, so a launch moves slightly more.  Both
+        # fractions are reported; the x-clamped cube's reduced block count is (3n-2)(3n+1)^2.
+        frac_reduced = csr_equiv = None
+        if args.etype == 2 and world == 1 and avg_ms > 0:
+            blocks_red = (3 * args.n - 2) * (3 * args.n + 1) ** 2
+            blk_bytes = 40 if args.mixed else 60 if args.fixed48 else 76
+            bytes_red = blocks_red * blk_bytes + job.n_red * 16 + (job.n_red // 3) * 4
+            frac_reduced = bytes_red / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            # the same product priced as scalar CSR (fp64 values, int32 columns): 12 nnz + 20 N
+            csr_equiv = (12 * 9 * blocks_red + 20 * job.n_red) / (avg_ms * 1e-3) / 1e9
         out = {
             "metric": "DOF/s (assembly+CG to 1e-8) on 10M-DOF HEX8 cube; SpMV GB/s vs HBM peak",
             "value": job.n_dof * args.steps / dt,
@@ -235,12 +253,19 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
+            # non-default library options this number depends on (DESIGN.md sections 3, 4)
+            "merit_stop": False, "placement_tries": args.placement_tries,
             "dtype": ("f32 matrix / f64 vectors" if args.mixed else
                       "f64 (matrix streamed as 48-bit fixed point)" if args.fixed48 else "f64"),
             "data": "synthetic",
-            "config": {"workload": "%d^3 HEX8_G%d cube, %d DOF, clamp x=0, PointLoad (0,0,50) on "
+            "config": {"workload": "%d^3 HEX8_G%d cube, %d DOF, clamp %s, PointLoad (0,0,50) on "
                                    "x=n; fp64 Jacobi-scaled CG to %.0e" %
-                                   (args.n, args.etype, job.n_dof, args.eps),
+                                   (args.n, args.etype, job.n_dof,
+                                    "x=0" if args.etype == 2 else "x=0, y=0, z=0", args.eps),
+                       "cg_loop": "single-reduction (Chronopoulos-Gear)" if args.single_reduce
+                                  else "classic (alglib lincg recurrences)",
+                       "loop_kernel_launches_per_iteration":
+                           prof["loop_kernel_launches"] / max(prof["loop_iterations_enqueued"], 1),
                        "n_dof": job.n_dof, "n_reduced": job.n_red,
                        "blocks_3x3_rank0": info["n_blocks"], "cg_iterations": rep["iterations"],
                        "termination_type": rep["terminationtype"],
@@ -260,6 +285,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_spmv (BSELL-64 SpMV + fused p.Ap)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         # counters cannot be read from inside this process: the figure is the
+                         # committed PMC pass of the same workload, not a measurement of this run
+                         "traffic_source": traffic_source,
+                         "frac_reduced_system_bytes": frac_reduced,
+                         "csr_equivalent_GBs": csr_equiv,
                          "bytes_per_launch": prof["spmv_bytes"], "avg_launch_ms": avg_ms,
                          "launches": int(spmv_n),
                          # refresh iterations: A p and A x from one matrix pass (not in the average)
@@ -273,10 +303,16 @@ def main():
             out["cpu_baseline_all_cores"] = base_all
         else:
             out["cpu_baseline"] = None
+        if not ok:   # a step that did not reach eps is not a step of this metric
+            out["value"] = None
+            out["error"] = "CG ended with type %d at %.3e (> eps %.0e): no DOF/s reported" % (
+                rep["terminationtype"], rep["rel_residual"], args.eps)
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0 and not ok:
+        raise SystemExit(4)
 
 
 if __name__ == "__main__":

@@ -88,6 +88,15 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
 #define STAN_OPT_CG_FUSED_REFRESH 6 /* 1 (default): on refresh iterations A x and A p come from ONE
                                      matrix pass and r = b - (A x + a A p); 0: ALGLIB's literal
                                      second product A (x + a p).  Same value up to rounding. */
+#define STAN_OPT_CG_SINGLE_REDUCE 10 /* 0 (default): the classic loop = alglib's recurrences (two reduction points
+                           per iteration: p.Ap, then r.r with the merit sum).  1: Chronopoulos-Gear form --
+                           the same iterates in exact arithmetic from ONE reduction point per iteration
+                           (r.r, r.Ar and the merit sum in one all-reduce of 3 doubles when sharded; two
+                           kernels per iteration instead of three).  Same stopping rules and codes;
+                           iteration counts may differ by a few (different rounding). */
+#define STAN_OPT_CG_FOLD_REDUCE 11 /* 1 (default): the block of a producing kernel that finishes last adds up the
+                           per-block partial sums (fixed order); 0: separate one-block reduction launches,
+                           same order, same bits. */
 #define STAN_OPT_PLACEMENT_TRIES 8 /* 1 (default): plain allocation.  n = 2..8: the value array of K is
                            allocated by trial -- n blocks side by side, the SpMV timed on each, the fastest
                            kept (placement.hip: the same matrix streams 10 % faster from some hipMalloc
@@ -97,7 +106,13 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
 #define STAN_OPT_POOL 7 /* 1 (default): device blocks >= 8 MB freed by the library stay with the
                            context and are reused by its next allocations (a hipMalloc of tens of GB
                            costs 0.4-1.8 s here); 0: release them now, plain hipMalloc/hipFree from then on */
-#define STAN_OPT_SPMV_VARIANT 3 /* tuning variants of the SpMV kernel (cg.hip), A/B runs only; -1 = auto (default) */
+#define STAN_OPT_POOL_MAX_BYTES 9 /* byte budget of the parked blocks (default: half the device memory; the oldest are released
+                           beyond it).  Setting it trims at once: 0 releases everything parked now and keeps
+                           nothing afterwards, without switching the reuse of live blocks' sizes off. */
+#define STAN_OPT_SPMV_VARIANT 3 /* SpMV kernel variant (cg.hip): -1 = auto (default: 9 for fp64/fp32 streams,
+                           12 for FIXED-48), 0 = plain loads + identity mapping, 9 = non-temporal matrix
+                           stream + XCD-chunked workgroup mapping, 12 = 9 unrolled by 4.  Every accepted
+                           value computes the same product; anything else is STAN_E_ARG. */
 int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value);
 /* What STAN_OPT_POOL currently keeps: bytes and number of parked device blocks (either may be NULL). */
 int stan_hip_pool_info(stan_ctx *ctx, int64_t *bytes_parked, int64_t *blocks_parked);
@@ -225,12 +240,8 @@ int stan_hip_spmv(stan_ctx *ctx, stan_matrix *K, const double *x, double *y);
 int stan_hip_spmv_bench(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode, int32_t reps,
                         double *avg_ms);
 
-/* Measurement aid: the same operator converted on the device to scalar CSR (fp64 values,
- * int32 columns) and multiplied by a CSR-vector kernel, timed like stan_hip_spmv_bench: the
- * number next to the BSELL-64 format decision.  max_rel_diff compares its product
- * with the BSELL-64 one.  Single-rank contexts, matrix in its current (scaled or not) state. */
-int stan_hip_csr_spmv_bench(stan_ctx *ctx, stan_matrix *K, int32_t reps, double *avg_ms,
-                            int64_t *bytes_per_launch, double *max_rel_diff);
+/* (The scalar-CSR comparison kernel of round 1, stan_hip_csr_spmv_bench, is a lab aid and lives in
+ * the lab build only: stan_amd/csrc/lab/stan_hip_lab.h, `make -C stan_amd/csrc lab`.) */
 
 /* Per-phase device timings of the most recent assemble / solve, measured with HIP events on
  * the context stream (profiling must be enabled first; it adds one event pair per launch). */
@@ -249,6 +260,9 @@ typedef struct stan_profile {
     int32_t value_stream;     /* STAN_PREC_* of the stream the last CG actually read */
     double spmv2_ms_total;    /* two-product launches of the refresh iterations (k_spmv2),  */
     int64_t spmv2_launches;   /* NOT included in spmv_ms_total / spmv_launches              */
+    int64_t loop_kernel_launches;     /* kernels the CG loop enqueued (incl. the run-ahead)  */
+    int64_t loop_collectives;         /* RCCL all-reduces the loop enqueued (halo exchanges not counted) */
+    int64_t loop_iterations_enqueued; /* iterations those two counts cover                   */
 } stan_profile;
 int stan_hip_set_profiling(stan_ctx *ctx, int32_t enabled);
 int stan_hip_get_profile(stan_ctx *ctx, stan_profile *out);

@@ -46,6 +46,8 @@ int stan_hip_init(int device, stan_ctx **out) {
         return STAN_E_HIP;
     }
     c->own_stream = true;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) c->pool.max_bytes = total_b / 2;
     *out = c;
     return STAN_OK;
 }
@@ -91,6 +93,8 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
     else if (option == STAN_OPT_CG_RUPDATE && value >= 0 && value < (1 << 30)) ctx->cg_rupdate = (int)value;
     else if (option == STAN_OPT_ASSEMBLY_MODE && (value == 0 || value == 1)) ctx->assembly_mode = (int)value;
     else if (option == STAN_OPT_CG_FUSED_REFRESH) ctx->cg_fused_refresh = value != 0;
+    else if (option == STAN_OPT_CG_SINGLE_REDUCE) ctx->cg_single_reduce = value != 0;
+    else if (option == STAN_OPT_CG_FOLD_REDUCE) ctx->cg_fold_reduce = value != 0;
     else if (option == STAN_OPT_POOL) {
         ctx->pool.enabled = value != 0;
         if (!ctx->pool.enabled) {
@@ -99,9 +103,24 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
             ctx->pool.flush();
         }
     }
+    else if (option == STAN_OPT_POOL_MAX_BYTES && value >= 0) {
+        ctx->pool.max_bytes = (size_t)value;
+        hipSetDevice(ctx->device);
+        hipStreamSynchronize(ctx->stream);  // parked blocks may still be in use by queued work
+        while (!ctx->pool.avail.empty() && ctx->pool.bytes_avail > ctx->pool.max_bytes) {
+            hipFree(ctx->pool.avail.front().p);
+            ctx->pool.bytes_avail -= ctx->pool.avail.front().cap;
+            ctx->pool.avail.erase(ctx->pool.avail.begin());
+        }
+    }
     else if (option == STAN_OPT_OVERLAP_HALO) ctx->overlap_halo = value != 0;
     else if (option == STAN_OPT_PLACEMENT_TRIES && value >= 1 && value <= 8) ctx->placement_tries = (int)value;
+#ifdef STAN_LAB
     else if (option == STAN_OPT_SPMV_VARIANT && value >= -1 && value <= 13) ctx->spmv_variant = (int)value;
+#else   // the product library carries the three variants that give right answers (cg.hip)
+    else if (option == STAN_OPT_SPMV_VARIANT && (value == -1 || value == 0 || value == 9 || value == 12))
+        ctx->spmv_variant = (int)value;
+#endif
     else { ctx->err = "set_option: unknown option or bad value"; return STAN_E_ARG; }
     return STAN_OK;
 }

@@ -38,7 +38,10 @@ constexpr int CHUNK = 32;         // iterations enqueued between two status poll
 
 // device scalar slots (double)
 enum { S_BNORM = 0, S_VMV = 1, S_R2NEW = 2, S_MERIT = 3, S_RHO0 = 4, S_RHO1 = 5, S_PMF0 = 6,
-       S_PMF1 = 7, S_R2OUT = 8, S_NSCAL = 16 };
+       S_PMF1 = 7, S_R2OUT = 8,
+       // single-reduction loop: the three sums of one iteration are contiguous (ONE all-reduce)
+       S_SR_GAMMA = 9, S_SR_DELTA = 10, S_SR_MERIT = 11, S_SR_GP0 = 12, S_SR_GP1 = 13, S_SR_AP0 = 14,
+       S_SR_AP1 = 15, S_NSCAL = 24 };
 // device status slots (int64)
 enum { T_ITER_A = 0, T_ITER_B = 1, T_TYPE = 2, T_ITERS = 3, T_XSEL = 4, T_NSTAT = 8 };
 
@@ -55,6 +58,65 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
     if (lane == 0) sh[w] = v;
     __syncthreads();
     return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ---- reductions folded into their producers ("last block done") --------------------------------
+// Every block of a producing kernel leaves its partial sum(s) in `partial`, then takes a ticket;
+// the block that draws the last ticket adds ALL partials in a fixed order (independent of which
+// block that is: the result is bit-reproducible) and writes the scalar.  That removes the two
+// one-block k_reduce launches per iteration from the stream (2 x (4.5 us + a kernel boundary) at
+// 148^3; more where it matters: the sharded loop, whose per-rank kernels are 8 x shorter).
+// Hand-off across XCDs (their L2s are not coherent, MI355X_MICROARCH.md "inter-workgroup
+// visibility", first row of the table of measured forms): the partial is an agent-scope store
+// (sc1, write-through), the storing lane waits for it (vmcnt(0)) before its agent-scope add to
+// the one unsharded counter, the block whose add returned the last ticket reads every partial
+// with agent-scope (sc1) loads after a workgroup barrier behind that add.
+// STAN_OPT_CG_FOLD_REDUCE = 0 restores the separate k_reduce launches (same order: same bits).
+__device__ __forceinline__ void st_agent(double *p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// sum_i partial[i*nv + j] over np blocks by one 256-thread block, fixed order; valid in thread 0
+__device__ __forceinline__ double sum_partials(const double *partial, int np, int nv, int j, double *sh) {
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int i = threadIdx.x;
+    for (; i + 7 * 256 < np; i += 8 * 256) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) a[q] += ld_agent(partial + (int64_t)(i + q * 256) * nv + j);
+    }
+    for (; i < np; i += 256) a[0] += ld_agent(partial + (int64_t)i * nv + j);
+    return block_sum(((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])), sh);
+}
+struct fold_args {
+    unsigned long long *counter;  // ticket counter (zero between kernels); nullptr: no fold
+    unsigned nblocks;             // tickets this launch hands out (its grid size)
+    int np;                       // partials to add (>= nblocks: earlier launches may have left some)
+    double *out;                  // [NV] results
+};
+// Thread 0 of every block calls this after storing its partials with st_agent(); true (in every
+// thread) for the block that arrived last.  `sh_last` is one int of LDS.
+__device__ __forceinline__ bool fold_arrive(const fold_args &f, int *sh_last) {
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial has left this CU
+        const unsigned long long t =
+            __hip_atomic_fetch_add(f.counter, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *sh_last = (t == (unsigned long long)f.nblocks - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    return *sh_last != 0;
+}
+template <int NV>
+__device__ __forceinline__ void fold_finish(const fold_args &f, const double *partial, double *sh) {
+    double r[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) r[j] = sum_partials(partial, f.np, NV, j, sh);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < NV; j++) f.out[j] = r[j];  // read by the NEXT kernel: a plain store will do
+        __hip_atomic_store(f.counter, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 __device__ __forceinline__ bool stopped(const int64_t *st, int64_t k) {
@@ -147,8 +209,9 @@ k_to_fx48(int64_t nslots, const double *vals, uint32_t *out, unsigned long long 
 // partial sums of b^.b^ (x0 = 0 => r0 = b^, merit0 = 0).
 __global__ void __launch_bounds__(VEC_T)
 k_init(int64_t n3, int64_t dof0, const int32_t *red, const double *F, const double *s,
-       double *bh, double *x0, double *r, double *p, double *partial) {
+       double *bh, double *x0, double *r, double *p, double *partial, fold_args fold) {
     __shared__ double sh[4];
+    __shared__ int sh_last;
     double acc = 0;
     const int64_t stride = (int64_t)gridDim.x * VEC_T;
     for (int64_t i = (int64_t)blockIdx.x * VEC_T + threadIdx.x; i < n3; i += stride) {
@@ -161,36 +224,18 @@ k_init(int64_t n3, int64_t dof0, const int32_t *red, const double *F, const doub
         acc += b * b;
     }
     const double t = block_sum(acc, sh);
-    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    if (threadIdx.x == 0) st_agent(partial + blockIdx.x, t);
+    if (fold.counter && fold_arrive(fold, &sh_last)) fold_finish<1>(fold, partial, sh);
 }
 
-// out[j] = sum_i partial[i*nv + j]: one 1024-thread block, four independent accumulators per
-// thread, fixed combination order (the 12.9 k SpMV partials of the 148^3 cube took 23 us with
-// 256 threads and one dependent chain)
-__global__ void __launch_bounds__(1024)
+// out[j] = sum_i partial[i*nv + j]: the unfolded form of the reduction (one 256-thread block, the
+// same summation order as fold_finish: both paths give the same bits)
+__global__ void __launch_bounds__(256)
 k_reduce(const double *partial, int np, int nv, double *out) {
-    __shared__ double sh[16];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __shared__ double sh[4];
     for (int j = 0; j < nv; j++) {
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        int i = threadIdx.x;
-        for (; i + 3 * 1024 < np; i += 4 * 1024) {
-            a0 += partial[(int64_t)i * nv + j];
-            a1 += partial[(int64_t)(i + 1024) * nv + j];
-            a2 += partial[(int64_t)(i + 2048) * nv + j];
-            a3 += partial[(int64_t)(i + 3072) * nv + j];
-        }
-        for (; i < np; i += 1024) a0 += partial[(int64_t)i * nv + j];
-        double v = wave_sum((a0 + a1) + (a2 + a3));
-        __syncthreads();
-        if (lane == 0) sh[w] = v;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double t = 0;
-#pragma unroll
-            for (int q = 0; q < 16; q++) t += sh[q];
-            out[j] = t;
-        }
+        const double t = sum_partials(partial, np, nv, j, sh);
+        if (threadIdx.x == 0) out[j] = t;
     }
 }
 
@@ -212,13 +257,16 @@ __global__ void k_init_scalars(double *sc, int64_t *st, double epsf) {
 // y = A x over BSELL-64.  One wavefront per slice, one lane per block row: every load of
 // the value stream is a contiguous 512-B (fp64) / 256-B (fp32) wave access; x is gathered
 // (24 B per block, L2 / Infinity-Cache resident: neighbouring rows share columns).
-// DOT: also the per-block partial of x_own . y  (p.Ap of the CG).
-// VAR selects tuning variants (STAN_OPT_SPMV_VARIANT, kept for A/B runs in one process):
-//   bit 0: non-temporal loads for the once-read matrix stream (keeps x in L2 / MALL)
-//   bit 1: XCD-contiguous slice mapping (blocks b, b+8, ... share an XCD: give each XCD a
-//          contiguous run of slices so that its L2 holds one window of x, not eight copies)
-//   bit 2: unroll the block loop by 4 instead of 2
-//   VAR 8: timing only -- reads the same bytes as 16-B (dwordx4) accesses; results are wrong
+// DOT = 1: also the per-block partial of x_own . y  (p.Ap of the CG); DOT = 2: the partials of
+// x_own . x_own and x_own . y (r.r and r.Ar of the single-reduction CG); the block that finishes
+// last adds the partials up (fold_args).
+// VAR selects the kernel variant.  The product library carries three:
+//   0   plain loads, identity workgroup mapping (reference point of the A/B runs)
+//   9   non-temporal loads for the once-read matrix stream (keeps x in L2 / MALL) + XCD-chunked
+//       workgroup mapping (below)                                   -- default for fp64 / fp32
+//   12  = 9 with the block loop unrolled by 4                       -- default for FIXED-48
+// A lab build (make lab: -DSTAN_LAB, build_lab/libstan_hip_lab.so, never shipped) adds the other
+// A/B variants of round 1 (1-8, 10, 11, 13; 8 is a timing-only kernel whose results are wrong).
 // NT must be a compile-time choice: with a run-time flag, `nt ? __builtin_nontemporal_load(p) : *p`
 // is two loads of one address that the optimiser merges into ONE plain load inside this helper,
 // before it is inlined anywhere -- the non-temporal hint never reached the ISA (no `nt` bit on any
@@ -261,14 +309,15 @@ __device__ __forceinline__ void load9(const VT *vp, double a[9]) {
     }
 }
 
-template <typename VT, bool DOT, int VAR>
+template <typename VT, int DOT, int VAR>
 __global__ void __launch_bounds__(256)
 k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
        const int32_t *__restrict__ cols, const VT *__restrict__ vals,
        const double *__restrict__ x, double *__restrict__ y, double *partial,
        const int64_t *st, int64_t kiter, const int32_t *__restrict__ slist, int32_t nlist,
-       int32_t poff) {
+       int32_t poff, fold_args fold) {
     __shared__ double sh[4];
+    __shared__ int sh_last;
     if (stopped(st, kiter)) return;
     constexpr bool NT = ((VAR & 1) != 0 && VAR < 8) || (VAR >= 9 && VAR != 13);  // 13 = 9 without the hint
     constexpr bool XCD = (VAR & 2) != 0 && VAR < 8;
@@ -297,7 +346,8 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
         const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
         const int32_t *cp = cols + (int64_t)k0 * 64 + lane;
         const VT *vp = vals + (int64_t)k0 * vstream<VT>::STRIDE + lane;
-        if (VAR == 8 && !vstream<VT>::FX) {  // timing only
+#ifdef STAN_LAB
+        if (VAR == 8 && !vstream<VT>::FX) {  // timing only: 16-B accesses, results are wrong
             typedef VT v2 __attribute__((ext_vector_type(2)));
             const v2 *vq = (const v2 *)(vals + (int64_t)k0 * 9 * 64) + lane;
             for (int32_t k = k0; k + 1 < k1; k += 2) {
@@ -313,7 +363,9 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
                 cp += 128;
                 vq += 9 * 64;
             }
-        } else {
+        } else
+#endif
+        {
 #pragma unroll UNR
             for (int32_t k = k0; k < k1; k++) {
                 const int64_t c = ld_stream<NT>(cp);
@@ -339,10 +391,21 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
         }
     }
     if (DOT) {
-        double d = 0;
-        if (slice < nslices && row < nloc) d = y0 * x[3 * row] + y1 * x[3 * row + 1] + y2 * x[3 * row + 2];
+        double d = 0, e = 0;
+        if (slice < nslices && row < nloc) {
+            const double x0 = x[3 * row], x1 = x[3 * row + 1], x2 = x[3 * row + 2];
+            d = y0 * x0 + y1 * x1 + y2 * x2;
+            if (DOT == 2) e = x0 * x0 + x1 * x1 + x2 * x2;
+        }
         const double t = block_sum(d, sh);
-        if (threadIdx.x == 0) partial[blockIdx.x + poff] = t;
+        if (DOT == 2) {
+            const double u = block_sum(e, sh);
+            if (threadIdx.x == 0) {
+                st_agent(partial + 2 * (int64_t)(blockIdx.x + poff), u);
+                st_agent(partial + 2 * (int64_t)(blockIdx.x + poff) + 1, t);
+            }
+        } else if (threadIdx.x == 0) st_agent(partial + blockIdx.x + poff, t);
+        if (fold.counter && fold_arrive(fold, &sh_last)) fold_finish<(DOT == 2 ? 2 : 1)>(fold, partial, sh);
     }
 }
 
@@ -355,8 +418,9 @@ k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
         const int32_t *__restrict__ cols, const VT *__restrict__ vals,
         const double *__restrict__ x, const double *__restrict__ x2, double *__restrict__ y,
         double *__restrict__ y2, double *partial, const int64_t *st, int64_t kiter,
-        const int32_t *__restrict__ slist, int32_t nlist, int32_t poff) {
+        const int32_t *__restrict__ slist, int32_t nlist, int32_t poff, fold_args fold) {
     __shared__ double sh[4];
+    __shared__ int sh_last;
     if (stopped(st, kiter)) return;
     const int lane = threadIdx.x & 63;
     int64_t bid = blockIdx.x;
@@ -408,7 +472,8 @@ k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
     double d = 0;
     if (slice < nslices && row < nloc) d = y0 * x[3 * row] + y1 * x[3 * row + 1] + yy2 * x[3 * row + 2];
     const double t = block_sum(d, sh);
-    if (threadIdx.x == 0) partial[blockIdx.x + poff] = t;
+    if (threadIdx.x == 0) st_agent(partial + blockIdx.x + poff, t);
+    if (fold.counter && fold_arrive(fold, &sh_last)) fold_finish<1>(fold, partial, sh);
 }
 
 // ---- CG step kernels ----------------------------------------------------------------------------
@@ -429,10 +494,12 @@ struct step_args {
     int merit;            // 0: the merit-function stop is off, skip its sum (and the b^ read)
     int refresh;          // 0: r -= a v; 1: only cx is formed here (r from a second SpMV);
                           // 2: fused refresh, r = b^ - (w + a v) with w = A^ x from the same pass
+    fold_args fold;       // r.r and the merit sum are added up by the last block (-> sc[S_R2NEW..])
 };
 
 __global__ void __launch_bounds__(VEC_T) k_step(step_args a) {
     __shared__ double sh[4];
+    __shared__ int sh_last;
     if (stopped(a.st, a.k)) return;
     const double vmv = a.sc[S_VMV];
     const double rho = a.sc[S_RHO0 + (a.k & 1)];
@@ -483,17 +550,19 @@ __global__ void __launch_bounds__(VEC_T) k_step(step_args a) {
         const double t0 = block_sum(s_r2, sh);
         const double t1 = block_sum(s_mf, sh);
         if (threadIdx.x == 0) {
-            a.partial[2 * blockIdx.x] = t0;
-            a.partial[2 * blockIdx.x + 1] = t1;
+            st_agent(a.partial + 2 * blockIdx.x, t0);
+            st_agent(a.partial + 2 * blockIdx.x + 1, t1);
         }
+        if (a.fold.counter && fold_arrive(a.fold, &sh_last)) fold_finish<2>(a.fold, a.partial, sh);
     }
 }
 
 // refresh iterations: r = b^ - A^ cx, merit = sum (mv - 2 b^) cx
 __global__ void __launch_bounds__(VEC_T)
 k_refresh(int64_t n3, int64_t k, const int64_t *st, const double *bh, const double *mv,
-          const double *cx, double *r, double *partial) {
+          const double *cx, double *r, double *partial, fold_args fold) {
     __shared__ double sh[4];
+    __shared__ int sh_last;
     if (st[T_ITER_A] < k || st[T_ITER_B] <= k) return;
     double s_r2 = 0, s_mf = 0;
     const int64_t stride = (int64_t)gridDim.x * VEC_T;
@@ -507,9 +576,10 @@ k_refresh(int64_t n3, int64_t k, const int64_t *st, const double *bh, const doub
     const double t0 = block_sum(s_r2, sh);
     const double t1 = block_sum(s_mf, sh);
     if (threadIdx.x == 0) {
-        partial[2 * blockIdx.x] = t0;
-        partial[2 * blockIdx.x + 1] = t1;
+        st_agent(partial + 2 * blockIdx.x, t0);
+        st_agent(partial + 2 * blockIdx.x + 1, t1);
     }
+    if (fold.counter && fold_arrive(fold, &sh_last)) fold_finish<2>(fold, partial, sh);
 }
 
 // decisions of the iteration + p = r + beta p
@@ -551,6 +621,99 @@ k_update(int64_t n3, int64_t k, double *sc, int64_t *st, double epsf, int64_t ma
 #else
         p[i] = r[i] + beta * p[i];
 #endif
+}
+
+// ---- single-reduction CG (Chronopoulos-Gear), STAN_OPT_CG_SINGLE_REDUCE --------------------------
+// Same iterates as the classic loop in exact arithmetic, ONE reduction point per iteration:
+//   w_k = A r_k,  gamma_k = r_k.r_k,  delta_k = r_k.w_k          (the SpMV, both sums in its epilogue)
+//   beta_k = gamma_k / gamma_{k-1},   p_k.A p_k = delta_k - beta_k gamma_k / alpha_{k-1},
+//   alpha_k = gamma_k / p_k.A p_k
+//   p = r + beta p,  s = w + beta s (= A p),  x' = x + alpha p,  r' = r - alpha s
+// Per iteration: this kernel + one SpMV (+ ONE all-reduce of 3 doubles when sharded) instead of
+// SpMV, all-reduce, step, all-reduce, update.  Iteration k's kernel first takes the decisions of
+// iteration k-1 (its residual norm and merit value arrived with the last reduction), with the
+// codes and the "previous point on type 7" rule of the classic loop.  Rounding differs from the
+// classic recurrences (alpha comes from a three-term formula), so iteration counts may differ by
+// a few: the default stays the classic loop, which is the oracle's.
+struct sr_args {
+    int64_t n3, k;
+    double *sc;
+    int64_t *st;
+    double epsf;
+    int64_t maxits, its_before_restart;
+    int merit_stop;
+    int refresh;          // 1: r' comes from b^ - A x' (k_refresh), only p, s, x' are formed here
+    const double *xcur;
+    double *xnext;
+    double *r, *p, *s;
+    const double *w, *bh;
+    double *partial;      // [blocks] merit partials
+    fold_args fold;       // -> sc[S_SR_MERIT]
+};
+
+__global__ void __launch_bounds__(VEC_T) k_vec_sr(sr_args a) {
+    __shared__ double sh[4];
+    __shared__ int sh_last;
+    const int64_t k = a.k;
+    if (a.st[T_ITER_A] < k) return;   // stopped by an earlier iteration's decisions
+    const double gamma = a.sc[S_SR_GAMMA], delta = a.sc[S_SR_DELTA], merit = a.sc[S_SR_MERIT];
+    const double bnorm = a.sc[S_BNORM];
+    int type = 0;
+    int64_t its = k - 1, xsel = (k - 1) & 1;
+    if (!isfinite(gamma)) type = -4;
+    else if (k > 1) {   // decisions of iteration k-1 (x_{k-1} lives in buffer (k-1)&1)
+        if (sqrt(gamma) <= a.epsf * bnorm) type = 1;
+        else if (k - 1 >= a.maxits && a.maxits > 0) type = 5;
+        else if (a.merit_stop && merit >= a.sc[S_PMF0 + ((k - 1) & 1)]) { type = 7; xsel = (k - 2) & 1; }
+    }
+    double alpha = 0, beta = 0;
+    if (!type) {
+        const bool restart = k == 1 || ((k - 1) % a.its_before_restart) == 0;
+        double pap = delta;
+        if (!restart) {
+            beta = gamma / a.sc[S_SR_GP0 + ((k - 1) & 1)];
+            pap = delta - beta * gamma / a.sc[S_SR_AP0 + ((k - 1) & 1)];
+        }
+        if (!isfinite(pap) || !isfinite(beta)) type = -4;
+        else if (pap <= 0) type = -5;
+        else { alpha = gamma / pap; if (!isfinite(alpha)) type = -4; }
+        if (type) { its = k; xsel = (k - 1) & 1; }   // as k_step: the previous point, this iteration's number
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.sc[S_R2OUT] = gamma;
+        if (type) {
+            a.st[T_TYPE] = type;
+            a.st[T_ITERS] = its;
+            a.st[T_XSEL] = xsel;
+            a.st[T_ITER_A] = k - 1;   // this iteration's product and everything later return at once
+        } else {
+            a.sc[S_SR_GP0 + (k & 1)] = gamma;
+            a.sc[S_SR_AP0 + (k & 1)] = alpha;
+            a.sc[S_PMF0 + (k & 1)] = merit;
+        }
+    }
+    if (type) return;
+    double s_mf = 0;
+    const int64_t stride = (int64_t)gridDim.x * VEC_T;
+    for (int64_t i = (int64_t)blockIdx.x * VEC_T + threadIdx.x; i < a.n3; i += stride) {
+        const double ri = a.r[i];
+        const double pi = ri + beta * a.p[i];
+        const double si = __builtin_nontemporal_load(a.w + i) + beta * a.s[i];
+        const double cx = __builtin_nontemporal_load(a.xcur + i) + alpha * pi;
+        a.p[i] = pi;
+        a.s[i] = si;
+        __builtin_nontemporal_store(cx, a.xnext + i);
+        if (!a.refresh) {
+            const double cr = ri - alpha * si;
+            a.r[i] = cr;   // gathered by the product that follows: stays cacheable
+            if (a.merit_stop) s_mf -= (cr + a.bh[i]) * cx;
+        }
+    }
+    if (!a.refresh) {
+        const double t = block_sum(s_mf, sh);
+        if (threadIdx.x == 0) st_agent(a.partial + blockIdx.x, t);
+        if (a.fold.counter && fold_arrive(a.fold, &sh_last)) fold_finish<1>(a.fold, a.partial, sh);
+    }
 }
 
 // U[d - red[d]] = s_d * x^_d on free DOFs (SolverFunctions.cs:305 lincgresults + un-scaling)
@@ -622,22 +785,27 @@ int alloc(stan_ctx *ctx, dev_bufs &b, T **p, size_t n) {
 }
 
 // which: 0 = all slices, 1 = interior list, 2 = boundary list (partials offset by the
-// interior launch's block count).  Returns the number of partials this launch writes.
-template <typename VT, bool DOT>
+// interior launch's block count).  Returns the number of partial slots this launch writes.
+// `fold`: counter/out of the folded reduction (counter == nullptr: partials only); nblocks and np
+// are filled in here (np = this launch's slots + poff: the boundary launch of a split product
+// also adds up what the interior launch left).
+template <typename VT, int DOT>
 unsigned launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double *x, double *y,
                      double *partial, const int64_t *st, int64_t k, int which = 0,
-                     hipStream_t stream = nullptr) {
+                     hipStream_t stream = nullptr, fold_args fold = fold_args{nullptr, 0, 0, nullptr}) {
     if (!stream) stream = ctx->stream;
     const int32_t *slist = which == 1 ? K->d_sl_int : which == 2 ? K->d_sl_bnd : nullptr;
     const int32_t nlist = which == 1 ? K->n_sl_int : which == 2 ? K->n_sl_bnd : K->nslices;
     const int32_t poff = which == 2 ? (int32_t)nblk(K->n_sl_int, 4) : 0;
     const unsigned grid = nblk(nlist, 4);
     if (grid == 0) return 0;
+    fold.nblocks = grid;
+    fold.np = (int)grid + poff;
 #define SPMV_CASE(V)                                                                          \
     case V:                                                                                   \
         hipLaunchKernelGGL((k_spmv<VT, DOT, V>), dim3(grid), dim3(256), 0, stream, K->nslices, \
                            K->nloc, K->d_slot_ptr, K->d_cols, vals, x, y, partial, st, k,     \
-                           slist, nlist, poff);                                               \
+                           slist, nlist, poff, fold);                                         \
         break;
     // auto (-1): non-temporal matrix stream + XCD-chunked workgroup mapping (variant 9), with the
     // loop unrolled by 4 for the FIXED-48 stream, whose iterations carry 21 % fewer bytes in
@@ -646,8 +814,11 @@ unsigned launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double
     // fp32 0.636 / 0.583 / 0.580.
     const int variant = ctx->spmv_variant >= 0 ? ctx->spmv_variant : vstream<VT>::FX ? 12 : 9;
     switch (variant) {
+        SPMV_CASE(9) SPMV_CASE(12)
+#ifdef STAN_LAB
         SPMV_CASE(1) SPMV_CASE(2) SPMV_CASE(3) SPMV_CASE(4) SPMV_CASE(5) SPMV_CASE(6) SPMV_CASE(7)
-        SPMV_CASE(8) SPMV_CASE(9) SPMV_CASE(10) SPMV_CASE(11) SPMV_CASE(12) SPMV_CASE(13)
+        SPMV_CASE(8) SPMV_CASE(10) SPMV_CASE(11) SPMV_CASE(13)
+#endif
         default:
         SPMV_CASE(0)
     }
@@ -658,15 +829,29 @@ unsigned launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double
 template <typename VT>
 unsigned launch_spmv2(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double *x, const double *x2,
                       double *y, double *y2, double *partial, const int64_t *st, int64_t k, int which,
-                      hipStream_t stream) {
+                      hipStream_t stream, fold_args fold) {
     const int32_t *slist = which == 1 ? K->d_sl_int : which == 2 ? K->d_sl_bnd : nullptr;
     const int32_t nlist = which == 1 ? K->n_sl_int : which == 2 ? K->n_sl_bnd : K->nslices;
     const int32_t poff = which == 2 ? (int32_t)nblk(K->n_sl_int, 4) : 0;
     const unsigned grid = nblk(nlist, 4);
     if (grid == 0) return 0;
+    fold.nblocks = grid;
+    fold.np = (int)grid + poff;
     hipLaunchKernelGGL((k_spmv2<VT>), dim3(grid), dim3(256), 0, stream, K->nslices, K->nloc, K->d_slot_ptr,
-                       K->d_cols, vals, x, x2, y, y2, partial, st, k, slist, nlist, poff);
+                       K->d_cols, vals, x, x2, y, y2, partial, st, k, slist, nlist, poff, fold);
     return grid;
+}
+
+// value-stream dispatch of one product (DOT as in k_spmv)
+template <int DOT>
+unsigned launch_spmv_any(stan_ctx *ctx, stan_matrix *K, int stream_kind, const double *x, double *y,
+                         double *partial, const int64_t *st, int64_t k, int which, hipStream_t s,
+                         fold_args fold) {
+    if (stream_kind == STAN_PREC_MIXED)
+        return launch_spmv<float, DOT>(ctx, K, K->d_vals32, x, y, partial, st, k, which, s, fold);
+    if (stream_kind == STAN_PREC_FIXED48)
+        return launch_spmv<uint32_t, DOT>(ctx, K, K->d_vals48, x, y, partial, st, k, which, s, fold);
+    return launch_spmv<double, DOT>(ctx, K, K->d_vals, x, y, partial, st, k, which, s, fold);
 }
 
 }  // namespace
@@ -687,6 +872,11 @@ static int ensure_scaled(stan_ctx *ctx, stan_matrix *K) {
                            K->nslices, K->d_slot_ptr, K->d_cols, K->d_vals, K->d_scale, 0);
     HIPCHK(ctx, hipGetLastError());
     K->scaled = true;
+    // copies of the value stream made before the scaling (stan_hip_spmv_bench on a fresh matrix)
+    // hold the unscaled K: a later solve must not iterate on them
+    if (K->d_vals32) { stan_dfree(ctx, K->d_vals32); K->d_vals32 = nullptr; }
+    if (K->d_vals48) { stan_dfree(ctx, K->d_vals48); K->d_vals48 = nullptr; }
+    K->fx48_refused = false;
     return STAN_OK;
 }
 
@@ -754,40 +944,63 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         hipEventRecord(ev0, st_);
     }
     STANCHK(ensure_scaled(ctx, K));
-    const bool mixed = precision_mode == STAN_PREC_MIXED;
-    if (mixed) STANCHK(stan_matrix_make_fp32(ctx, K));
+    if (precision_mode == STAN_PREC_MIXED) STANCHK(stan_matrix_make_fp32(ctx, K));
     if (precision_mode == STAN_PREC_FIXED48) STANCHK(stan_matrix_make_fx48(ctx, K));
-    const bool fx = precision_mode == STAN_PREC_FIXED48 && K->d_vals48 != nullptr;
+    // the stream the products really read (FIXED-48 falls back to fp64 when K is not SPD-scalable)
+    const int vs = precision_mode == STAN_PREC_FIXED48 ? (K->d_vals48 ? STAN_PREC_FIXED48 : STAN_PREC_FP64)
+                                                       : precision_mode;
     const bool dist = ctx->comm != nullptr || ctx->nranks > 1;  // collectives in the loop
+    const bool sr = ctx->cg_single_reduce;
+    const bool foldr = ctx->cg_fold_reduce;
 
     const int64_t n3 = 3 * K->nloc;
     const int64_t npad = (int64_t)K->nslices * 64;
     const int64_t ng = 3 * ((npad > K->nloc + K->nhalo ? npad : K->nloc + K->nhalo));
     const int64_t dof0 = 3 * K->r0;
     dev_bufs bufs;
-    double *xb[2], *p, *r, *v, *w, *bh, *partial, *sc;
+    double *xb[2], *p, *r, *v, *w, *bh, *partial, *sc, *sv = nullptr;
     int64_t *stt;
+    unsigned long long *tick;
     STANCHK(alloc(ctx, bufs, &xb[0], (size_t)ng));
     STANCHK(alloc(ctx, bufs, &xb[1], (size_t)ng));
     STANCHK(alloc(ctx, bufs, &p, (size_t)ng));
-    STANCHK(alloc(ctx, bufs, &r, (size_t)n3));
+    STANCHK(alloc(ctx, bufs, &r, (size_t)(sr ? ng : n3)));   // the single-reduction loop multiplies r
     STANCHK(alloc(ctx, bufs, &v, (size_t)n3));
     STANCHK(alloc(ctx, bufs, &w, (size_t)n3));
     STANCHK(alloc(ctx, bufs, &bh, (size_t)n3));
+    if (sr) STANCHK(alloc(ctx, bufs, &sv, (size_t)n3));
     const unsigned spmv_blocks = nblk(K->nslices, 4);
     const size_t npart = 2 * (size_t)(spmv_blocks > VEC_BLOCKS ? spmv_blocks : VEC_BLOCKS) + 16;
     STANCHK(alloc(ctx, bufs, &partial, npart));
     STANCHK(alloc(ctx, bufs, &sc, (size_t)S_NSCAL));
     STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
+    STANCHK(alloc(ctx, bufs, &tick, (size_t)32));   // two ticket counters, a 128-B line each
     HIPCHK(ctx, hipMemsetAsync(sc, 0, S_NSCAL * 8, st_));
+    HIPCHK(ctx, hipMemsetAsync(tick, 0, 32 * 8, st_));
     HIPCHK(ctx, hipMemsetAsync(xb[0], 0, (size_t)ng * 8, st_));
     HIPCHK(ctx, hipMemsetAsync(xb[1], 0, (size_t)ng * 8, st_));
     HIPCHK(ctx, hipMemsetAsync(p, 0, (size_t)ng * 8, st_));
+    if (sr) {
+        HIPCHK(ctx, hipMemsetAsync(r, 0, (size_t)ng * 8, st_));
+        HIPCHK(ctx, hipMemsetAsync(sv, 0, (size_t)n3 * 8, st_));
+    }
+    // folded reductions: counter A serves the products, counter B the vector kernels
+    auto fold_to = [&](int which, double *out) {
+        return fold_args{foldr ? tick + 16 * which : nullptr, 0, 0, out};
+    };
+    auto reduce_if_unfolded = [&](int np, int nv, double *out) {
+        if (!foldr && np > 0)
+            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st_, partial, np, nv, out);
+    };
 
     const unsigned vg = vec_grid(n3);
-    hipLaunchKernelGGL(k_init, dim3(vg), dim3(VEC_T), 0, st_, n3, dof0, K->d_red, d_F, K->d_scale,
-                       bh, xb[0], r, p, partial);
-    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st_, partial, (int)vg, 1, sc + S_VMV);
+    {
+        fold_args f = fold_to(1, sc + S_VMV);
+        f.nblocks = vg; f.np = (int)vg;
+        hipLaunchKernelGGL(k_init, dim3(vg), dim3(VEC_T), 0, st_, n3, dof0, K->d_red, d_F, K->d_scale,
+                           bh, xb[0], r, p, partial, f);
+        reduce_if_unfolded((int)vg, 1, sc + S_VMV);
+    }
     if (dist) STANCHK(stan_comm_allreduce_sum_f64(ctx, sc + S_VMV, 1));
     hipLaunchKernelGGL(k_init_scalars, dim3(1), dim3(1), 0, st_, sc, stt, eps_f);
     HIPCHK(ctx, hipGetLastError());
@@ -808,69 +1021,92 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     }
     std::vector<hipEvent_t> spmv_ev, spmv2_ev;
     std::vector<int64_t> spmv_k, spmv2_k;  // iteration of each timed launch (see the profile below)
-    unsigned spmv_parts = 0;
-    // y = A^ x (x gets its halo filled first when sharded); returns 0 or an error code
-    auto spmv = [&](double *x, double *y, bool dot, int64_t k) -> int {
+    int64_t n_launch = 0, n_coll = 0;      // kernels / collectives enqueued by the loop (profile)
+    // y = A^ x (x gets its halo filled first when sharded) with `dot` sums (k_spmv's DOT) reduced
+    // into out[0..dot): folded into the last launch of the product, or by k_reduce.
+    auto spmv = [&](double *x, double *y, int dot, double *out, int64_t k) -> int {
         if (ctx->profiling) {
             hipEvent_t a = events.make(), b = events.make();
             hipEventRecord(a, st_);
             spmv_ev.push_back(a); spmv_ev.push_back(b);
             spmv_k.push_back(k);
         }
-        auto go = [&](int which, hipStream_t s) -> unsigned {
-            if (mixed)
-                return dot ? launch_spmv<float, true>(ctx, K, K->d_vals32, x, y, partial, stt, k, which, s)
-                           : launch_spmv<float, false>(ctx, K, K->d_vals32, x, y, partial, stt, k, which, s);
-            if (fx)
-                return dot ? launch_spmv<uint32_t, true>(ctx, K, K->d_vals48, x, y, partial, stt, k, which, s)
-                           : launch_spmv<uint32_t, false>(ctx, K, K->d_vals48, x, y, partial, stt, k, which, s);
-            return dot ? launch_spmv<double, true>(ctx, K, K->d_vals, x, y, partial, stt, k, which, s)
-                       : launch_spmv<double, false>(ctx, K, K->d_vals, x, y, partial, stt, k, which, s);
+        auto go = [&](int which, hipStream_t s, bool last) -> unsigned {
+            const fold_args f = (dot && last) ? fold_to(0, out) : fold_args{nullptr, 0, 0, nullptr};
+            n_launch++;
+            return dot == 2 ? launch_spmv_any<2>(ctx, K, vs, x, y, partial, stt, k, which, s, f)
+                 : dot == 1 ? launch_spmv_any<1>(ctx, K, vs, x, y, partial, stt, k, which, s, f)
+                            : launch_spmv_any<0>(ctx, K, vs, x, y, partial, stt, k, which, s, f);
         };
+        unsigned parts = 0;
+        bool folded = foldr;
         if (split) {
             HIPCHK(ctx, hipEventRecord(ctx->ev_a, st_));
             HIPCHK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_a, 0));
-            spmv_parts = go(1, ctx->side);
+            parts = go(1, ctx->side, false);
             HIPCHK(ctx, hipEventRecord(ctx->ev_b, ctx->side));
             STANCHK(stan_comm_halo_exchange(ctx, K, x));
             HIPCHK(ctx, hipStreamWaitEvent(st_, ctx->ev_b, 0));
-            spmv_parts += go(2, st_);
+            const unsigned pb = go(2, st_, true);   // adds up the interior launch's partials too
+            if (pb == 0) folded = false;            // no boundary slices on this rank: nobody folded
+            parts += pb;
         } else {
             if (dist) STANCHK(stan_comm_halo_exchange(ctx, K, x));
-            spmv_parts = go(0, st_);
+            parts = go(0, st_, true);
+            if (parts == 0) folded = false;
+        }
+        if (dot && !folded) {
+            if (parts > 0) { hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st_, partial, (int)parts, dot, out); n_launch++; }
+            else HIPCHK(ctx, hipMemsetAsync(out, 0, 8 * dot, st_));   // a rank that owns no rows
         }
         if (ctx->profiling) hipEventRecord(spmv_ev.back(), st_);
         return STAN_OK;
     };
 
-    // v = A^ x and w = A^ x2 in one matrix pass (fused residual refresh)
-    auto spmv2 = [&](double *x, double *x2, int64_t k) -> int {
+    // v = A^ x and w = A^ x2 in one matrix pass (fused residual refresh), x.v -> out
+    auto spmv2 = [&](double *x, double *x2, double *out, int64_t k) -> int {
         if (ctx->profiling) {
             hipEvent_t a = events.make(), b = events.make();
             hipEventRecord(a, st_);
             spmv2_ev.push_back(a); spmv2_ev.push_back(b);
             spmv2_k.push_back(k);
         }
-        auto go = [&](int which, hipStream_t s) -> unsigned {
-            if (fx) return launch_spmv2<uint32_t>(ctx, K, K->d_vals48, x, x2, v, w, partial, stt, k, which, s);
-            return mixed ? launch_spmv2<float>(ctx, K, K->d_vals32, x, x2, v, w, partial, stt, k, which, s)
-                         : launch_spmv2<double>(ctx, K, K->d_vals, x, x2, v, w, partial, stt, k, which, s);
+        auto go = [&](int which, hipStream_t s, bool last) -> unsigned {
+            const fold_args f = last ? fold_to(0, out) : fold_args{nullptr, 0, 0, nullptr};
+            n_launch++;
+            if (vs == STAN_PREC_FIXED48) return launch_spmv2<uint32_t>(ctx, K, K->d_vals48, x, x2, v, w, partial, stt, k, which, s, f);
+            return vs == STAN_PREC_MIXED ? launch_spmv2<float>(ctx, K, K->d_vals32, x, x2, v, w, partial, stt, k, which, s, f)
+                                         : launch_spmv2<double>(ctx, K, K->d_vals, x, x2, v, w, partial, stt, k, which, s, f);
         };
+        unsigned parts = 0;
+        bool folded = foldr;
         if (split) {
             HIPCHK(ctx, hipEventRecord(ctx->ev_a, st_));
             HIPCHK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_a, 0));
-            spmv_parts = go(1, ctx->side);
+            parts = go(1, ctx->side, false);
             HIPCHK(ctx, hipEventRecord(ctx->ev_b, ctx->side));
             STANCHK(stan_comm_halo_exchange(ctx, K, x));
             STANCHK(stan_comm_halo_exchange(ctx, K, x2));
             HIPCHK(ctx, hipStreamWaitEvent(st_, ctx->ev_b, 0));
-            spmv_parts += go(2, st_);
+            const unsigned pb = go(2, st_, true);
+            if (pb == 0) folded = false;
+            parts += pb;
         } else {
             if (dist) { STANCHK(stan_comm_halo_exchange(ctx, K, x)); STANCHK(stan_comm_halo_exchange(ctx, K, x2)); }
-            spmv_parts = go(0, st_);
+            parts = go(0, st_, true);
+            if (parts == 0) folded = false;
+        }
+        if (!folded) {
+            if (parts > 0) { hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st_, partial, (int)parts, 1, out); n_launch++; }
+            else HIPCHK(ctx, hipMemsetAsync(out, 0, 8, st_));
         }
         if (ctx->profiling) hipEventRecord(spmv2_ev.back(), st_);
         return STAN_OK;
+    };
+    auto vec_fold = [&](double *out) {
+        fold_args f = fold_to(1, out);
+        f.nblocks = vg; f.np = (int)vg;
+        return f;
     };
 
     int64_t *h_st = ctx->h_status + SS_H_CG_STATUS;  // pinned
@@ -883,34 +1119,64 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     HIPCHK(ctx, hipMemcpyAsync(h_st, stt, T_NSTAT * 8, hipMemcpyDeviceToHost, st_));
     HIPCHK(ctx, hipStreamSynchronize(st_));
     if (h_st[T_ITER_A] == 0) done = true;
+    if (sr && !done) {   // w_0 = A r_0 with gamma_0, delta_0 (merit_0 = 0 sits in the zeroed scalars)
+        rc = spmv(r, w, 2, sc + S_SR_GAMMA, 0);
+        if (rc == STAN_OK && dist) { rc = stan_comm_allreduce_sum_f64(ctx, sc + S_SR_GAMMA, 3); n_coll++; }
+    }
     while (!done && rc == STAN_OK) {
         // enqueue one chunk of iterations
         for (int c = 0; c < CHUNK && k < hard_cap; c++, k++) {
             const bool refresh = ctx->cg_rupdate > 0 && (k % ctx->cg_rupdate) == 0;
+            if (sr) {
+                sr_args a;
+                a.n3 = n3; a.k = k; a.sc = sc; a.st = stt; a.epsf = eps_f; a.maxits = max_its;
+                a.its_before_restart = its_before_restart; a.merit_stop = ctx->cg_merit_stop ? 1 : 0;
+                a.refresh = refresh ? 1 : 0;
+                a.xcur = xb[(k - 1) & 1]; a.xnext = xb[k & 1];
+                a.r = r; a.p = p; a.s = sv; a.w = w; a.bh = bh; a.partial = partial;
+                a.fold = vec_fold(sc + S_SR_MERIT);
+                hipLaunchKernelGGL(k_vec_sr, dim3(vg), dim3(VEC_T), 0, st_, a);
+                n_launch++;
+                if (!refresh) reduce_if_unfolded((int)vg, 1, sc + S_SR_MERIT);
+                else {   // r' = b^ - A^ x' (ALGLIB's periodic residual recomputation), then as usual
+                    rc = spmv(xb[k & 1], v, 0, nullptr, k);
+                    if (rc) break;
+                    hipLaunchKernelGGL(k_refresh, dim3(vg), dim3(VEC_T), 0, st_, n3, k, (const int64_t *)stt,
+                                       bh, v, xb[k & 1], r, partial, vec_fold(sc + S_SR_DELTA));
+                    n_launch++;
+                    reduce_if_unfolded((int)vg, 2, sc + S_SR_DELTA);   // [r.r (rewritten below), merit]
+                }
+                rc = spmv(r, w, 2, sc + S_SR_GAMMA, k);
+                if (rc) break;
+                if (dist) { rc = stan_comm_allreduce_sum_f64(ctx, sc + S_SR_GAMMA, 3); n_coll++; if (rc) break; }
+                continue;
+            }
             const bool fused = refresh && ctx->cg_fused_refresh;
-            rc = fused ? spmv2(p, xb[(k - 1) & 1], k) : spmv(p, v, true, k);
+            rc = fused ? spmv2(p, xb[(k - 1) & 1], sc + S_VMV, k) : spmv(p, v, 1, sc + S_VMV, k);
             if (rc) break;
-            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st_, partial, (int)spmv_parts, 1,
-                               sc + S_VMV);
-            if (dist) { rc = stan_comm_allreduce_sum_f64(ctx, sc + S_VMV, 1); if (rc) break; }
+            if (dist) { rc = stan_comm_allreduce_sum_f64(ctx, sc + S_VMV, 1); n_coll++; if (rc) break; }
             step_args a;
             a.n3 = n3; a.k = k; a.sc = sc; a.st = stt;
             a.xcur = xb[(k - 1) & 1]; a.xnext = xb[k & 1];
             a.r = r; a.p = p; a.v = v; a.w = w; a.bh = bh; a.partial = partial;
             a.refresh = refresh ? (fused ? 2 : 1) : 0;
             a.merit = ctx->cg_merit_stop ? 1 : 0;
+            a.fold = vec_fold(sc + S_R2NEW);
             hipLaunchKernelGGL(k_step, dim3(vg), dim3(VEC_T), 0, st_, a);
+            n_launch++;
             if (a.refresh == 1) {
                 // a -5/-4 stop of this iteration is caught by k_refresh/k_update (ITER_B <= k)
-                rc = spmv(xb[k & 1], v, false, k);
+                rc = spmv(xb[k & 1], v, 0, nullptr, k);
                 if (rc) break;
                 hipLaunchKernelGGL(k_refresh, dim3(vg), dim3(VEC_T), 0, st_, n3, k,
-                                   (const int64_t *)stt, bh, v, xb[k & 1], r, partial);
+                                   (const int64_t *)stt, bh, v, xb[k & 1], r, partial, vec_fold(sc + S_R2NEW));
+                n_launch++;
             }
-            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st_, partial, (int)vg, 2, sc + S_R2NEW);
-            if (dist) { rc = stan_comm_allreduce_sum_f64(ctx, sc + S_R2NEW, 2); if (rc) break; }
+            if (!foldr) { reduce_if_unfolded((int)vg, 2, sc + S_R2NEW); n_launch++; }
+            if (dist) { rc = stan_comm_allreduce_sum_f64(ctx, sc + S_R2NEW, 2); n_coll++; if (rc) break; }
             hipLaunchKernelGGL(k_update, dim3(vg), dim3(VEC_T), 0, st_, n3, k, sc, stt, eps_f,
                                (int64_t)max_its, its_before_restart, ctx->cg_merit_stop ? 1 : 0, r, p);
+            n_launch++;
         }
         if (rc) break;
         // poll: read the status of the PREVIOUS chunk while this one runs
@@ -930,7 +1196,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     if (e != hipSuccess) { ctx->err = std::string("cg: ") + hipGetErrorString(e); return STAN_E_HIP; }
     HIPCHK(ctx, hipMemcpyAsync(h_st, stt, T_NSTAT * 8, hipMemcpyDeviceToHost, st_));
     double *h_sc = (double *)(ctx->h_status + SS_H_CG_SCALARS);
-    HIPCHK(ctx, hipMemcpyAsync(h_sc, sc, S_NSCAL * 8, hipMemcpyDeviceToHost, st_));
+    HIPCHK(ctx, hipMemcpyAsync(h_sc, sc, 16 * 8, hipMemcpyDeviceToHost, st_));
     HIPCHK(ctx, hipStreamSynchronize(st_));
     int type = (int)h_st[T_TYPE];
     int64_t its = h_st[T_ITERS];
@@ -988,10 +1254,13 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         ctx->prof.spmv2_launches = nwork2;
         ctx->prof.iterations = (int32_t)its;
         ctx->prof.termination_type = type;
-        const int64_t blk_bytes = fx ? 60 : mixed ? 40 : 76;
+        const int64_t blk_bytes = vs == STAN_PREC_FIXED48 ? 60 : vs == STAN_PREC_MIXED ? 40 : 76;
         ctx->prof.spmv_bytes = K->nblocks * blk_bytes + 3 * K->nloc * 16 + K->nloc * 4;
-        ctx->prof.value_stream = fx ? STAN_PREC_FIXED48 : mixed ? STAN_PREC_MIXED : STAN_PREC_FP64;
+        ctx->prof.value_stream = vs;
         ctx->prof.cg_iteration_vector_bytes = 3 * K->nloc * 8 * 10;
+        ctx->prof.loop_kernel_launches = n_launch;
+        ctx->prof.loop_collectives = n_coll;
+        ctx->prof.loop_iterations_enqueued = k - 1;
     }
     return STAN_OK;
 }
@@ -1013,7 +1282,7 @@ int stan_spmv_reduced(stan_ctx *ctx, stan_matrix *K, const double *d_x, double *
     // K x = S^-1 (A^ (S^-1 x)) when the matrix already carries its scaling
     hipLaunchKernelGGL(k_expand, dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, n3, (int64_t)0, K->d_red,
                        d_x, sdiv, xf);
-    launch_spmv<double, false>(ctx, K, K->d_vals, xf, yf, nullptr, stt, 1);
+    launch_spmv<double, 0>(ctx, K, K->d_vals, xf, yf, nullptr, stt, 1);
     // compress (and undo the row scaling)
     hipLaunchKernelGGL(k_compress_div, dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, n3, K->d_red, sdiv, yf, d_y);
     HIPCHK(ctx, hipGetLastError());
@@ -1030,10 +1299,10 @@ int stan_spmv_local(stan_ctx *ctx, stan_matrix *K, const double *d_x, double *d_
     HIPCHK(ctx, hipMemcpyAsync(stt, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
     if (K->d_sl_bnd) {  // sharded: interior + boundary lists must cover every slice exactly once
         HIPCHK(ctx, hipMemsetAsync(d_y, 0xff, (size_t)(3 * K->nloc) * 8, ctx->stream));  // NaN
-        launch_spmv<double, false>(ctx, K, K->d_vals, d_x, d_y, nullptr, stt, 1, 1);
-        launch_spmv<double, false>(ctx, K, K->d_vals, d_x, d_y, nullptr, stt, 1, 2);
+        launch_spmv<double, 0>(ctx, K, K->d_vals, d_x, d_y, nullptr, stt, 1, 1);
+        launch_spmv<double, 0>(ctx, K, K->d_vals, d_x, d_y, nullptr, stt, 1, 2);
     } else
-        launch_spmv<double, false>(ctx, K, K->d_vals, d_x, d_y, nullptr, stt, 1);
+        launch_spmv<double, 0>(ctx, K, K->d_vals, d_x, d_y, nullptr, stt, 1);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return STAN_OK;
@@ -1064,9 +1333,9 @@ int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode
     event_bag events;
     hipEvent_t a = events.make(), b = events.make();
     auto one = [&]() {
-        if (mixed) launch_spmv<float, true>(ctx, K, K->d_vals32, x, y, partial, stt, 1);
-        else if (fx) launch_spmv<uint32_t, true>(ctx, K, K->d_vals48, x, y, partial, stt, 1);
-        else launch_spmv<double, true>(ctx, K, K->d_vals, x, y, partial, stt, 1);
+        if (mixed) launch_spmv<float, 1>(ctx, K, K->d_vals32, x, y, partial, stt, 1);
+        else if (fx) launch_spmv<uint32_t, 1>(ctx, K, K->d_vals48, x, y, partial, stt, 1);
+        else launch_spmv<double, 1>(ctx, K, K->d_vals, x, y, partial, stt, 1);
     };
     for (int i = 0; i < 3; i++) one();
     hipEventRecord(a, st_);
@@ -1103,11 +1372,11 @@ int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, int32_t pre
         hipEvent_t a = ev.make(), b = ev.make();
         hipEventRecord(a, st_);
         if (precision == STAN_PREC_FIXED48)
-            launch_spmv<uint32_t, true>(ctx, K, (const uint32_t *)vals, x, y, partial, stt, 1);
+            launch_spmv<uint32_t, 1>(ctx, K, (const uint32_t *)vals, x, y, partial, stt, 1);
         else if (precision == STAN_PREC_MIXED)
-            launch_spmv<float, true>(ctx, K, (const float *)vals, x, y, partial, stt, 1);
+            launch_spmv<float, 1>(ctx, K, (const float *)vals, x, y, partial, stt, 1);
         else
-            launch_spmv<double, true>(ctx, K, (const double *)vals, x, y, partial, stt, 1);
+            launch_spmv<double, 1>(ctx, K, (const double *)vals, x, y, partial, stt, 1);
         hipEventRecord(b, st_);
         HIPCHK(ctx, hipEventSynchronize(b));
         if (r > 0) hipEventElapsedTime(&t[r - 1], a, b);

@@ -56,6 +56,7 @@ struct rccl_api {
 struct stan_pool {
     static constexpr size_t MIN_BYTES = 8u << 20;
     static constexpr size_t MAX_BLOCKS = 64;   // parked blocks; one assemble + solve parks ~30
+    size_t max_bytes = (size_t)64 << 30;       // parked bytes (STAN_OPT_POOL_MAX_BYTES; init: half the device); oldest go first
     struct blk { void *p; size_t cap; };
     std::vector<blk> avail;
     std::unordered_map<void *, size_t> live;  // pooled-class blocks currently handed out
@@ -116,6 +117,8 @@ struct stan_ctx {
     bool cg_merit_stop = true;
     int cg_rupdate = 10;
     bool cg_fused_refresh = true;  // A x and A p of a refresh iteration in one matrix pass
+    bool cg_single_reduce = false; // Chronopoulos-Gear loop: one reduction point per iteration
+    bool cg_fold_reduce = true;    // reductions finished by the producing kernel's last block
     bool overlap_halo = true;  // interior SpMV on a side stream while the halo is exchanged
     hipStream_t side = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
@@ -262,8 +265,11 @@ static inline void stan_dfree(stan_ctx *ctx, void *p) {
             if (ctx->pool.enabled) {
                 ctx->pool.avail.push_back({p, cap});
                 ctx->pool.bytes_avail += cap;
-                if (ctx->pool.avail.size() > stan_pool::MAX_BLOCKS) {  // a host cycling through
-                    hipFree(ctx->pool.avail.front().p);               // many sizes: drop the oldest
+                // a host cycling through many sizes, or one sharing the GPU with another
+                // allocator: drop the oldest parked blocks beyond the block / byte budget
+                while (!ctx->pool.avail.empty() && (ctx->pool.avail.size() > stan_pool::MAX_BLOCKS ||
+                                                    ctx->pool.bytes_avail > ctx->pool.max_bytes)) {
+                    hipFree(ctx->pool.avail.front().p);
                     ctx->pool.bytes_avail -= ctx->pool.avail.front().cap;
                     ctx->pool.avail.erase(ctx->pool.avail.begin());
                 }

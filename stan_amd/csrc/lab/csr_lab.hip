@@ -6,7 +6,8 @@
 #include <algorithm>
 #include <cmath>
 
-#include "internal.h"
+#include "../internal.h"
+#include "stan_hip_lab.h"
 
 namespace {
 

@@ -161,7 +161,7 @@ int stan_recover_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz, con
     hipError_t e3 = hipGetLastError();
     hipError_t e4 = hipMemcpyAsync(ctx->h_status + SS_BAD_ELEM, ctx->d_status + SS_BAD_ELEM, 16, hipMemcpyDeviceToHost, st);
     hipError_t e5 = hipStreamSynchronize(st);
-    hipFree(d_lamG);
+    stan_dfree(ctx, d_lamG);
     for (hipError_t e : {e1, e2, e3, e4, e5})
         if (e != hipSuccess) { ctx->err = std::string("recover: ") + hipGetErrorString(e); return STAN_E_HIP; }
     if (ctx->h_status[SS_AUX] != init[0]) {

@@ -100,10 +100,10 @@ int scan_rec(stan_ctx *ctx, const Tin *d_in, int64_t *d_out, int64_t n) {
         if (rc == STAN_OK)
             hipLaunchKernelGGL(k_tile_scan<Tin>, dim3((unsigned)ntiles), dim3(SCAN_T), 0,
                                ctx->stream, d_in, (const int64_t *)d_toff, d_out, n);
-        // the frees synchronise with the stream's outstanding work
-        hipStreamSynchronize(ctx->stream);
-        hipFree(d_tsum);
-        hipFree(d_toff);
+        // pooled blocks are reused in stream order; smaller ones go through hipFree, which waits
+        // for the device itself
+        stan_dfree(ctx, d_tsum);
+        stan_dfree(ctx, d_toff);
         STANCHK(rc);
     }
     if (sizeof(Tin) == 4)

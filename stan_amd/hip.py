@@ -21,6 +21,9 @@ OPT_CG_MERIT_STOP, OPT_CG_RUPDATE, OPT_SPMV_VARIANT, OPT_OVERLAP_HALO, OPT_ASSEM
 OPT_CG_FUSED_REFRESH = 6
 OPT_POOL = 7
 OPT_PLACEMENT_TRIES = 8
+OPT_POOL_MAX_BYTES = 9
+OPT_CG_SINGLE_REDUCE = 10
+OPT_CG_FOLD_REDUCE = 11
 E_HIP, E_ARG, E_ALLOC, E_DETJ, E_DOF_LAYOUT, E_VALENCE, E_COMM, E_UNSUPPORTED = (
     -1, -2, -3, -4, -5, -6, -7, -8)
 
@@ -32,8 +35,10 @@ EXPORTS = [
     "stan_hip_ke_hex8_batch", "stan_hip_matrix_to_csr", "stan_hip_spmv", "stan_hip_spmv_bench",
     "stan_hip_set_profiling", "stan_hip_get_profile", "stan_hip_set_option", "stan_hip_recover_hex8", "stan_hip_recover_hex8_dev",
     "stan_hip_nodal_forces_hex8", "stan_hip_pool_info",
-    "stan_hip_matrix_plan", "stan_hip_spmv_local", "stan_hip_csr_spmv_bench",
+    "stan_hip_matrix_plan", "stan_hip_spmv_local",
 ]
+# only in the lab build (stan_amd/csrc/lab/stan_hip_lab.h, selected with STAN_HIP_LIB)
+LAB_EXPORTS = ["stan_hip_csr_spmv_bench"]
 
 
 class MatrixInfo(C.Structure):
@@ -49,7 +54,9 @@ class Profile(C.Structure):
                 ("spmv_launches", C.c_int64), ("spmv_bytes", C.c_int64),
                 ("cg_iteration_vector_bytes", C.c_int64), ("iterations", C.c_int32),
                 ("termination_type", C.c_int32), ("assembly_colours", C.c_int32),
-                ("value_stream", C.c_int32), ("spmv2_ms_total", C.c_double), ("spmv2_launches", C.c_int64)]
+                ("value_stream", C.c_int32), ("spmv2_ms_total", C.c_double), ("spmv2_launches", C.c_int64),
+                ("loop_kernel_launches", C.c_int64), ("loop_collectives", C.c_int64),
+                ("loop_iterations_enqueued", C.c_int64)]
 
 
 class StanHipError(RuntimeError):
@@ -263,9 +270,10 @@ class Matrix:
             self.k = None
 
     def __del__(self):
+        # valid for a matrix whose context is already closed too: stan_hip_destroy detaches its
+        # matrices, and a detached matrix gives its buffers straight back to the driver
         try:
-            if self.ctx.h:
-                self.free()
+            self.free()
         except Exception:
             pass
 
@@ -345,6 +353,9 @@ class Matrix:
         return y
 
     def csr_spmv_bench(self, reps=20):
+        """lab build only (make -C stan_amd/csrc lab; STAN_HIP_LIB=.../libstan_hip_lab.so)"""
+        if not hasattr(self.ctx.lib, "stan_hip_csr_spmv_bench"):
+            raise RuntimeError("stan_hip_csr_spmv_bench exists only in the lab build of the library")
         ms, nb, diff = C.c_double(0), C.c_int64(0), C.c_double(0)
         self.ctx._chk(self.ctx.lib.stan_hip_csr_spmv_bench(self.ctx.h, self.k, C.c_int32(reps),
                                                            C.byref(ms), C.byref(nb), C.byref(diff)))

@@ -23,6 +23,17 @@ def test_hip_library_exports(built_libs):
         assert hasattr(lib, n), n
 
 
+def test_product_library_carries_no_lab_code(built_libs):
+    """The A/B kernel variants of round 1 (one of them, variant 8, computes wrong numbers on purpose)
+    and the scalar-CSR comparison kernel live in the lab build only (make -C stan_amd/csrc lab)."""
+    from stan_amd import hip
+    lib = hip.load()
+    for n in hip.LAB_EXPORTS:
+        assert not hasattr(lib, n), n
+    api = open(os.path.join(ROOT, "stan_amd", "csrc", "api.hip")).read()
+    assert "value == -1 || value == 0 || value == 9 || value == 12" in api
+
+
 def test_host_library_exports(built_libs):
     from stan_amd import host
     lib = host.load()
