@@ -1387,6 +1387,48 @@ int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, int32_t pre
     return STAN_OK;
 }
 
+#ifdef STAN_LAB
+// lab: time the fp64 SpMV over the slices [s0, s1) only, streaming the values from `vals`
+// (lab/placement_lab.hip: where inside a block does a slow block lose its time?)
+int stan_spmv_probe_range(stan_ctx *ctx, stan_matrix *K, const double *vals, int32_t s0, int32_t s1,
+                          int reps, float *ms_out) {
+    hipStream_t st_ = ctx->stream;
+    *ms_out = 0;
+    if (s1 <= s0) return STAN_OK;
+    const int64_t npad = (int64_t)K->nslices * 64;
+    const int64_t ng = 3 * ((npad > K->nloc + K->nhalo ? npad : K->nloc + K->nhalo));
+    dev_bufs bufs;
+    double *x, *y, *partial; int64_t *stt; int32_t *list;
+    STANCHK(alloc(ctx, bufs, &x, (size_t)ng));
+    STANCHK(alloc(ctx, bufs, &y, (size_t)ng));
+    STANCHK(alloc(ctx, bufs, &partial, (size_t)nblk(K->nslices, 4) + 1));
+    STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
+    STANCHK(alloc(ctx, bufs, &list, (size_t)(s1 - s0)));
+    std::vector<int32_t> h((size_t)(s1 - s0));
+    for (int32_t i = s0; i < s1; i++) h[i - s0] = i;
+    int64_t init[T_NSTAT] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0, 0, 0, 0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(stt, init, sizeof(init), hipMemcpyHostToDevice, st_));
+    HIPCHK(ctx, hipMemcpyAsync(list, h.data(), h.size() * 4, hipMemcpyHostToDevice, st_));
+    hipLaunchKernelGGL(k_fill, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, x, ng, 1.0);
+    HIPCHK(ctx, hipStreamSynchronize(st_));
+    const unsigned grid = nblk(s1 - s0, 4);
+    event_bag ev;
+    hipEvent_t a = ev.make(), b = ev.make();
+    for (int r = 0; r < reps + 2; r++) {
+        if (r == 2) hipEventRecord(a, st_);
+        hipLaunchKernelGGL((k_spmv<double, 1, 9>), dim3(grid), dim3(256), 0, st_, K->nslices, K->nloc,
+                           K->d_slot_ptr, K->d_cols, vals, x, y, partial, stt, (int64_t)1, list, s1 - s0, 0,
+                           fold_args{nullptr, 0, 0, nullptr});
+    }
+    hipEventRecord(b, st_);
+    HIPCHK(ctx, hipEventSynchronize(b));
+    hipEventElapsedTime(ms_out, a, b);
+    *ms_out /= reps;
+    HIPCHK(ctx, hipGetLastError());
+    return STAN_OK;
+}
+#endif
+
 // un-scale on export
 int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K) {
     if (!K->scaled) return STAN_OK;

@@ -14,6 +14,12 @@ extern "C" {
  * Single-rank contexts, matrix in its current (scaled or not) state. */
 int stan_hip_csr_spmv_bench(stan_ctx *ctx, stan_matrix *K, int32_t reps, double *avg_ms,
                             int64_t *bytes_per_launch, double *max_rel_diff);
+/* Placement map (lab/placement_lab.hip): ntries candidate blocks for K's value stream; per
+ * candidate the whole-SpMV time, the SpMV time of each of nseg consecutive slice ranges and the
+ * plain-read time of each range's bytes: ms [ntries * (1 + 2*nseg)], addr [ntries] device addresses.
+ * keep_fastest: 0 leave K where it is, 1 move it to the fastest candidate, 2 to the slowest. */
+int stan_hip_lab_placement_map(stan_ctx *ctx, stan_matrix *K, int32_t ntries, int32_t nseg,
+                               int32_t keep_fastest, double *ms, uint64_t *addr);
 #ifdef __cplusplus
 }
 #endif
