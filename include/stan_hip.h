@@ -19,11 +19,15 @@
  * exactly as the reference prints them (SolverFunctions.cs:308-325) and the
  * solution vector is returned regardless (SolverFunctions.cs:329).
  *
- * One context drives ONE GPU (one process per GPU).  For N GPUs every rank
- * creates a context, joins a communicator (stan_hip_comm_init) and then makes
- * the same calls with the same full-size arguments; rows of K are sharded by
- * contiguous block-row ranges in reference DOF order and the CG exchanges halos
- * and reduces its dot products over RCCL.
+ * Several GPUs, two ways, same sharding underneath (rows of K cut into contiguous
+ * block-row ranges in reference DOF order; the CG exchanges halos and reduces its
+ * dot products over RCCL):
+ *   (a) ONE PROCESS -- what a .NET host or the console driver uses: stan_hip_init_multi
+ *       returns a handle that drives n devices (one worker thread and one communicator
+ *       rank per device inside the library); every other call is the single-GPU call.
+ *   (b) one process per GPU under a launcher (bench.py under torch.distributed.run):
+ *       every rank creates an ordinary context, joins a communicator
+ *       (stan_hip_comm_init) and makes the same calls with the same full-size arguments.
  */
 #ifndef STAN_HIP_H
 #define STAN_HIP_H
@@ -67,6 +71,13 @@ typedef struct stan_matrix stan_matrix;
 /* `device` = HIP device ordinal this process drives.  Fails loudly (STAN_E_HIP) when no
  * GPU is present: there is no CPU fallback. */
 int stan_hip_init(int device, stan_ctx **out);
+/* One handle for n_devices GPUs of this node (devices [n_devices] HIP ordinals, NULL = 0..n-1):
+ * SURVEY.md section 8b's `stan_hip_init(int n_devices, ...)`.  assemble_hex8, cg_solve,
+ * recover_hex8, nodal_forces_hex8, set_option, set_profiling, matrix_info, matrix_free, last_error
+ * and destroy take the handle like a single-GPU context; the entry points with DEVICE pointers
+ * (*_dev), set_stream, comm_init and the single-rank parity helpers (matrix_to_csr, spmv, ...)
+ * return STAN_E_UNSUPPORTED on it.  n_devices == 1 is allowed (no communicator). */
+int stan_hip_init_multi(int n_devices, const int *devices, stan_ctx **out);
 void stan_hip_destroy(stan_ctx *ctx);
 const char *stan_hip_last_error(stan_ctx *ctx);
 int64_t stan_hip_last_bad_element(stan_ctx *ctx);

@@ -23,6 +23,8 @@ struct dbuf {  // RAII device buffer filled from host memory
 };
 }  // namespace
 
+void stan_set_global_error(const std::string &msg) { g_err = msg; }
+
 extern "C" {
 
 int stan_hip_init(int device, stan_ctx **out) {
@@ -54,6 +56,7 @@ int stan_hip_init(int device, stan_ctx **out) {
 
 void stan_hip_destroy(stan_ctx *ctx) {
     if (!ctx) return;
+    if (ctx->group) { stan_group_destroy(ctx); return; }
     hipSetDevice(ctx->device);
     if (ctx->comm && ctx->nccl.CommDestroy) ctx->nccl.CommDestroy(ctx->comm);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -69,11 +72,15 @@ void stan_hip_destroy(stan_ctx *ctx) {
     delete ctx;
 }
 
-const char *stan_hip_last_error(stan_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+const char *stan_hip_last_error(stan_ctx *ctx) {
+    if (ctx && ctx->group) return stan_group_last_error(ctx);
+    return ctx ? ctx->err.c_str() : g_err.c_str();
+}
 int64_t stan_hip_last_bad_element(stan_ctx *ctx) { return ctx ? ctx->bad_elem : -1; }
 
 int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream) {
     if (!ctx) return STAN_E_ARG;
+    STAN_NO_GROUP(ctx, "set_stream");
     hipSetDevice(ctx->device);
     // parked blocks of the pool are reused in stream order: drain the old stream before switching
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
@@ -89,6 +96,8 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream) {
 
 int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
     if (!ctx) return STAN_E_ARG;
+    if (ctx->group)
+        return stan_group_ctx_call(ctx, [&](stan_ctx *c) { return stan_hip_set_option(c, option, value); });
     if (option == STAN_OPT_CG_MERIT_STOP) ctx->cg_merit_stop = value != 0;
     else if (option == STAN_OPT_CG_RUPDATE && value >= 0 && value < (1 << 30)) ctx->cg_rupdate = (int)value;
     else if (option == STAN_OPT_ASSEMBLY_MODE && (value == 0 || value == 1)) ctx->assembly_mode = (int)value;
@@ -116,7 +125,7 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
     else if (option == STAN_OPT_OVERLAP_HALO) ctx->overlap_halo = value != 0;
     else if (option == STAN_OPT_PLACEMENT_TRIES && value >= 1 && value <= 8) ctx->placement_tries = (int)value;
 #ifdef STAN_LAB
-    else if (option == STAN_OPT_SPMV_VARIANT && value >= -1 && value <= 13) ctx->spmv_variant = (int)value;
+    else if (option == STAN_OPT_SPMV_VARIANT && value >= -1 && value <= 16) ctx->spmv_variant = (int)value;
 #else   // the product library carries the three variants that give right answers (cg.hip)
     else if (option == STAN_OPT_SPMV_VARIANT && (value == -1 || value == 0 || value == 9 || value == 12))
         ctx->spmv_variant = (int)value;
@@ -127,6 +136,7 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
 
 int stan_hip_pool_info(stan_ctx *ctx, int64_t *bytes_parked, int64_t *blocks_parked) {
     if (!ctx) return STAN_E_ARG;
+    if (ctx->group) ctx = stan_group_rank0(ctx);
     if (bytes_parked) *bytes_parked = (int64_t)ctx->pool.bytes_avail;
     if (blocks_parked) *blocks_parked = (int64_t)ctx->pool.avail.size();
     return STAN_OK;
@@ -134,11 +144,14 @@ int stan_hip_pool_info(stan_ctx *ctx, int64_t *bytes_parked, int64_t *blocks_par
 
 int stan_hip_set_profiling(stan_ctx *ctx, int32_t enabled) {
     if (!ctx) return STAN_E_ARG;
+    if (ctx->group)
+        return stan_group_ctx_call(ctx, [&](stan_ctx *c) { return stan_hip_set_profiling(c, enabled); });
     ctx->profiling = enabled != 0;
     return STAN_OK;
 }
 int stan_hip_get_profile(stan_ctx *ctx, stan_profile *out) {
     if (!ctx || !out) return STAN_E_ARG;
+    if (ctx->group) ctx = stan_group_rank0(ctx);   // rank 0's timings; spmv_bytes is that shard's
     *out = ctx->prof;
     out->assembly_colours = ctx->prof_colours;
     return STAN_OK;
@@ -152,6 +165,7 @@ int stan_hip_assemble_hex8_dev(stan_ctx *ctx, int64_t n_nodes, const double *d_x
     if (!ctx || !outK || !d_xyz || !d_node_dof || !d_red || !mat_E_nu ||
         (n_elem > 0 && (!d_conn || !d_elem_mat || !d_elem_type)))
         return STAN_E_ARG;
+    STAN_NO_GROUP(ctx, "assemble_hex8_dev (device pointers belong to one device)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return stan_assemble_device(ctx, n_nodes, d_xyz, d_node_dof, n_elem, d_conn, d_elem_mat,
                                 d_elem_type, n_mat, mat_E_nu, n_dof, d_red, outK);
@@ -167,6 +181,9 @@ int stan_hip_assemble_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz,
         if (ctx) ctx->err = "assemble_hex8: null or empty argument";
         return STAN_E_ARG;
     }
+    if (ctx->group)
+        return stan_group_assemble(ctx, n_nodes, xyz, node_dof, n_elem, conn, elem_mat, elem_type, n_mat,
+                                   mat_E_nu, n_dof, red, outK);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     for (int64_t e = 0; e < n_elem; e++) {
         if (elem_mat[e] < 0 || elem_mat[e] >= n_mat) {
@@ -191,6 +208,7 @@ int stan_hip_assemble_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz,
 
 void stan_hip_matrix_free(stan_matrix *K) {
     if (!K) return;
+    if (!K->parts.empty()) { stan_group_matrix_free(K); return; }
     if (K->ctx) {
         hipSetDevice(K->ctx->device);
         auto &v = K->ctx->matrices;
@@ -211,6 +229,7 @@ int stan_hip_cg_solve_dev(stan_ctx *ctx, stan_matrix *K, const double *d_F, doub
                           int32_t max_its, int32_t precision_mode, double *d_U,
                           int32_t *termination_type, int32_t *iterations, double *rel_residual) {
     if (!ctx || !K || !d_F || !d_U || K->ctx != ctx) return STAN_E_ARG;
+    STAN_NO_GROUP(ctx, "cg_solve_dev (device pointers belong to one device)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return stan_cg_device(ctx, K, d_F, eps_f, max_its, precision_mode, d_U, termination_type,
                           iterations, rel_residual);
@@ -220,6 +239,9 @@ int stan_hip_cg_solve(stan_ctx *ctx, stan_matrix *K, const double *F, double eps
                       int32_t max_its, int32_t precision_mode, double *U,
                       int32_t *termination_type, int32_t *iterations, double *rel_residual) {
     if (!ctx || !K || !F || !U || K->ctx != ctx) return STAN_E_ARG;
+    if (ctx->group)
+        return stan_group_cg_solve(ctx, K, F, eps_f, max_its, precision_mode, U, termination_type, iterations,
+                                   rel_residual);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t N = (size_t)K->n_red;
     dbuf<double> dF, dU;
@@ -241,6 +263,7 @@ int stan_hip_recover_hex8_dev(stan_ctx *ctx, int64_t n_nodes, const double *d_xy
     if (!ctx || !d_xyz || !d_disp || !mat_E_nu || n_mat <= 0 ||
         (n_elem > 0 && (!d_conn || !d_elem_mat || !d_elem_type || !d_strain || !d_stress)))
         return STAN_E_ARG;
+    STAN_NO_GROUP(ctx, "recover_hex8_dev (device pointers belong to one device)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return stan_recover_device(ctx, n_nodes, d_xyz, d_disp, n_elem, d_conn, d_elem_mat, d_elem_type,
                                n_mat, mat_E_nu, d_strain, d_stress, nullptr, nullptr, nullptr);
@@ -253,6 +276,9 @@ int stan_hip_recover_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz, con
     if (!ctx || !xyz || !disp || !mat_E_nu || n_nodes <= 0 || n_mat <= 0 || n_elem < 0 ||
         (n_elem > 0 && (!conn || !elem_mat || !elem_type || !strain || !stress)))
         return STAN_E_ARG;
+    if (ctx->group)
+        return stan_group_recover(ctx, n_nodes, xyz, disp, n_elem, conn, elem_mat, elem_type, n_mat, mat_E_nu,
+                                  strain, stress);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     for (int64_t e = 0; e < n_elem; e++) {
         if (elem_mat[e] < 0 || elem_mat[e] >= n_mat) { ctx->err = "recover_hex8: elem_mat out of range"; return STAN_E_ARG; }
@@ -284,6 +310,7 @@ int stan_hip_nodal_forces_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz
     if (!ctx || !xyz || !disp || !node_dof || !mat_E_nu || n_nodes <= 0 || n_mat <= 0 || n_elem < 0 ||
         n_dof != n_nodes * 3 || (!elem_forces && !R) || (n_elem > 0 && (!conn || !elem_mat || !elem_type)))
         return STAN_E_ARG;
+    if (ctx->group) ctx = stan_group_rank0(ctx);   // R is an all-element sum: one device
     HIPCHK(ctx, hipSetDevice(ctx->device));
     for (int64_t e = 0; e < n_elem; e++) {
         if (elem_mat[e] < 0 || elem_mat[e] >= n_mat) { ctx->err = "nodal_forces_hex8: elem_mat out of range"; return STAN_E_ARG; }
@@ -319,7 +346,7 @@ int stan_hip_matrix_info(stan_matrix *K, stan_matrix_info *o) {
     o->row_begin = K->r0; o->row_end = K->r1; o->n_halo = K->nhalo; o->n_blocks = K->nblocks;
     o->n_slots = K->nslots;
     o->bytes_matrix = K->nslots * 64 * (9 * 8 + 4);
-    o->scaled = K->scaled ? 1 : 0;
+    o->scaled = (K->parts.empty() ? K->scaled : K->parts[0]->scaled) ? 1 : 0;
     o->max_row_blocks = K->max_row_blocks;
     return STAN_OK;
 }
@@ -327,6 +354,7 @@ int stan_hip_matrix_info(stan_matrix *K, stan_matrix_info *o) {
 int stan_hip_ke_hex8_batch(stan_ctx *ctx, int64_t n, const double *xyz8, double E, double nu,
                            const uint8_t *type, double *out) {
     if (!ctx || n < 0 || (n > 0 && (!xyz8 || !type || !out))) return STAN_E_ARG;
+    if (ctx->group) ctx = stan_group_rank0(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     for (int64_t e = 0; e < n; e++)
         if (type[e] != STAN_HEX8_G1 && type[e] != STAN_HEX8_G2) {
@@ -356,6 +384,7 @@ int stan_hip_ke_hex8(stan_ctx *ctx, const double xyz8[24], double E, double nu, 
 int stan_hip_matrix_to_csr(stan_ctx *ctx, stan_matrix *K, int32_t upper_only, int64_t *nnz,
                            int64_t *rowptr, int32_t *col, double *val) {
     if (!ctx || !K || !nnz || K->ctx != ctx) return STAN_E_ARG;
+    STAN_NO_GROUP(ctx, "matrix_to_csr");
     if (ctx->nranks != 1) { ctx->err = "matrix_to_csr: single-rank contexts only"; return STAN_E_UNSUPPORTED; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     STANCHK(stan_matrix_unscale(ctx, K));  // export K itself, not S K S
@@ -406,6 +435,7 @@ int stan_hip_matrix_to_csr(stan_ctx *ctx, stan_matrix *K, int32_t upper_only, in
 
 int stan_hip_spmv(stan_ctx *ctx, stan_matrix *K, const double *x, double *y) {
     if (!ctx || !K || !x || !y || K->ctx != ctx) return STAN_E_ARG;
+    STAN_NO_GROUP(ctx, "spmv");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t N = (size_t)K->n_red;
     dbuf<double> dx, dy;
@@ -421,6 +451,7 @@ int stan_hip_matrix_plan(stan_ctx *ctx, stan_matrix *K, int64_t *row_starts, int
                          int32_t *halo_glob, int32_t *n_nbr, int32_t *nbr, int64_t *send_off,
                          int32_t *send_rows, int64_t *recv_off) {
     if (!ctx || !K || K->ctx != ctx) return STAN_E_ARG;
+    STAN_NO_GROUP(ctx, "matrix_plan");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (row_starts) for (size_t i = 0; i < K->row_starts.size(); i++) row_starts[i] = K->row_starts[i];
     if (n_halo) *n_halo = K->nhalo;
@@ -437,6 +468,7 @@ int stan_hip_matrix_plan(stan_ctx *ctx, stan_matrix *K, int64_t *row_starts, int
 
 int stan_hip_spmv_local(stan_ctx *ctx, stan_matrix *K, const double *x_local, double *y_owned) {
     if (!ctx || !K || !x_local || !y_owned || K->ctx != ctx) return STAN_E_ARG;
+    STAN_NO_GROUP(ctx, "spmv_local");
     if (K->scaled) { ctx->err = "spmv_local: matrix already carries the CG scaling"; return STAN_E_UNSUPPORTED; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int64_t npad = (int64_t)K->nslices * 64;
@@ -454,6 +486,7 @@ int stan_hip_spmv_local(stan_ctx *ctx, stan_matrix *K, const double *x_local, do
 int stan_hip_spmv_bench(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode, int32_t reps,
                         double *avg_ms) {
     if (!ctx || !K || !avg_ms || reps <= 0 || K->ctx != ctx) return STAN_E_ARG;
+    STAN_NO_GROUP(ctx, "spmv_bench");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return stan_spmv_bench_device(ctx, K, precision_mode, reps, avg_ms);
 }

@@ -89,8 +89,16 @@ __device__ __forceinline__ double sum_partials(const double *partial, int np, in
     for (; i < np; i += 256) a[0] += ld_agent(partial + (int64_t)i * nv + j);
     return block_sum(((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])), sh);
 }
+// Tickets are two-level: block b first counts itself into sub-counter b % FOLD_SUB (a 128-B line
+// of its own), the last arrival of a sub-counter counts that sub-counter into the top counter, the
+// last arrival there finishes.  One flat counter cost k_step +10 us (rocprofv3, 148^3): its 2048
+// blocks end together and 2048 adds to ONE address are served one after the other at the memory
+// side; with 32 sub-counters the longest queue is 64.
+constexpr int FOLD_SUB = 32;
+constexpr int FOLD_LINE = 16;                               // uint64 per 128-B line
+constexpr int FOLD_WORDS = (1 + FOLD_SUB) * FOLD_LINE;      // one counter set: top + sub-counters
 struct fold_args {
-    unsigned long long *counter;  // ticket counter (zero between kernels); nullptr: no fold
+    unsigned long long *counter;  // counter set (zero between kernels); nullptr: no fold
     unsigned nblocks;             // tickets this launch hands out (its grid size)
     int np;                       // partials to add (>= nblocks: earlier launches may have left some)
     double *out;                  // [NV] results
@@ -100,9 +108,17 @@ struct fold_args {
 __device__ __forceinline__ bool fold_arrive(const fold_args &f, int *sh_last) {
     if (threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial has left this CU
-        const unsigned long long t =
-            __hip_atomic_fetch_add(f.counter, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *sh_last = (t == (unsigned long long)f.nblocks - 1) ? 1 : 0;
+        const unsigned sub = blockIdx.x % FOLD_SUB;
+        const unsigned in_sub = (f.nblocks - sub + FOLD_SUB - 1) / FOLD_SUB;     // blocks b with b % SUB == sub
+        const unsigned nsub = f.nblocks < (unsigned)FOLD_SUB ? f.nblocks : (unsigned)FOLD_SUB;
+        int last = 0;
+        unsigned long long t = __hip_atomic_fetch_add(f.counter + (1 + sub) * FOLD_LINE, 1ULL, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+        if (t == (unsigned long long)in_sub - 1) {
+            t = __hip_atomic_fetch_add(f.counter, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = t == (unsigned long long)nsub - 1;
+        }
+        *sh_last = last;
     }
     __syncthreads();
     return *sh_last != 0;
@@ -115,8 +131,10 @@ __device__ __forceinline__ void fold_finish(const fold_args &f, const double *pa
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int j = 0; j < NV; j++) f.out[j] = r[j];  // read by the NEXT kernel: a plain store will do
-        __hip_atomic_store(f.counter, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // every ticket of this launch has been drawn: clear the set for the next one
+    if (threadIdx.x <= FOLD_SUB)
+        __hip_atomic_store(f.counter + threadIdx.x * FOLD_LINE, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ bool stopped(const int64_t *st, int64_t k) {
@@ -319,14 +337,14 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
     __shared__ double sh[4];
     __shared__ int sh_last;
     if (stopped(st, kiter)) return;
-    constexpr bool NT = ((VAR & 1) != 0 && VAR < 8) || (VAR >= 9 && VAR != 13);  // 13 = 9 without the hint
+    constexpr bool NT = ((VAR & 1) != 0 && VAR < 8) || (VAR >= 9 && VAR != 13);  // 13 = 9 without the hint; 14-16 lab
     constexpr bool XCD = (VAR & 2) != 0 && VAR < 8;
     constexpr int UNR = (((VAR & 4) != 0 && VAR < 8) || VAR == 12) ? 4 : 2;
     // VAR 9/10/11: XCD-chunked mapping.  Workgroups go round-robin to the 8 XCDs; here every
     // window of 8*C consecutive workgroups is dealt so that each XCD gets C CONSECUTIVE ones
     // (C = 32 / 8 / 128): an XCD's L2 then holds the x window of one contiguous run of rows
     // while the chip as a whole still sweeps the matrix front to back.
-    constexpr int CH = (VAR == 9 || VAR == 12 || VAR == 13) ? 32 : VAR == 10 ? 8 : VAR == 11 ? 128 : 0;  // 12 = 9 + unroll 4
+    constexpr int CH = (VAR == 9 || VAR == 12 || VAR >= 13) ? 32 : VAR == 10 ? 8 : VAR == 11 ? 128 : 0;  // 12 = 9 + unroll 4
     const int lane = threadIdx.x & 63;
     int64_t bid = blockIdx.x;
     if (XCD) {
@@ -362,6 +380,29 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
                 y2 += a[6] * x0 + a[7] * x1 + a[8] * x2 + b[6] * z0 + b[7] * z1 + b[8] * z2;
                 cp += 128;
                 vq += 9 * 64;
+            }
+        } else if (VAR == 14 || VAR == 15 || VAR == 16) {
+            // lab: break the lockstep of neighbouring streams (tools/placement_map.py).  14: odd slices
+            // walk their slots back to front; 15: every slice starts at slot (slice % width) and wraps;
+            // 16: like 15 with a hashed start.  Same products, other summation order per row.
+            const int32_t n = k1 - k0;
+            const int32_t rot = VAR == 14 ? 0 : VAR == 15 ? (int32_t)(slice % (n > 0 ? n : 1))
+                                                          : (int32_t)(((uint32_t)slice * 2654435761u >> 16) % (uint32_t)(n > 0 ? n : 1));
+            const bool rev = VAR == 14 && (slice & 1);
+#pragma unroll 2
+            for (int32_t i = 0; i < n; i++) {
+                int32_t kk = rev ? n - 1 - i : i + rot;
+                if (kk >= n) kk -= n;
+                const int32_t *cq = cp + (int64_t)kk * 64;
+                const VT *vq = vp + (int64_t)kk * vstream<VT>::STRIDE;
+                const int64_t c = ld_stream<true>(cq);
+                double a[9];
+                load9<true, VT>(vq, a);
+                double x0 = x[3 * c], x1 = x[3 * c + 1], x2 = x[3 * c + 2];
+                if (vstream<VT>::FX) { x0 *= FX48_INV; x1 *= FX48_INV; x2 *= FX48_INV; }
+                y0 += a[0] * x0 + a[1] * x1 + a[2] * x2;
+                y1 += a[3] * x0 + a[4] * x1 + a[5] * x2;
+                y2 += a[6] * x0 + a[7] * x1 + a[8] * x2;
             }
         } else
 #endif
@@ -817,7 +858,7 @@ unsigned launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double
         SPMV_CASE(9) SPMV_CASE(12)
 #ifdef STAN_LAB
         SPMV_CASE(1) SPMV_CASE(2) SPMV_CASE(3) SPMV_CASE(4) SPMV_CASE(5) SPMV_CASE(6) SPMV_CASE(7)
-        SPMV_CASE(8) SPMV_CASE(10) SPMV_CASE(11) SPMV_CASE(13)
+        SPMV_CASE(8) SPMV_CASE(10) SPMV_CASE(11) SPMV_CASE(13) SPMV_CASE(14) SPMV_CASE(15) SPMV_CASE(16)
 #endif
         default:
         SPMV_CASE(0)
@@ -974,9 +1015,9 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     STANCHK(alloc(ctx, bufs, &partial, npart));
     STANCHK(alloc(ctx, bufs, &sc, (size_t)S_NSCAL));
     STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
-    STANCHK(alloc(ctx, bufs, &tick, (size_t)32));   // two ticket counters, a 128-B line each
+    STANCHK(alloc(ctx, bufs, &tick, (size_t)(2 * FOLD_WORDS)));   // two ticket-counter sets
     HIPCHK(ctx, hipMemsetAsync(sc, 0, S_NSCAL * 8, st_));
-    HIPCHK(ctx, hipMemsetAsync(tick, 0, 32 * 8, st_));
+    HIPCHK(ctx, hipMemsetAsync(tick, 0, 2 * FOLD_WORDS * 8, st_));
     HIPCHK(ctx, hipMemsetAsync(xb[0], 0, (size_t)ng * 8, st_));
     HIPCHK(ctx, hipMemsetAsync(xb[1], 0, (size_t)ng * 8, st_));
     HIPCHK(ctx, hipMemsetAsync(p, 0, (size_t)ng * 8, st_));
@@ -986,7 +1027,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     }
     // folded reductions: counter A serves the products, counter B the vector kernels
     auto fold_to = [&](int which, double *out) {
-        return fold_args{foldr ? tick + 16 * which : nullptr, 0, 0, out};
+        return fold_args{foldr ? tick + FOLD_WORDS * which : nullptr, 0, 0, out};
     };
     auto reduce_if_unfolded = [&](int np, int nv, double *out) {
         if (!foldr && np > 0)
@@ -1391,7 +1432,7 @@ int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, int32_t pre
 // lab: time the fp64 SpMV over the slices [s0, s1) only, streaming the values from `vals`
 // (lab/placement_lab.hip: where inside a block does a slow block lose its time?)
 int stan_spmv_probe_range(stan_ctx *ctx, stan_matrix *K, const double *vals, int32_t s0, int32_t s1,
-                          int reps, float *ms_out) {
+                          int reps, float *ms_out, int variant) {
     hipStream_t st_ = ctx->stream;
     *ms_out = 0;
     if (s1 <= s0) return STAN_OK;
@@ -1416,9 +1457,11 @@ int stan_spmv_probe_range(stan_ctx *ctx, stan_matrix *K, const double *vals, int
     hipEvent_t a = ev.make(), b = ev.make();
     for (int r = 0; r < reps + 2; r++) {
         if (r == 2) hipEventRecord(a, st_);
-        hipLaunchKernelGGL((k_spmv<double, 1, 9>), dim3(grid), dim3(256), 0, st_, K->nslices, K->nloc,
-                           K->d_slot_ptr, K->d_cols, vals, x, y, partial, stt, (int64_t)1, list, s1 - s0, 0,
-                           fold_args{nullptr, 0, 0, nullptr});
+#define LABV(V) case V: hipLaunchKernelGGL((k_spmv<double, 1, V>), dim3(grid), dim3(256), 0, st_, K->nslices, K->nloc, \
+                           K->d_slot_ptr, K->d_cols, vals, x, y, partial, stt, (int64_t)1, list, s1 - s0, 0,           \
+                           fold_args{nullptr, 0, 0, nullptr}); break;
+        switch (variant) { LABV(0) LABV(13) LABV(14) LABV(15) LABV(16) LABV(12) default: LABV(9) }
+#undef LABV
     }
     hipEventRecord(b, st_);
     HIPCHK(ctx, hipEventSynchronize(b));

@@ -96,6 +96,7 @@ extern "C" int stan_hip_comm_unique_id(char id[128]) {
 
 extern "C" int stan_hip_comm_init(stan_ctx *ctx, int rank, int nranks, const char id[128]) {
     if (!ctx || nranks < 1 || rank < 0 || rank >= nranks) return STAN_E_ARG;
+    STAN_NO_GROUP(ctx, "comm_init (a multi-device handle builds its own communicator)");
     if (ctx->comm) {
         ctx->err = "comm_init: communicator already initialised";
         return STAN_E_ARG;

@@ -103,7 +103,9 @@ enum stan_status_slot {
 };
 
 struct stan_matrix;
+struct stan_group;   // multi.hip: one process, several GPUs
 struct stan_ctx {
+    stan_group *group = nullptr;  // set on the handle stan_hip_init_multi returns: the calls fan out
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -139,6 +141,7 @@ struct stan_ctx {
 
 struct stan_matrix {
     stan_ctx *ctx = nullptr;
+    std::vector<stan_matrix *> parts;  // group matrix (multi.hip): the shard of each device
     int64_t n_dof = 0, n_red = 0;
     int64_t nb_glob = 0;  // global block rows
     int64_t r0 = 0, r1 = 0;  // owned block rows
@@ -279,6 +282,33 @@ static inline void stan_dfree(stan_ctx *ctx, void *p) {
     }
     hipFree(p);
 }
+
+// ---- multi.hip: fan-out of the public entry points for a group handle ------------------------
+void stan_set_global_error(const std::string &msg);   // api.hip: errors raised before a context exists
+void stan_group_destroy(stan_ctx *lead);
+const char *stan_group_last_error(stan_ctx *lead);
+int stan_group_ctx_call(stan_ctx *lead, const std::function<int(stan_ctx *)> &fn);
+int stan_group_assemble(stan_ctx *lead, int64_t n_nodes, const double *xyz, const int32_t *node_dof,
+                        int64_t n_elem, const int32_t *conn, const int32_t *elem_mat,
+                        const uint8_t *elem_type, int32_t n_mat, const double *mat_E_nu, int64_t n_dof,
+                        const int32_t *red, stan_matrix **outK);
+void stan_group_matrix_free(stan_matrix *K);
+int stan_group_cg_solve(stan_ctx *lead, stan_matrix *K, const double *F, double eps_f, int32_t max_its,
+                        int32_t precision_mode, double *U, int32_t *termination_type, int32_t *iterations,
+                        double *rel_residual);
+int stan_group_recover(stan_ctx *lead, int64_t n_nodes, const double *xyz, const double *disp, int64_t n_elem,
+                       const int32_t *conn, const int32_t *elem_mat, const uint8_t *elem_type, int32_t n_mat,
+                       const double *mat_E_nu, double *strain, double *stress);
+stan_ctx *stan_group_rank0(stan_ctx *lead);
+int stan_group_size(stan_ctx *lead);
+// entry points that have no meaning for a group handle (device pointers, single-rank helpers)
+#define STAN_NO_GROUP(ctx, what)                                                                   \
+    do {                                                                                           \
+        if ((ctx) && (ctx)->group) {                                                               \
+            (ctx)->err = std::string(what) + ": not available on a multi-device handle";           \
+            return STAN_E_UNSUPPORTED;                                                             \
+        }                                                                                          \
+    } while (0)
 
 // placement.hip
 int stan_probe_block(stan_ctx *ctx, const void *p, size_t bytes, float *ms_out);

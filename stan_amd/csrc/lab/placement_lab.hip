@@ -9,7 +9,7 @@
 #include "stan_hip_lab.h"
 
 int stan_spmv_probe_range(stan_ctx *ctx, stan_matrix *K, const double *vals, int32_t s0, int32_t s1,
-                          int reps, float *ms_out);
+                          int reps, float *ms_out, int variant);
 
 extern "C" int stan_hip_lab_placement_map(stan_ctx *ctx, stan_matrix *K, int32_t ntries, int32_t nseg,
                                           int32_t keep_fastest, double *ms, uint64_t *addr) {
@@ -28,11 +28,11 @@ extern "C" int stan_hip_lab_placement_map(stan_ctx *ctx, stan_matrix *K, int32_t
         cand.push_back(q);
         if (addr) addr[t] = (uint64_t)(uintptr_t)q;
         float f = 0;
-        STANCHK(stan_spmv_probe_range(ctx, K, (const double *)q, 0, K->nslices, 10, &f));
+        STANCHK(stan_spmv_probe_range(ctx, K, (const double *)q, 0, K->nslices, 10, &f, 9));
         ms[t * per] = f;
         for (int g = 0; g < nseg; g++) {
             const int32_t s0 = (int32_t)((int64_t)K->nslices * g / nseg), s1 = (int32_t)((int64_t)K->nslices * (g + 1) / nseg);
-            STANCHK(stan_spmv_probe_range(ctx, K, (const double *)q, s0, s1, 10, &f));
+            STANCHK(stan_spmv_probe_range(ctx, K, (const double *)q, s0, s1, 10, &f, 9));
             ms[t * per + 1 + g] = f;
             const size_t b0 = (size_t)sp[s0] * 9 * 64 * 8, b1 = (size_t)sp[s1] * 9 * 64 * 8;
             STANCHK(stan_probe_block(ctx, (const char *)q + b0, b1 - b0, &f));
@@ -53,5 +53,34 @@ extern "C" int stan_hip_lab_placement_map(stan_ctx *ctx, stan_matrix *K, int32_t
         stan_dfree(ctx, K->d_vals);
         K->d_vals = (double *)cand[pick];
     }
+    return STAN_OK;
+}
+
+// Whole-SpMV time of each candidate block under several kernel variants (walk order / mapping):
+// is a slow block slow for every access order, or only for the lockstep front-to-back walk?
+// ms [ntries * nvar].  All candidates are freed afterwards (candidate 0 is K's own block).
+extern "C" int stan_hip_lab_placement_variants(stan_ctx *ctx, stan_matrix *K, int32_t ntries, int32_t nvar,
+                                               const int32_t *variants, int32_t reps, double *ms) {
+    if (!ctx || !K || !ms || !variants || ntries < 1 || ntries > 16 || nvar < 1 || K->ctx != ctx) return STAN_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)K->nslots * 9 * 64 * 8;
+    std::vector<void *> cand;
+    for (int t = 0; t < ntries; t++) {
+        void *q = nullptr;
+        if (t == 0) q = K->d_vals;
+        else if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        if (t > 0) HIPCHK(ctx, hipMemcpyAsync(q, K->d_vals, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        cand.push_back(q);
+    }
+    for (int round = 0; round < 2; round++)   // second round overwrites the first: warm
+        for (size_t t = 0; t < cand.size(); t++)
+            for (int v = 0; v < nvar; v++) {
+                float f = 0;
+                STANCHK(stan_spmv_probe_range(ctx, K, (const double *)cand[t], 0, K->nslices, reps, &f, variants[v]));
+                ms[t * nvar + v] = f;
+            }
+    for (size_t t = cand.size(); t < (size_t)ntries; t++) for (int v = 0; v < nvar; v++) ms[t * nvar + v] = -1;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t t = 1; t < cand.size(); t++) hipFree(cand[t]);
     return STAN_OK;
 }

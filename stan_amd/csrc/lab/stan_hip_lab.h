@@ -20,6 +20,11 @@ int stan_hip_csr_spmv_bench(stan_ctx *ctx, stan_matrix *K, int32_t reps, double 
  * keep_fastest: 0 leave K where it is, 1 move it to the fastest candidate, 2 to the slowest. */
 int stan_hip_lab_placement_map(stan_ctx *ctx, stan_matrix *K, int32_t ntries, int32_t nseg,
                                int32_t keep_fastest, double *ms, uint64_t *addr);
+/* Whole-SpMV time of each of ntries candidate blocks under each of nvar kernel variants
+ * (cg.hip: 0 plain, 9 default, 13 default without the nt hint, 14 odd slices walk backwards,
+ * 15 rotated start, 16 hashed start): ms [ntries * nvar]. */
+int stan_hip_lab_placement_variants(stan_ctx *ctx, stan_matrix *K, int32_t ntries, int32_t nvar,
+                                    const int32_t *variants, int32_t reps, double *ms);
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,7 @@ E_HIP, E_ARG, E_ALLOC, E_DETJ, E_DOF_LAYOUT, E_VALENCE, E_COMM, E_UNSUPPORTED = 
     -1, -2, -3, -4, -5, -6, -7, -8)
 
 EXPORTS = [
-    "stan_hip_init", "stan_hip_destroy", "stan_hip_last_error", "stan_hip_last_bad_element",
+    "stan_hip_init", "stan_hip_init_multi", "stan_hip_destroy", "stan_hip_last_error", "stan_hip_last_bad_element",
     "stan_hip_set_stream", "stan_hip_comm_unique_id", "stan_hip_comm_init",
     "stan_hip_assemble_hex8", "stan_hip_assemble_hex8_dev", "stan_hip_matrix_free",
     "stan_hip_cg_solve", "stan_hip_cg_solve_dev", "stan_hip_matrix_info", "stan_hip_ke_hex8",
@@ -38,7 +38,7 @@ EXPORTS = [
     "stan_hip_matrix_plan", "stan_hip_spmv_local",
 ]
 # only in the lab build (stan_amd/csrc/lab/stan_hip_lab.h, selected with STAN_HIP_LIB)
-LAB_EXPORTS = ["stan_hip_csr_spmv_bench", "stan_hip_lab_placement_map"]
+LAB_EXPORTS = ["stan_hip_csr_spmv_bench", "stan_hip_lab_placement_map", "stan_hip_lab_placement_variants"]
 
 
 class MatrixInfo(C.Structure):
@@ -104,10 +104,16 @@ def _dev(p, t):
 
 
 class Context:
-    def __init__(self, device=0):
+    def __init__(self, device=0, devices=None):
+        """device: one GPU.  devices=[...]: ONE handle driving several GPUs from this process
+        (stan_hip_init_multi; ordinals may repeat only with the test transport tests/fake_rccl)."""
         self.lib = load()
         h = C.c_void_p()
-        rc = self.lib.stan_hip_init(C.c_int(device), C.byref(h))
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            rc = self.lib.stan_hip_init_multi(C.c_int(len(devices)), arr, C.byref(h))
+        else:
+            rc = self.lib.stan_hip_init(C.c_int(device), C.byref(h))
         if rc != 0:
             self.lib.stan_hip_last_error.argtypes = [C.c_void_p]
             msg = self.lib.stan_hip_last_error(None)

@@ -7,7 +7,9 @@
 // (SolverFunctions.cs:18-20 throws when stdout is redirected) and no 10 s sleep at exit
 // (Solver.cs:67-68).  LinSolver "Cholesky"/"LU" (SolverFunctions.cs:332-516) are outside the
 // hot path: the driver reports them as unsupported instead of silently using CG.
-// Extra switches (never stored in the STdb): --device N, --mixed, --fixed48, --no-merit-stop, --packed,
+// Extra switches (never stored in the STdb): --device N, --gpus N (devices 0..N-1) or --devices a,b,c
+// (several GPUs from this ONE process: stan_hip_init_multi, rows of K sharded, RCCL inside the CG),
+// --mixed, --fixed48, --no-merit-stop, --packed,
 // --json (one JSON line with sizes, iterations, phase times and the SpMV's HBM rate).
 #include <chrono>
 #include <cstdio>
@@ -34,8 +36,20 @@ int main(int argc, char **argv) {
     std::string path;
     int device = 0, precision = STAN_PREC_FP64;
     bool merit_stop = true, packed = false, json = false;
+    std::vector<int> devices;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) {
+            devices.clear();
+            for (int d = 0, n = atoi(argv[++i]); d < n; d++) devices.push_back(d);
+        } else if (!strcmp(argv[i], "--devices") && i + 1 < argc) {
+            devices.clear();
+            for (const char *p = argv[++i]; *p;) {
+                devices.push_back(atoi(p));
+                while (*p && *p != ',') p++;
+                if (*p == ',') p++;
+            }
+        }
         else if (!strcmp(argv[i], "--mixed")) precision = STAN_PREC_MIXED;
         else if (!strcmp(argv[i], "--fixed48")) precision = STAN_PREC_FIXED48;
         else if (!strcmp(argv[i], "--no-merit-stop")) merit_stop = false;
@@ -44,11 +58,12 @@ int main(int argc, char **argv) {
         else path = argv[i];
     }
     if (path.empty()) {  // Path = path[0] -> IndexOutOfRangeException in the reference
-        fprintf(stderr, "usage: stan_solver [--device N] [--mixed|--fixed48] [--no-merit-stop] [--packed] [--json] <model.STdb>\n");
+        fprintf(stderr, "usage: stan_solver [--device N | --gpus N | --devices a,b,..] [--mixed|--fixed48] "
+                        "[--no-merit-stop] [--packed] [--json] <model.STdb>\n");
         return 2;
     }
     SolverOptions opt;
-    opt.device = device; opt.precision = precision; opt.merit_stop = merit_stop; opt.profile = json;
+    opt.device = device; opt.devices = devices; opt.precision = precision; opt.merit_stop = merit_stop; opt.profile = json;
     SolverFunctions Functions(opt);  // Solver.cs:16
     Functions.Welcome_Messsage();
 
@@ -105,10 +120,10 @@ int main(int argc, char **argv) {
             stan_profile pr;
             stan_hip_get_profile(K.ctx, &pr);
             const double spmv_ms = pr.spmv_launches ? pr.spmv_ms_total / (double)pr.spmv_launches : 0;
-            printf("{\"n_dof\": %d, \"n_reduced\": %lld, \"blocks_3x3\": %lld, \"cg_iterations\": %d, "
+            printf("{\"n_gpus\": %d, \"n_dof\": %d, \"n_reduced\": %lld, \"blocks_3x3\": %lld, \"cg_iterations\": %d, "
                    "\"termination_type\": %d, \"rel_residual\": %.3e, \"t_assembly_s\": %.4f, \"t_cg_s\": %.4f, "
                    "\"spmv_ms\": %.4f, \"spmv_GBs\": %.1f, \"hbm_frac\": %.3f}\n",
-                   DB.nDOF, (long long)minfo.n_reduced, (long long)minfo.n_blocks, Functions.last_iterations,
+                   devices.size() > 1 ? (int)devices.size() : 1, DB.nDOF, (long long)minfo.n_reduced, (long long)minfo.n_blocks, Functions.last_iterations,
                    Functions.last_termination_type, Functions.last_rel_residual, Functions.last_assembly_s,
                    Functions.last_cg_s, spmv_ms, spmv_ms > 0 ? pr.spmv_bytes / spmv_ms / 1e6 : 0.0,
                    spmv_ms > 0 ? pr.spmv_bytes / spmv_ms / 1e6 / 8000.0 : 0.0);

@@ -35,7 +35,11 @@ void SolverFunctions::ParallelAssembly_K(const Database &DB, const std::vector<i
     fflush(stdout);
     std::string err;
     if (Flatten(DB, &K->flat, &err)) throw std::runtime_error(err);
-    if (stan_hip_init(opt_.device, &K->ctx)) throw std::runtime_error(stan_hip_last_error(nullptr));
+    // several GPUs: still ONE process and the same calls -- the handle fans them out (stan_hip.h)
+    const int rc_init = opt_.devices.size() > 1
+                            ? stan_hip_init_multi((int)opt_.devices.size(), opt_.devices.data(), &K->ctx)
+                            : stan_hip_init(opt_.devices.empty() ? opt_.device : opt_.devices[0], &K->ctx);
+    if (rc_init) throw std::runtime_error(stan_hip_last_error(nullptr));
     stan_hip_set_option(K->ctx, STAN_OPT_CG_MERIT_STOP, opt_.merit_stop ? 1 : 0);
     if (opt_.profile) stan_hip_set_profiling(K->ctx, 1);
     const FlatModel &f = K->flat;

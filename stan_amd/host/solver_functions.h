@@ -35,6 +35,7 @@ class SparseMatrixHandle {
 
 struct SolverOptions {  // extras of the native driver, never stored in the STdb
     int device = 0;
+    std::vector<int> devices;   // --gpus N / --devices a,b,...: one process drives them all (stan_hip_init_multi)
     int precision = STAN_PREC_FP64;
     bool merit_stop = true;
     bool profile = false;
