@@ -44,9 +44,10 @@ def effective_cores():
     return max(1, n)
 
 
-def cpu_baseline(n, eps):
+def cpu_baseline(n, eps, return_u=False):
     """Oracle = port of the reference algorithm (parallel K_e, serial locked scatter into a
-    hash table, serial symmetric-upper CG), timed on this host's cores."""
+    hash table, serial symmetric-upper CG), timed on this host's cores.  return_u: also the
+    oracle's displacements and report (tools/cpu_sizes.py compares the GPU's with them)."""
     from oracle import pyoracle as O
     from stan_amd import problem
     job = problem.cube_job(n)
@@ -72,6 +73,8 @@ def cpu_baseline(n, eps):
     base_all = {"value": job.n_dof / ((t1 - t0) + (t4 - t3)), "unit": "DOF/s", "cores": allc,
                 "kind": "port", "sample": "same sample, CG matrix-vector product on %d OpenMP "
                 "threads: CG %.2f s (%d its)" % (allc, t4 - t3, rep2["iterations"])}
+    if return_u:
+        return base, base_all, U, rep
     return base, base_all
 
 

@@ -22,6 +22,7 @@ extern "C" {
 #define STAN_HOST_E_DISCONNECTED (-21) /* Database.cs:218 NextNode[index2] out of range          */
 #define STAN_HOST_E_IO (-22)
 #define STAN_HOST_E_FORMAT (-23)
+#define STAN_HOST_E_MEMORY (-24)       /* the skyline profile does not fit (direct solver)       */
 
 /* Database.AssignDOF (Database.cs:140-234): BFS node numbering, bit-exact with the
  * reference's neighbour order (element iteration order x NList order, first occurrence).
@@ -48,6 +49,22 @@ int stan_host_load_vector(int64_t n_dof, const int32_t *node_dof, const int32_t 
  * disp_out[i*3+j] = U_full[node_dof[i*3+j]], U_full = 0 on fixed DOFs. */
 int stan_host_nodal_displacements(int64_t n_nodes, const int32_t *node_dof, const int32_t *red,
                                   const double *U, double *disp_out);
+
+/* ---- direct solvers: CPU fallback for Analysis.LinSolver = "Cholesky" / "LU" -----------------
+ * (SolverFunctions.cs:332-444, 446-516; not on the GPU hot path).  K = the reduced upper-triangle
+ * CRS the reference's alglib.sparsematrix holds: rowptr [n+1], col/val [nnz], col >= row
+ * (stan_hip_matrix_to_csr with upper_only = 1).  b, x [n].
+ * cholesky: in-place skyline A = U^T U without a profile-reducing permutation, like
+ * alglib.sparsecholeskyskyline; *termination_type = 1 and x = solution, or -3 and x = 0 when the
+ * matrix is not positive definite (sparsecholeskysolvesks' report).  *profile_entries (may be NULL)
+ * = doubles in the skyline; more than 2^32 of them is STAN_HOST_E_MEMORY.
+ * lu: what the reference's LinearSolver_LU returns -- alglib.sparselu is handed the stored UPPER
+ * triangle as a general matrix, so x solves triu(K) x = b (a reference quirk, kept). */
+int stan_host_cholesky_skyline_solve(int64_t n, const int64_t *rowptr, const int32_t *col,
+                                     const double *val, const double *b, double *x,
+                                     int32_t *termination_type, int64_t *profile_entries);
+int stan_host_lu_upper_solve(int64_t n, const int64_t *rowptr, const int32_t *col, const double *val,
+                             const double *b, double *x, int32_t *termination_type);
 
 /* ---- row partition + halo plan of the sharded CG (no counterpart in the reference) -----------
  * Block rows = nodes in reference DOF order.  row_starts [nranks+1]. */

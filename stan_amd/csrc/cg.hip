@@ -78,16 +78,34 @@ __device__ __forceinline__ void st_agent(double *p, double v) {
 __device__ __forceinline__ double ld_agent(const double *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// sum_i partial[i*nv + j] over np blocks by one 256-thread block, fixed order; valid in thread 0
-__device__ __forceinline__ double sum_partials(const double *partial, int np, int nv, int j, double *sh) {
-    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int i = threadIdx.x;
-    for (; i + 7 * 256 < np; i += 8 * 256) {
+// r[j] = sum_i partial[i*NV + j] over np blocks by one 256-thread block, all NV sums in ONE pass
+// over the partials (their loads overlap), fixed order; valid in thread 0
+template <int NV>
+__device__ __forceinline__ void sum_partials(const double *partial, int np, double *sh, double r[NV]) {
+    constexpr int W = 16 / NV;   // loads in flight per thread: the last block's latency adds to the kernel
+    double a[NV][W];
 #pragma unroll
-        for (int q = 0; q < 8; q++) a[q] += ld_agent(partial + (int64_t)(i + q * 256) * nv + j);
+    for (int j = 0; j < NV; j++)
+#pragma unroll
+        for (int q = 0; q < W; q++) a[j][q] = 0;
+    int i = threadIdx.x;
+    for (; i + (W - 1) * 256 < np; i += W * 256) {
+#pragma unroll
+        for (int q = 0; q < W; q++)
+#pragma unroll
+            for (int j = 0; j < NV; j++) a[j][q] += ld_agent(partial + (int64_t)(i + q * 256) * NV + j);
     }
-    for (; i < np; i += 256) a[0] += ld_agent(partial + (int64_t)i * nv + j);
-    return block_sum(((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])), sh);
+    for (; i < np; i += 256)
+#pragma unroll
+        for (int j = 0; j < NV; j++) a[j][0] += ld_agent(partial + (int64_t)i * NV + j);
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+#pragma unroll
+        for (int w = W / 2; w > 0; w >>= 1)   // fixed pairwise tree
+#pragma unroll
+            for (int q = 0; q < w; q++) a[j][q] += a[j][q + w];
+        r[j] = block_sum(a[j][0], sh);
+    }
 }
 // Tickets are two-level: block b first counts itself into sub-counter b % FOLD_SUB (a 128-B line
 // of its own), the last arrival of a sub-counter counts that sub-counter into the top counter, the
@@ -126,8 +144,7 @@ __device__ __forceinline__ bool fold_arrive(const fold_args &f, int *sh_last) {
 template <int NV>
 __device__ __forceinline__ void fold_finish(const fold_args &f, const double *partial, double *sh) {
     double r[NV];
-#pragma unroll
-    for (int j = 0; j < NV; j++) r[j] = sum_partials(partial, f.np, NV, j, sh);
+    sum_partials<NV>(partial, f.np, sh, r);
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int j = 0; j < NV; j++) f.out[j] = r[j];  // read by the NEXT kernel: a plain store will do
@@ -248,13 +265,15 @@ k_init(int64_t n3, int64_t dof0, const int32_t *red, const double *F, const doub
 
 // out[j] = sum_i partial[i*nv + j]: the unfolded form of the reduction (one 256-thread block, the
 // same summation order as fold_finish: both paths give the same bits)
+template <int NV>
 __global__ void __launch_bounds__(256)
-k_reduce(const double *partial, int np, int nv, double *out) {
+k_reduce(const double *partial, int np, double *out) {
     __shared__ double sh[4];
-    for (int j = 0; j < nv; j++) {
-        const double t = sum_partials(partial, np, nv, j, sh);
-        if (threadIdx.x == 0) out[j] = t;
-    }
+    double r[NV];
+    sum_partials<NV>(partial, np, sh, r);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int j = 0; j < NV; j++) out[j] = r[j];
 }
 
 // after the b^.b^ reduction: bnorm, first residual test, rho, prevmf
@@ -1030,8 +1049,9 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         return fold_args{foldr ? tick + FOLD_WORDS * which : nullptr, 0, 0, out};
     };
     auto reduce_if_unfolded = [&](int np, int nv, double *out) {
-        if (!foldr && np > 0)
-            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st_, partial, np, nv, out);
+        if (foldr || np <= 0) return;
+        if (nv == 2) hipLaunchKernelGGL(k_reduce<2>, dim3(1), dim3(256), 0, st_, partial, np, out);
+        else hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, np, out);
     };
 
     const unsigned vg = vec_grid(n3);
@@ -1097,8 +1117,11 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             if (parts == 0) folded = false;
         }
         if (dot && !folded) {
-            if (parts > 0) { hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st_, partial, (int)parts, dot, out); n_launch++; }
-            else HIPCHK(ctx, hipMemsetAsync(out, 0, 8 * dot, st_));   // a rank that owns no rows
+            if (parts > 0) {
+                if (dot == 2) hipLaunchKernelGGL(k_reduce<2>, dim3(1), dim3(256), 0, st_, partial, (int)parts, out);
+                else hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, (int)parts, out);
+                n_launch++;
+            } else HIPCHK(ctx, hipMemsetAsync(out, 0, 8 * dot, st_));   // a rank that owns no rows
         }
         if (ctx->profiling) hipEventRecord(spmv_ev.back(), st_);
         return STAN_OK;
@@ -1138,7 +1161,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             if (parts == 0) folded = false;
         }
         if (!folded) {
-            if (parts > 0) { hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st_, partial, (int)parts, 1, out); n_launch++; }
+            if (parts > 0) { hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, (int)parts, out); n_launch++; }
             else HIPCHK(ctx, hipMemsetAsync(out, 0, 8, st_));
         }
         if (ctx->profiling) hipEventRecord(spmv2_ev.back(), st_);

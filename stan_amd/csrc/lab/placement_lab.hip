@@ -3,6 +3,7 @@
 // copies the values into each, and times (a) the whole SpMV (b) the SpMV restricted to each of
 // `nseg` consecutive slice ranges (c) a plain front-to-back read of each segment's bytes.
 // ms [ntries * (1 + 2*nseg)]: per candidate {whole, seg SpMV x nseg, seg read x nseg}.
+#include <chrono>
 #include <vector>
 
 #include "../internal.h"
@@ -82,5 +83,73 @@ extern "C" int stan_hip_lab_placement_variants(stan_ctx *ctx, stan_matrix *K, in
     for (size_t t = cand.size(); t < (size_t)ntries; t++) for (int v = 0; v < nvar; v++) ms[t * nvar + v] = -1;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (size_t t = 1; t < cand.size(); t++) hipFree(cand[t]);
+    return STAN_OK;
+}
+
+// ---- what distinguishes a slow block?  page-touch probes + allocation strategies ------------------
+namespace {
+// one 8-B load per `stride` bytes: little data, one translation per page of that size
+__global__ void k_touch(const char *p, size_t bytes, size_t stride, size_t phase, double *sink) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t off = i * stride + phase;
+    if (off + 8 > bytes) return;
+    const double v = __builtin_nontemporal_load((const double *)(p + off));
+    if (v == 0.1234567890123) sink[0] = v;
+}
+int touch_ms(stan_ctx *ctx, const void *p, size_t bytes, size_t stride, float *ms) {
+    const size_t n = bytes / stride;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    event_bag ev;
+    hipEvent_t a = ev.make(), b = ev.make();
+    const int reps = stride >= (1u << 20) ? 64 : 8;
+    for (int r = 0; r < reps + 1; r++) {
+        if (r == 1) hipEventRecord(a, ctx->stream);
+        hipLaunchKernelGGL(k_touch, dim3(grid ? grid : 1), dim3(256), 0, ctx->stream, (const char *)p, bytes, stride,
+                           (size_t)(r * 4096 % (stride > 4096 ? stride : 4096)), (double *)(ctx->d_status + SS_AUX));
+    }
+    hipEventRecord(b, ctx->stream);
+    HIPCHK(ctx, hipEventSynchronize(b));
+    hipEventElapsedTime(ms, a, b);
+    *ms /= reps;
+    return STAN_OK;
+}
+}  // namespace
+
+// strategy per candidate: 0 hipMalloc(bytes), 1 hipMalloc(next power of two), 2 hipMalloc(bytes
+// rounded up to 1 GiB), 3 hipExtMallocWithFlags(hipDeviceMallocContiguous? -> see code), 4 = K's own block.
+// out [n * 5]: whole-SpMV ms, touch ms at 4 KiB / 64 KiB / 2 MiB stride, allocation ms.
+extern "C" int stan_hip_lab_placement_alloc(stan_ctx *ctx, stan_matrix *K, int32_t n, const int32_t *strategy,
+                                            double *out, uint64_t *addr) {
+    if (!ctx || !K || !out || !strategy || n < 1 || n > 32 || K->ctx != ctx) return STAN_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)K->nslots * 9 * 64 * 8;
+    std::vector<void *> cand((size_t)n, nullptr);
+    for (int t = 0; t < n; t++) {
+        size_t req = bytes;
+        if (strategy[t] == 1) { req = 1; while (req < bytes) req <<= 1; }
+        if (strategy[t] == 2) req = (bytes + ((size_t)1 << 30) - 1) >> 30 << 30;
+        void *q = nullptr;
+        event_bag ev;
+        const auto t0 = std::chrono::steady_clock::now();
+        hipError_t e = hipSuccess;
+        if (strategy[t] == 4) q = K->d_vals;
+        else if (strategy[t] == 3) e = hipExtMallocWithFlags(&q, req, hipDeviceMallocUncached);
+        else e = hipMalloc(&q, req);
+        const double alloc_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (e != hipSuccess) { (void)hipGetLastError(); for (int v = 0; v < 5; v++) out[t * 5 + v] = -1; continue; }
+        cand[(size_t)t] = q;
+        if (addr) addr[t] = (uint64_t)(uintptr_t)q;
+        if (q != K->d_vals) HIPCHK(ctx, hipMemcpyAsync(q, K->d_vals, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        float f = 0;
+        STANCHK(stan_spmv_probe_range(ctx, K, (const double *)q, 0, K->nslices, 10, &f, 9));
+        out[t * 5] = f;
+        STANCHK(touch_ms(ctx, q, bytes, 4096, &f)); out[t * 5 + 1] = f;
+        STANCHK(touch_ms(ctx, q, bytes, 65536, &f)); out[t * 5 + 2] = f;
+        STANCHK(touch_ms(ctx, q, bytes, (size_t)2 << 20, &f)); out[t * 5 + 3] = f;
+        out[t * 5 + 4] = alloc_ms;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int t = 0; t < n; t++)
+        if (cand[(size_t)t] && cand[(size_t)t] != K->d_vals) hipFree(cand[(size_t)t]);
     return STAN_OK;
 }

@@ -25,6 +25,12 @@ int stan_hip_lab_placement_map(stan_ctx *ctx, stan_matrix *K, int32_t ntries, in
  * 15 rotated start, 16 hashed start): ms [ntries * nvar]. */
 int stan_hip_lab_placement_variants(stan_ctx *ctx, stan_matrix *K, int32_t ntries, int32_t nvar,
                                     const int32_t *variants, int32_t reps, double *ms);
+/* What distinguishes a slow block: per candidate (allocation strategy 0 hipMalloc(bytes), 1 next
+ * power of two, 2 rounded up to 1 GiB, 3 hipExtMallocWithFlags(uncached), 4 K's own block) the
+ * whole-SpMV ms, page-touch ms at 4 KiB / 64 KiB / 2 MiB stride (one load per page of that size:
+ * translation cost, hardly any data) and the allocation's wall ms: out [n * 5]. */
+int stan_hip_lab_placement_alloc(stan_ctx *ctx, stan_matrix *K, int32_t n, const int32_t *strategy,
+                                 double *out, uint64_t *addr);
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstan_host.so")
 
 EXPORTS = ["stan_host_assign_dof", "stan_host_dof_reduction", "stan_host_load_vector",
-           "stan_host_nodal_displacements", "stan_host_partition_rows", "stan_host_partition_plan"]
+           "stan_host_nodal_displacements", "stan_host_partition_rows", "stan_host_partition_plan",
+           "stan_host_cholesky_skyline_solve", "stan_host_lu_upper_solve"]
 
 _lib = None
 
@@ -89,6 +90,40 @@ def nodal_displacements(node_dof, red, U):
     if rc:
         raise StanHostError(rc, "nodal_displacements")
     return out
+
+
+def cholesky_skyline_solve(rowptr, col, val, b):
+    """LinearSolver_Cholesky (SolverFunctions.cs:332-444) on the reduced upper CRS: returns
+    (x, terminationtype, profile_entries); terminationtype -3 and x = 0 when K is not SPD."""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    val = np.ascontiguousarray(val, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    n = rowptr.shape[0] - 1
+    x = np.zeros(n)
+    t, prof = C.c_int32(0), C.c_int64(0)
+    rc = load().stan_host_cholesky_skyline_solve(C.c_int64(n), _p(rowptr, C.c_int64), _p(col, C.c_int32),
+                                                 _p(val, C.c_double), _p(b, C.c_double), _p(x, C.c_double),
+                                                 C.byref(t), C.byref(prof))
+    if rc:
+        raise StanHostError(rc, "cholesky_skyline_solve")
+    return x, t.value, prof.value
+
+
+def lu_upper_solve(rowptr, col, val, b):
+    """LinearSolver_LU as the reference computes it (SolverFunctions.cs:446-516): triu(K) x = b."""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    val = np.ascontiguousarray(val, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    n = rowptr.shape[0] - 1
+    x = np.zeros(n)
+    t = C.c_int32(0)
+    rc = load().stan_host_lu_upper_solve(C.c_int64(n), _p(rowptr, C.c_int64), _p(col, C.c_int32),
+                                         _p(val, C.c_double), _p(b, C.c_double), _p(x, C.c_double), C.byref(t))
+    if rc:
+        raise StanHostError(rc, "lu_upper_solve")
+    return x, t.value
 
 
 def partition_plan(node_index, conn, nranks, rank):

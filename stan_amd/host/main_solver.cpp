@@ -5,8 +5,8 @@
 // overwrite the input file with the results (Result_StepNo = 1).
 // Differences kept on purpose: no console-window sizing in the banner
 // (SolverFunctions.cs:18-20 throws when stdout is redirected) and no 10 s sleep at exit
-// (Solver.cs:67-68).  LinSolver "Cholesky"/"LU" (SolverFunctions.cs:332-516) are outside the
-// hot path: the driver reports them as unsupported instead of silently using CG.
+// (Solver.cs:67-68).  LinSolver "Cholesky"/"LU" (SolverFunctions.cs:332-516) are outside the GPU
+// hot path: K is exported as the upper CRS the reference holds and solved on the CPU (direct.cpp).
 // Extra switches (never stored in the STdb): --device N, --gpus N (devices 0..N-1) or --devices a,b,c
 // (several GPUs from this ONE process: stan_hip_init_multi, rows of K sharded, RCCL inside the CG),
 // --mixed, --fixed48, --no-merit-stop, --packed,
@@ -102,8 +102,12 @@ int main(int argc, char **argv) {
             U = Functions.LinearSolver_CG(K, F, DB.AnalysisLib);
             printf("   CG iterations: %d, scaled relative residual %.3e\n", Functions.last_iterations,
                    Functions.last_rel_residual);
-        } else if (ls == "Cholesky" || ls == "LU") {
-            return fail("solver selection", "LinSolver '" + ls + "' is a direct solver outside the GPU hot path");
+        } else if (ls == "Cholesky") {  // Solver.cs:163: CPU fallback, outside the GPU hot path (direct.cpp)
+            if (devices.size() > 1) return fail("solver selection", "the direct solvers run on one device's export of K: drop --gpus/--devices");
+            U = Functions.LinearSolver_Cholesky(K, F);
+        } else if (ls == "LU") {        // Solver.cs:164
+            if (devices.size() > 1) return fail("solver selection", "the direct solvers run on one device's export of K: drop --gpus/--devices");
+            U = Functions.LinearSolver_LU(K, F);
         }  // any other string: the reference leaves U = 0 (Solver.cs:160-164)
 
         // U = Include_BC_DOF(U, nDOF_reduction); node.dU_buffer[d] = U[DOF[d]] (Solver.cs:168-178)

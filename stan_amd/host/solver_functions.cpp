@@ -1,6 +1,8 @@
 // solver_functions.cpp -- see solver_functions.h.
 #include "solver_functions.h"
 
+#include "../../include/stan_host.h"
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -69,6 +71,66 @@ std::vector<double> SolverFunctions::LinearSolver_CG(SparseMatrixHandle &K, cons
     printf(type == 1 || type == 7 ? "  NORMAL " : "  ERROR ");  // SolverFunctions.cs:323-324
     printf(" (type %d) in %.2fs\n", type, last_cg_s);          // :325-327
     return U;                                                    // :329, returned regardless
+}
+
+// alglib.sparsematrix as the reference holds it after ParallelAssembly_K: reduced upper CRS
+static void ExportUpperCrs(SparseMatrixHandle &K, std::vector<int64_t> *rowptr, std::vector<int32_t> *col,
+                           std::vector<double> *val) {
+    int64_t nnz = 0;
+    if (stan_hip_matrix_to_csr(K.ctx, K.K, 1, &nnz, nullptr, nullptr, nullptr))
+        throw std::runtime_error(stan_hip_last_error(K.ctx));
+    stan_matrix_info info;
+    stan_hip_matrix_info(K.K, &info);
+    rowptr->assign((size_t)info.n_reduced + 1, 0);
+    col->assign((size_t)nnz, 0);
+    val->assign((size_t)nnz, 0.0);
+    if (stan_hip_matrix_to_csr(K.ctx, K.K, 1, &nnz, rowptr->data(), col->data(), val->data()))
+        throw std::runtime_error(stan_hip_last_error(K.ctx));
+}
+
+std::vector<double> SolverFunctions::LinearSolver_Cholesky(SparseMatrixHandle &K, const std::vector<double> &F) const {
+    const auto t0 = clk::now();
+    puts("   Linear system K*U=F:");                       // SolverFunctions.cs:385
+    std::vector<int64_t> rp; std::vector<int32_t> ci; std::vector<double> cv;
+    ExportUpperCrs(K, &rp, &ci, &cv);                      // sparseconverttosks works on the same triangle
+    printf("    - Cholesky decomposition:");               // :388
+    fflush(stdout);
+    std::vector<double> U(F.size(), 0.0);
+    int32_t type = 0;
+    int64_t profile = 0;
+    const int rc = stan_host_cholesky_skyline_solve((int64_t)F.size(), rp.data(), ci.data(), cv.data(), F.data(),
+                                                    U.data(), &type, &profile);
+    if (rc == STAN_HOST_E_MEMORY)
+        throw std::runtime_error("LinearSolver_Cholesky: the skyline profile (" + std::to_string(profile) +
+                                 " entries) does not fit in memory; use LinSolver = CG");
+    if (rc) throw std::runtime_error("LinearSolver_Cholesky: bad matrix (code " + std::to_string(rc) + ")");
+    puts(type > 0 ? "   Done" : "   ERROR");                 // :390-397
+    printf("    - Solving:");                               // :426
+    printf(type > 0 ? "                  NORMAL termination" : "                  ERROR termination");
+    printf(" (type %d)\n", type);                           // :430-438
+    SolverFunctions *self = const_cast<SolverFunctions *>(this);
+    self->last_termination_type = type; self->last_iterations = 0; self->last_rel_residual = 0;
+    self->last_cg_s = secs(t0);
+    printf("    Total time to solve K*U=F:  %.2fs\n", last_cg_s);   // :441
+    return U;
+}
+
+std::vector<double> SolverFunctions::LinearSolver_LU(SparseMatrixHandle &K, const std::vector<double> &F) const {
+    const auto t0 = clk::now();
+    printf("   Solving linear system...   ");               // SolverFunctions.cs:449
+    fflush(stdout);
+    std::vector<int64_t> rp; std::vector<int32_t> ci; std::vector<double> cv;
+    ExportUpperCrs(K, &rp, &ci, &cv);
+    std::vector<double> U(F.size(), 0.0);
+    int32_t type = 0;
+    if (int rc = stan_host_lu_upper_solve((int64_t)F.size(), rp.data(), ci.data(), cv.data(), F.data(), U.data(), &type))
+        throw std::runtime_error("LinearSolver_LU: bad matrix (code " + std::to_string(rc) + ")");
+    SolverFunctions *self = const_cast<SolverFunctions *>(this);
+    self->last_termination_type = type; self->last_iterations = 0; self->last_rel_residual = 0;
+    self->last_cg_s = secs(t0);
+    printf(type > 0 ? "NORMAL TERMINATION" : "ERROR TERMINATION");   // :506-507
+    printf(" (type %d) in %.2fs\n", type, last_cg_s);               // :508-510
+    return U;
 }
 
 void SolverFunctions::Recovery_Stress(SparseMatrixHandle &K, const std::vector<double> &dU,

@@ -55,6 +55,11 @@ class SolverFunctions {
     // U = LinearSolver_CG(K, F, AnalysisLib)
     std::vector<double> LinearSolver_CG(SparseMatrixHandle &K, const std::vector<double> &F,
                                         const Analysis &AnalysisLib) const;
+    // U = LinearSolver_Cholesky(K, F) / LinearSolver_LU(K, F) (SolverFunctions.cs:332-516): the
+    // direct solvers are outside the GPU hot path -- K is exported as the reduced upper CRS alglib
+    // would hold and factorised on the CPU (libstan_host.so, direct.cpp)
+    std::vector<double> LinearSolver_Cholesky(SparseMatrixHandle &K, const std::vector<double> &F) const;
+    std::vector<double> LinearSolver_LU(SparseMatrixHandle &K, const std::vector<double> &F) const;
     // Element.Recovery_Stress + Update_StrainStress for every element (Solver.cs:183-210)
     void Recovery_Stress(SparseMatrixHandle &K, const std::vector<double> &nodal_dU,
                          std::vector<double> *strain, std::vector<double> *stress) const;

@@ -12,7 +12,7 @@ sizes = [int(a) for a in sys.argv[1:]] or [24, 100]
 ctx = hip.Context(0)
 ctx.set_option(hip.OPT_CG_MERIT_STOP, 0)
 for n in sizes:
-    base, base_all = bench.cpu_baseline(n, 1e-8)
+    base, base_all, Uo, repo = bench.cpu_baseline(n, 1e-8, return_u=True)
     job = problem.cube_job(n)
     best = None
     for _ in range(2):
@@ -24,5 +24,9 @@ for n in sizes:
         best = dt if best is None else min(best, dt)
     print(json.dumps({"n": n, "n_dof": job.n_dof, "cpu_port": base, "cpu_port_all_cores": base_all,
                       "gpu_s_host_pointers": best, "gpu_DOF_per_s": job.n_dof / best,
-                      "gpu_iterations": rep["iterations"],
+                      "gpu_iterations": rep["iterations"], "oracle_iterations": repo["iterations"],
+                      "gpu_termination_type": rep["terminationtype"], "oracle_termination_type": repo["terminationtype"],
+                      # parity at this size: same seeded job, same mode (merit stop off, eps 1e-8)
+                      "max_abs_U_diff_over_max_abs_U": float(np.abs(U - Uo).max() / np.abs(Uo).max()),
+                      "kappa_eps_bound": 12.7 * n * n * 1e-8,
                       "speedup_vs_reference_like_port": job.n_dof / best / base["value"]}), flush=True)
