@@ -117,7 +117,7 @@ def main():
                     help="STAN_OPT_CG_SINGLE_REDUCE: Chronopoulos-Gear loop (not the oracle's recurrences)")
     ap.add_argument("--cpu-n", type=int, default=56, help="cube edge of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--placement-tries", type=int, default=4,
+    ap.add_argument("--placement-tries", type=int, default=24,
                     help="STAN_OPT_PLACEMENT_TRIES: allocate the value array of K by trial in the first "
                          "(warm-up) assembly; 1 = plain allocation (the library default)")
     args = ap.parse_args()
@@ -156,7 +156,7 @@ def main():
         dist.broadcast(uid, 0)
         ctx.comm_init(rank, world, bytes(uid.cpu().tolist()))
     ctx.set_option(hip.OPT_CG_MERIT_STOP, 0)
-    ctx.set_option(hip.OPT_PLACEMENT_TRIES, max(1, min(8, args.placement_tries)))
+    ctx.set_option(hip.OPT_PLACEMENT_TRIES, max(1, min(64, args.placement_tries)))
     if args.single_reduce:
         ctx.set_option(hip.OPT_CG_SINGLE_REDUCE, 1)
     ctx.set_profiling(True)
@@ -281,6 +281,9 @@ def main():
                        # the block pool keeps K's arrays between steps; with tries > 1 the first
                        # assembly picks the fastest-streaming of several hipMalloc blocks
                        "placement_tries": args.placement_tries,
+                       "placement_search": {"candidates_timed": prof["placement_candidates"],
+                                            "probe_ms_kept": prof["placement_ms_best"],
+                                            "probe_ms_slowest": prof["placement_ms_worst"]},
                        # SURVEY section 8d assembly bytes: coords + connectivity read, K written once
                        "assembly_GBs": (job.conn.shape[0] * (192 + 32) + info["n_slots"] * 64 * 72)
                                        / (asm_ms / args.steps * 1e-3) / 1e9 if asm_ms > 0 else None,

@@ -108,12 +108,15 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
 #define STAN_OPT_CG_FOLD_REDUCE 11 /* 1 (default): the block of a producing kernel that finishes last adds up the
                            per-block partial sums (fixed order); 0: separate one-block reduction launches,
                            same order, same bits. */
-#define STAN_OPT_PLACEMENT_TRIES 8 /* 1 (default): plain allocation.  n = 2..8: the value array of K is
-                           allocated by trial -- n blocks side by side, the SpMV timed on each, the fastest
-                           kept (placement.hip: the same matrix streams 10 % faster from some hipMalloc
-                           blocks than from others).  Costs n allocations once per context and size; the
-                           block pool keeps the winner.  Destroying a context detaches its matrices: they
-                           may be freed afterwards. */
+#define STAN_OPT_PLACEMENT_TRIES 8 /* 1 (default): plain allocation.  n = 2..64: the value array of K is
+                           allocated by search (placement.hip) -- the same matrix streams ~8 % faster from some
+                           hipMalloc blocks than from others, for the life of the block, and fresh allocations
+                           land in the slow class in runs.  Candidates are allocated one after the other and
+                           the SpMV is timed on each; the slow ones stay allocated while the search goes on,
+                           until one is 5 % faster than the slowest seen, n candidates have been timed, or
+                           free device memory falls under 4 block sizes; the fastest is kept.  Costs ~5 ms per
+                           candidate once per context and size; the block pool keeps the winner.  Destroying a
+                           context detaches its matrices: they may be freed afterwards. */
 #define STAN_OPT_POOL 7 /* 1 (default): device blocks >= 8 MB freed by the library stay with the
                            context and are reused by its next allocations (a hipMalloc of tens of GB
                            costs 0.4-1.8 s here); 0: release them now, plain hipMalloc/hipFree from then on */
@@ -274,6 +277,8 @@ typedef struct stan_profile {
     int64_t loop_kernel_launches;     /* kernels the CG loop enqueued (incl. the run-ahead)  */
     int64_t loop_collectives;         /* RCCL all-reduces the loop enqueued (halo exchanges not counted) */
     int64_t loop_iterations_enqueued; /* iterations those two counts cover                   */
+    int32_t placement_candidates;     /* blocks the last allocation-by-search timed (0: none) */
+    float placement_ms_best, placement_ms_worst; /* SpMV probe time of the kept / the slowest candidate */
 } stan_profile;
 int stan_hip_set_profiling(stan_ctx *ctx, int32_t enabled);
 int stan_hip_get_profile(stan_ctx *ctx, stan_profile *out);

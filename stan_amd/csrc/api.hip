@@ -123,7 +123,7 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
         }
     }
     else if (option == STAN_OPT_OVERLAP_HALO) ctx->overlap_halo = value != 0;
-    else if (option == STAN_OPT_PLACEMENT_TRIES && value >= 1 && value <= 8) ctx->placement_tries = (int)value;
+    else if (option == STAN_OPT_PLACEMENT_TRIES && value >= 1 && value <= 64) ctx->placement_tries = (int)value;
 #ifdef STAN_LAB
     else if (option == STAN_OPT_SPMV_VARIANT && value >= -1 && value <= 16) ctx->spmv_variant = (int)value;
 #else   // the product library carries the three variants that give right answers (cg.hip)
@@ -154,6 +154,9 @@ int stan_hip_get_profile(stan_ctx *ctx, stan_profile *out) {
     if (ctx->group) ctx = stan_group_rank0(ctx);   // rank 0's timings; spmv_bytes is that shard's
     *out = ctx->prof;
     out->assembly_colours = ctx->prof_colours;
+    out->placement_candidates = ctx->prof_placement_candidates;
+    out->placement_ms_best = ctx->prof_placement_ms_best;
+    out->placement_ms_worst = ctx->prof_placement_ms_worst;
     return STAN_OK;
 }
 

@@ -127,6 +127,7 @@ struct stan_ctx {
     int assembly_mode = 0;     // 0 row-owner gather (default), 1 element-wave colour scatter
     int placement_tries = 1;   // > 1: allocate the value stream by trial (placement.hip)
     float prof_placement_ms_best = 0, prof_placement_ms_worst = 0;
+    int prof_placement_candidates = 0;
     int prof_colours = 0;
     int spmv_variant = -1; // -1 = auto (launch_spmv picks per value stream); >= 0: A/B lab
     // profiling

@@ -4,6 +4,7 @@
 // `nseg` consecutive slice ranges (c) a plain front-to-back read of each segment's bytes.
 // ms [ntries * (1 + 2*nseg)]: per candidate {whole, seg SpMV x nseg, seg read x nseg}.
 #include <chrono>
+#include <thread>
 #include <vector>
 
 #include "../internal.h"
@@ -151,5 +152,37 @@ extern "C" int stan_hip_lab_placement_alloc(stan_ctx *ctx, stan_matrix *K, int32
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (int t = 0; t < n; t++)
         if (cand[(size_t)t] && cand[(size_t)t] != K->d_vals) hipFree(cand[(size_t)t]);
+    return STAN_OK;
+}
+
+// Placement or time?  All candidates are allocated and filled FIRST, then timed round-robin:
+// ms [nrounds * ntries] (whole-SpMV, `reps` launches each), t_s [nrounds * ntries] host seconds
+// since the first measurement.  A block that is slow in every round is slow by placement; rounds
+// in which every block is slow are the device's state at that time.
+extern "C" int stan_hip_lab_placement_rounds(stan_ctx *ctx, stan_matrix *K, int32_t ntries, int32_t nrounds,
+                                             int32_t reps, int32_t pause_ms, double *ms, double *t_s) {
+    if (!ctx || !K || !ms || ntries < 1 || ntries > 16 || nrounds < 1 || K->ctx != ctx) return STAN_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)K->nslots * 9 * 64 * 8;
+    std::vector<void *> cand;
+    for (int t = 0; t < ntries; t++) {
+        void *q = nullptr;
+        if (t == 0) q = K->d_vals;
+        else if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        if (t > 0) HIPCHK(ctx, hipMemcpyAsync(q, K->d_vals, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        cand.push_back(q);
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < nrounds; r++) {
+        for (size_t t = 0; t < (size_t)ntries; t++) {
+            float f = -1;
+            if (t < cand.size()) STANCHK(stan_spmv_probe_range(ctx, K, (const double *)cand[t], 0, K->nslices, reps, &f, 9));
+            ms[(size_t)r * ntries + t] = f;
+            if (t_s) t_s[(size_t)r * ntries + t] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+        if (pause_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(pause_ms));
+    }
+    for (size_t t = 1; t < cand.size(); t++) hipFree(cand[t]);
     return STAN_OK;
 }

@@ -31,6 +31,11 @@ int stan_hip_lab_placement_variants(stan_ctx *ctx, stan_matrix *K, int32_t ntrie
  * translation cost, hardly any data) and the allocation's wall ms: out [n * 5]. */
 int stan_hip_lab_placement_alloc(stan_ctx *ctx, stan_matrix *K, int32_t n, const int32_t *strategy,
                                  double *out, uint64_t *addr);
+/* Placement or time?  ntries candidates allocated and filled first, then timed round-robin for
+ * nrounds rounds (reps launches per measurement, pause_ms of host sleep between rounds):
+ * ms, t_s [nrounds * ntries] (t_s = host seconds since the first measurement; may be NULL). */
+int stan_hip_lab_placement_rounds(stan_ctx *ctx, stan_matrix *K, int32_t ntries, int32_t nrounds,
+                                  int32_t reps, int32_t pause_ms, double *ms, double *t_s);
 #ifdef __cplusplus
 }
 #endif

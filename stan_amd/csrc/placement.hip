@@ -68,7 +68,20 @@ int stan_probe_block(stan_ctx *ctx, const void *p, size_t bytes, float *ms_out) 
     return STAN_OK;
 }
 
-// Allocation by trial for a block that will be streamed many times (see the header comment).
+// Allocation by search for a block that will be streamed many times (see the header comment and
+// profiles/r02/PLACEMENT.md).  Round 2 measurements: the time a block streams in is a property of
+// the block for its whole life (round-robin timing of six blocks over 5 s: 0.2 % noise), it is
+// BIMODAL (148^3 fp64: ~1.02 ms or ~1.10-1.12 ms, nothing in between but stragglers), it does not
+// depend on the walk order of the kernel, on the allocation size class or flags, or on translation
+// cost, and which class a fresh hipMalloc lands in comes in runs: on one box the first 40 GB of a
+// process were all slow and everything after that fast, on another all of the first 38 GB.  So
+// four candidates side by side (round 1) often see one class only.  The search therefore goes on,
+// KEEPING the slow candidates allocated so that the allocator cannot hand their memory out again,
+// until a candidate is at least 5 % faster than the slowest one seen (a member of the fast class
+// next to a known slow one), or `tries` candidates have been timed, or the device would be left
+// with less than three block sizes of free memory; the fastest is kept, the rest freed.  A
+// hipMalloc of 6.4 GB takes 0.3 ms and a probe 4 SpMV launches: 16 candidates cost ~80 ms, once
+// per context and size (the pool keeps the winner).
 int stan_dmalloc_streamed(stan_ctx *ctx, void **p, size_t bytes,
                           const std::function<int(const void *, float *)> &probe) {
     const int tries = ctx->placement_tries;
@@ -78,7 +91,10 @@ int stan_dmalloc_streamed(stan_ctx *ctx, void **p, size_t bytes,
         if (b.cap >= bytes && b.cap <= bytes + bytes / 2) return stan_dmalloc_bytes(ctx, p, bytes);
     std::vector<void *> cand;
     std::vector<float> ms;
+    float best = 0, worst = 0;
     for (int i = 0; i < tries; i++) {
+        size_t free_b = 0, total_b = 0;
+        if (i > 0 && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 4 * bytes)) break;
         void *q = nullptr;
         if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
         float t = 0;
@@ -86,17 +102,20 @@ int stan_dmalloc_streamed(stan_ctx *ctx, void **p, size_t bytes,
         if (rc) { hipFree(q); for (void *c : cand) hipFree(c); return rc; }
         cand.push_back(q);
         ms.push_back(t);
+        if (i == 0 || t < best) best = t;
+        if (i == 0 || t > worst) worst = t;
+        if (i > 0 && best <= 0.95f * worst) break;   // both classes seen: the best is a fast one
     }
     if (cand.empty()) return stan_dmalloc_bytes(ctx, p, bytes);  // reports the allocation failure
-    size_t best = 0;
+    size_t ibest = 0;
     for (size_t i = 1; i < cand.size(); i++)
-        if (ms[i] < ms[best]) best = i;
+        if (ms[i] < ms[ibest]) ibest = i;
     for (size_t i = 0; i < cand.size(); i++)
-        if (i != best) hipFree(cand[i]);
-    *p = cand[best];
+        if (i != ibest) hipFree(cand[i]);
+    *p = cand[ibest];
     if (ctx->pool.enabled) ctx->pool.live[*p] = bytes;
-    ctx->prof_placement_ms_best = ms[best];
-    ctx->prof_placement_ms_worst = ms[0];
-    for (float t : ms) if (t > ctx->prof_placement_ms_worst) ctx->prof_placement_ms_worst = t;
+    ctx->prof_placement_ms_best = ms[ibest];
+    ctx->prof_placement_ms_worst = worst;
+    ctx->prof_placement_candidates = (int)cand.size();
     return STAN_OK;
 }

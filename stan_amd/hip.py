@@ -38,7 +38,7 @@ EXPORTS = [
     "stan_hip_matrix_plan", "stan_hip_spmv_local",
 ]
 # only in the lab build (stan_amd/csrc/lab/stan_hip_lab.h, selected with STAN_HIP_LIB)
-LAB_EXPORTS = ["stan_hip_csr_spmv_bench", "stan_hip_lab_placement_map", "stan_hip_lab_placement_variants", "stan_hip_lab_placement_alloc"]
+LAB_EXPORTS = ["stan_hip_csr_spmv_bench", "stan_hip_lab_placement_map", "stan_hip_lab_placement_variants", "stan_hip_lab_placement_alloc", "stan_hip_lab_placement_rounds"]
 
 
 class MatrixInfo(C.Structure):
@@ -56,7 +56,8 @@ class Profile(C.Structure):
                 ("termination_type", C.c_int32), ("assembly_colours", C.c_int32),
                 ("value_stream", C.c_int32), ("spmv2_ms_total", C.c_double), ("spmv2_launches", C.c_int64),
                 ("loop_kernel_launches", C.c_int64), ("loop_collectives", C.c_int64),
-                ("loop_iterations_enqueued", C.c_int64)]
+                ("loop_iterations_enqueued", C.c_int64), ("placement_candidates", C.c_int32),
+                ("placement_ms_best", C.c_float), ("placement_ms_worst", C.c_float)]
 
 
 class StanHipError(RuntimeError):
