@@ -218,6 +218,9 @@ typedef struct stan_matrix_info {
     int64_t bytes_matrix; /* device bytes of values + column indices             */
     int32_t scaled;       /* 1 once the CG has applied its diagonal scaling      */
     int32_t max_row_blocks;
+    int64_t n_elements_on_device; /* elements this rank uploaded and scanned: all of them on a single
+                                     rank; on a rank of a sharded run (host-pointer entry) only those
+                                     that touch its rows; summed over the devices of a group handle */
 } stan_matrix_info;
 int stan_hip_matrix_info(stan_matrix *K, stan_matrix_info *out);
 

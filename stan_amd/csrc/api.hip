@@ -66,6 +66,7 @@ void stan_hip_destroy(stan_ctx *ctx) {
     // matrices that outlive their context keep working memory-wise: they are detached and their
     // buffers go straight back to the driver when they are freed
     for (stan_matrix *K : ctx->matrices) K->ctx = nullptr;
+    stan_cg_workspace_free(ctx);
     ctx->pool.flush();
     if (ctx->h_status) hipHostFree(ctx->h_status);
     if (ctx->d_status) hipFree(ctx->d_status);
@@ -198,6 +199,39 @@ int stan_hip_assemble_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz,
             return STAN_E_UNSUPPORTED;
         }
     }
+    // A rank of a sharded run only needs the elements that touch its block rows (boundary elements
+    // are assembled by both owners): they are picked on the host, in element order (the
+    // accumulation order of a row is the element order, so K keeps its bits), and only they go to
+    // the device -- neither the upload nor the incidence scan of a rank grows with the ranks of
+    // the others.  The node arrays stay whole: any node may be a halo column.
+    std::vector<int32_t> sub, conn_s, mat_s;
+    std::vector<uint8_t> type_s;
+    const bool shard = ctx->nranks > 1 && n_elem > 0;
+    if (shard) {
+        const int64_t nb = n_dof / 3;
+        const int64_t r0 = stan_row_start(nb, ctx->nranks, ctx->rank), r1 = stan_row_start(nb, ctx->nranks, ctx->rank + 1);
+        for (int64_t e = 0; e < n_elem; e++) {
+            bool mine = false;
+            for (int a = 0; a < 8; a++) {
+                const int32_t nd = conn[e * 8 + a];
+                if (nd < 0 || nd >= n_nodes) {
+                    ctx->err = "assemble: connectivity references a node index outside [0,n_nodes)";
+                    return STAN_E_ARG;
+                }
+                const int64_t row = node_dof[3 * (int64_t)nd] / 3;   // a bad DOF layout is caught on the device
+                mine |= row >= r0 && row < r1;
+            }
+            if (mine) sub.push_back((int32_t)e);
+        }
+        conn_s.resize(sub.size() * 8); mat_s.resize(sub.size()); type_s.resize(sub.size());
+        for (size_t i = 0; i < sub.size(); i++) {
+            memcpy(&conn_s[8 * i], conn + 8 * (int64_t)sub[i], 8 * sizeof(int32_t));
+            mat_s[i] = elem_mat[sub[i]];
+            type_s[i] = elem_type[sub[i]];
+        }
+        conn = conn_s.data(); elem_mat = mat_s.data(); elem_type = type_s.data();
+        n_elem = (int64_t)sub.size();
+    }
     dbuf<double> dx; dbuf<int32_t> dd, dc, dm, dr; dbuf<uint8_t> dt;
     STANCHK(dx.upload(ctx, xyz, (size_t)n_nodes * 3));
     STANCHK(dd.upload(ctx, node_dof, (size_t)n_nodes * 3));
@@ -205,8 +239,16 @@ int stan_hip_assemble_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz,
     STANCHK(dm.upload(ctx, elem_mat, (size_t)n_elem));
     STANCHK(dt.upload(ctx, elem_type, (size_t)n_elem));
     STANCHK(dr.upload(ctx, red, (size_t)n_dof));
-    return stan_assemble_device(ctx, n_nodes, dx.p, dd.p, n_elem, dc.p, dm.p, dt.p, n_mat, mat_E_nu,
-                                n_dof, dr.p, outK);
+    const int rc = stan_assemble_device(ctx, n_nodes, dx.p, dd.p, n_elem, dc.p, dm.p, dt.p, n_mat, mat_E_nu,
+                                        n_dof, dr.p, outK);
+    if (rc == STAN_OK) (*outK)->n_elem_scanned = n_elem;
+    if (rc == STAN_E_DETJ && shard && ctx->bad_elem >= 0 && ctx->bad_elem < (int64_t)sub.size()) {
+        ctx->bad_elem = sub[(size_t)ctx->bad_elem];   // element number of the whole model
+        ctx->err = "det J == 0 in element " + std::to_string(ctx->bad_elem) + " (MatrixST.Inverse would throw)";
+    }
+    // the uploads above are stream-ordered with the assembly; the host vectors must outlive them
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return rc;
 }
 
 void stan_hip_matrix_free(stan_matrix *K) {
@@ -351,6 +393,7 @@ int stan_hip_matrix_info(stan_matrix *K, stan_matrix_info *o) {
     o->bytes_matrix = K->nslots * 64 * (9 * 8 + 4);
     o->scaled = (K->parts.empty() ? K->scaled : K->parts[0]->scaled) ? 1 : 0;
     o->max_row_blocks = K->max_row_blocks;
+    o->n_elements_on_device = K->n_elem_scanned;
     return STAN_OK;
 }
 

@@ -678,16 +678,10 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     const int64_t nb = n_dof / 3;
     K->n_dof = n_dof;
     K->nb_glob = nb;
+    K->n_elem_scanned = n_elem;
     // contiguous block-row partition, cut on slice boundaries
     K->row_starts.resize(ctx->nranks + 1);
-    {
-        const int64_t nsl = (nb + 63) / 64;
-        for (int r = 0; r <= ctx->nranks; r++) {
-            int64_t s = nsl * r / ctx->nranks * 64;
-            K->row_starts[r] = s > nb ? nb : s;
-        }
-        K->row_starts[ctx->nranks] = nb;
-    }
+    for (int r = 0; r <= ctx->nranks; r++) K->row_starts[r] = stan_row_start(nb, ctx->nranks, r);
     const int64_t r0 = K->r0 = K->row_starts[ctx->rank], r1 = K->r1 = K->row_starts[ctx->rank + 1];
     const int64_t nloc = K->nloc = r1 - r0;
     K->nslices = (int32_t)((nloc + 63) / 64);

@@ -916,6 +916,28 @@ unsigned launch_spmv_any(stan_ctx *ctx, stan_matrix *K, int stream_kind, const d
 
 }  // namespace
 
+// Vectors of the CG for a matrix of K's sizes, owned by the context (see stan_cg_ws).
+int stan_cg_workspace(stan_ctx *ctx, const stan_matrix *K) {
+    const int64_t npad = (int64_t)K->nslices * 64;
+    const int64_t ng = 3 * ((npad > K->nloc + K->nhalo ? npad : K->nloc + K->nhalo));
+    const int64_t n3 = 3 * K->nloc > 0 ? 3 * K->nloc : 1;
+    stan_cg_ws &ws = ctx->ws;
+    if (ws.p && ws.ng >= ng && ws.n3 >= n3 && ws.ng <= ng + ng / 2 + 64) return STAN_OK;
+    stan_cg_workspace_free(ctx);
+    for (double **q : {&ws.xb[0], &ws.xb[1], &ws.p, &ws.r}) STANCHK(stan_dmalloc(ctx, q, (size_t)(ng > 0 ? ng : 1)));
+    for (double **q : {&ws.v, &ws.w, &ws.bh, &ws.sv}) STANCHK(stan_dmalloc(ctx, q, (size_t)n3));
+    ws.ng = ng; ws.n3 = n3;
+    return STAN_OK;
+}
+void stan_cg_workspace_free(stan_ctx *ctx) {
+    stan_cg_ws &ws = ctx->ws;
+    for (double **q : {&ws.xb[0], &ws.xb[1], &ws.p, &ws.r, &ws.v, &ws.w, &ws.bh, &ws.sv}) {
+        if (*q) stan_dfree(ctx, *q);
+        *q = nullptr;
+    }
+    ws.ng = ws.n3 = 0;
+}
+
 // Diagonal scaling of the matrix (once per matrix): A^ = S K S.
 static int ensure_scaled(stan_ctx *ctx, stan_matrix *K) {
     if (K->scaled) return STAN_OK;
@@ -1021,14 +1043,10 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     double *xb[2], *p, *r, *v, *w, *bh, *partial, *sc, *sv = nullptr;
     int64_t *stt;
     unsigned long long *tick;
-    STANCHK(alloc(ctx, bufs, &xb[0], (size_t)ng));
-    STANCHK(alloc(ctx, bufs, &xb[1], (size_t)ng));
-    STANCHK(alloc(ctx, bufs, &p, (size_t)ng));
-    STANCHK(alloc(ctx, bufs, &r, (size_t)(sr ? ng : n3)));   // the single-reduction loop multiplies r
-    STANCHK(alloc(ctx, bufs, &v, (size_t)n3));
-    STANCHK(alloc(ctx, bufs, &w, (size_t)n3));
-    STANCHK(alloc(ctx, bufs, &bh, (size_t)n3));
-    if (sr) STANCHK(alloc(ctx, bufs, &sv, (size_t)n3));
+    STANCHK(stan_cg_workspace(ctx, K));   // the context's vectors (the placement search probed with them)
+    xb[0] = ctx->ws.xb[0]; xb[1] = ctx->ws.xb[1]; p = ctx->ws.p; r = ctx->ws.r;
+    v = ctx->ws.v; w = ctx->ws.w; bh = ctx->ws.bh;
+    if (sr) sv = ctx->ws.sv;
     const unsigned spmv_blocks = nblk(K->nslices, 4);
     const size_t npart = 2 * (size_t)(spmv_blocks > VEC_BLOCKS ? spmv_blocks : VEC_BLOCKS) + 16;
     STANCHK(alloc(ctx, bufs, &partial, npart));
@@ -1387,8 +1405,10 @@ int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode
     const int64_t ng = 3 * ((npad > K->nloc + K->nhalo ? npad : K->nloc + K->nhalo));
     dev_bufs bufs;
     double *x, *y, *partial; int64_t *stt;
-    STANCHK(alloc(ctx, bufs, &x, (size_t)ng));
-    STANCHK(alloc(ctx, bufs, &y, (size_t)ng));
+    // the CG's own gather vector and product buffer: the pair (value block, vector blocks) that is
+    // timed here is the pair the solve will run on
+    STANCHK(stan_cg_workspace(ctx, K));
+    x = ctx->ws.p; y = ctx->ws.v;
     STANCHK(alloc(ctx, bufs, &partial, (size_t)nblk(K->nslices, 4) + 1));
     STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
     int64_t init[T_NSTAT] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0, 0, 0, 0, 0, 0};
@@ -1423,8 +1443,10 @@ int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, int32_t pre
     const int64_t ng = 3 * ((npad > K->nloc + K->nhalo ? npad : K->nloc + K->nhalo));
     dev_bufs bufs;
     double *x, *y, *partial; int64_t *stt;
-    STANCHK(alloc(ctx, bufs, &x, (size_t)ng));
-    STANCHK(alloc(ctx, bufs, &y, (size_t)ng));
+    // the CG's own gather vector and product buffer: the pair (value block, vector blocks) that is
+    // timed here is the pair the solve will run on
+    STANCHK(stan_cg_workspace(ctx, K));
+    x = ctx->ws.p; y = ctx->ws.v;
     STANCHK(alloc(ctx, bufs, &partial, (size_t)nblk(K->nslices, 4) + 1));
     STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
     int64_t init[T_NSTAT] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0, 0, 0, 0, 0, 0};
@@ -1455,7 +1477,7 @@ int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, int32_t pre
 // lab: time the fp64 SpMV over the slices [s0, s1) only, streaming the values from `vals`
 // (lab/placement_lab.hip: where inside a block does a slow block lose its time?)
 int stan_spmv_probe_range(stan_ctx *ctx, stan_matrix *K, const double *vals, int32_t s0, int32_t s1,
-                          int reps, float *ms_out, int variant) {
+                          int reps, float *ms_out, int variant, double *xy_region) {
     hipStream_t st_ = ctx->stream;
     *ms_out = 0;
     if (s1 <= s0) return STAN_OK;
@@ -1463,8 +1485,13 @@ int stan_spmv_probe_range(stan_ctx *ctx, stan_matrix *K, const double *vals, int
     const int64_t ng = 3 * ((npad > K->nloc + K->nhalo ? npad : K->nloc + K->nhalo));
     dev_bufs bufs;
     double *x, *y, *partial; int64_t *stt; int32_t *list;
-    STANCHK(alloc(ctx, bufs, &x, (size_t)ng));
-    STANCHK(alloc(ctx, bufs, &y, (size_t)ng));
+    if (xy_region) {   // lab: gather vector and product live inside a block the caller chose
+        x = xy_region;
+        y = xy_region + ((ng + 511) & ~(int64_t)511);
+    } else {
+        STANCHK(alloc(ctx, bufs, &x, (size_t)ng));
+        STANCHK(alloc(ctx, bufs, &y, (size_t)ng));
+    }
     STANCHK(alloc(ctx, bufs, &partial, (size_t)nblk(K->nslices, 4) + 1));
     STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
     STANCHK(alloc(ctx, bufs, &list, (size_t)(s1 - s0)));

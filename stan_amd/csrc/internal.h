@@ -102,6 +102,16 @@ enum stan_status_slot {
     SS_H_CG_SCALARS = 40 // host: the CG scalars at the end of a solve
 };
 
+// Vectors of the CG, kept by the context between solves (cg.hip: stan_cg_workspace).  They are
+// allocated BEFORE the value stream of K is placed by search, and the search's probe multiplies
+// with exactly these buffers: whether a block streams fast depends on the PAIR (value block,
+// vector block) -- profiles/r02/PLACEMENT.md -- so the pair that is timed is the pair that runs.
+struct stan_cg_ws {
+    int64_t ng = 0, n3 = 0;        // capacities: gather-sized (owned + pad + halo) / owned-sized, in doubles
+    double *xb[2] = {nullptr, nullptr}, *p = nullptr, *r = nullptr;   // ng each
+    double *v = nullptr, *w = nullptr, *bh = nullptr, *sv = nullptr;  // n3 each
+};
+
 struct stan_matrix;
 struct stan_group;   // multi.hip: one process, several GPUs
 struct stan_ctx {
@@ -134,6 +144,7 @@ struct stan_ctx {
     bool profiling = false;
     stan_profile prof{};
     stan_pool pool;
+    stan_cg_ws ws;
     std::vector<stan_matrix *> matrices;  // alive matrices of this context (detached when it is destroyed)
     // small pinned host + device scratch for status words
     int64_t *h_status = nullptr;  // pinned, 64 words
@@ -151,6 +162,7 @@ struct stan_matrix {
     int64_t nslots = 0;      // total k-slots (each = 64 rows x one block)
     int64_t nblocks = 0;     // structural blocks on this rank
     int32_t max_row_blocks = 0;
+    int64_t n_elem_scanned = 0;  // elements this rank holds on the device (sharded host entry: its subset)
     int32_t *d_slot_ptr = nullptr;  // [nslices+1]
     int32_t *d_rowlen = nullptr;    // [nslices*64] blocks per row
     int32_t *d_cols = nullptr;      // [nslots][64] local block-column index
@@ -174,6 +186,15 @@ struct stan_matrix {
     int32_t *d_sl_int = nullptr, *d_sl_bnd = nullptr;
     int32_t n_sl_int = 0, n_sl_bnd = 0;
 };
+
+// contiguous block-row partition of the sharded system, cut on slice (64-row) boundaries:
+// rank r owns [row_start(r), row_start(r+1)) of the nb block rows (reference DOF order)
+static inline int64_t stan_row_start(int64_t nb, int nranks, int r) {
+    if (r >= nranks) return nb;
+    const int64_t nsl = (nb + 63) / 64;
+    const int64_t s = nsl * r / nranks * 64;
+    return s > nb ? nb : s;
+}
 
 // ---- scan.hip -------------------------------------------------------------------------------
 // out[i] = sum_{j<i} in[j] (int32 in, int64 out), out has n+1 entries (out[n] = total).
@@ -205,6 +226,8 @@ int stan_spmv_local(stan_ctx *ctx, stan_matrix *K, const double *d_x, double *d_
 int stan_matrix_make_fp32(stan_ctx *ctx, stan_matrix *K);
 int stan_matrix_make_fx48(stan_ctx *ctx, stan_matrix *K);
 int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K);
+int stan_cg_workspace(stan_ctx *ctx, const stan_matrix *K);  // (re)allocates ctx->ws for K's sizes
+void stan_cg_workspace_free(stan_ctx *ctx);
 
 // ---- recovery.hip ---------------------------------------------------------------------------
 int stan_recover_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz, const double *d_disp,

@@ -11,7 +11,7 @@
 #include "stan_hip_lab.h"
 
 int stan_spmv_probe_range(stan_ctx *ctx, stan_matrix *K, const double *vals, int32_t s0, int32_t s1,
-                          int reps, float *ms_out, int variant);
+                          int reps, float *ms_out, int variant, double *xy_region = nullptr);
 
 extern "C" int stan_hip_lab_placement_map(stan_ctx *ctx, stan_matrix *K, int32_t ntries, int32_t nseg,
                                           int32_t keep_fastest, double *ms, uint64_t *addr) {
@@ -184,5 +184,49 @@ extern "C" int stan_hip_lab_placement_rounds(stan_ctx *ctx, stan_matrix *K, int3
         if (pause_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(pause_ms));
     }
     for (size_t t = 1; t < cand.size(); t++) hipFree(cand[t]);
+    return STAN_OK;
+}
+
+// Does the placement of the VECTORS matter too?  ntries blocks are classified with the value stream
+// in each (vectors from the pool); then the value stream stays in the fastest (and in the slowest)
+// block while the gather vector x and the product y are carved out of each OTHER block in turn.
+// out [ntries]: class probe per block; cross_fast / cross_slow [ntries]: SpMV ms with the values in
+// the fastest / slowest block and x, y inside block t (-1 for t == that block).
+extern "C" int stan_hip_lab_placement_cross(stan_ctx *ctx, stan_matrix *K, int32_t ntries, double *out,
+                                            double *cross_fast, double *cross_slow, int32_t *i_fast, int32_t *i_slow) {
+    if (!ctx || !K || !out || !cross_fast || !cross_slow || ntries < 2 || ntries > 32 || K->ctx != ctx) return STAN_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)K->nslots * 9 * 64 * 8;
+    std::vector<void *> cand;
+    for (int t = 0; t < ntries; t++) {
+        void *q = nullptr;
+        if (t == 0) q = K->d_vals;
+        else if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        if (t > 0) HIPCHK(ctx, hipMemcpyAsync(q, K->d_vals, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        cand.push_back(q);
+        float f = 0;
+        STANCHK(stan_spmv_probe_range(ctx, K, (const double *)q, 0, K->nslices, 10, &f, 9));
+        out[t] = f;
+    }
+    const int n = (int)cand.size();
+    for (int t = n; t < ntries; t++) out[t] = cross_fast[t] = cross_slow[t] = -1;
+    int bf = 0, bs = 0;
+    for (int t = 1; t < n; t++) { if (out[t] < out[bf]) bf = t; if (out[t] > out[bs]) bs = t; }
+    if (i_fast) *i_fast = bf;
+    if (i_slow) *i_slow = bs;
+    // vectors inside block t: block t's matrix copy is overwritten at its front (only blocks other
+    // than the one the values are streamed from)
+    for (int pass = 0; pass < 2; pass++) {
+        const int src = pass == 0 ? bf : bs;
+        double *res = pass == 0 ? cross_fast : cross_slow;
+        for (int t = 0; t < n; t++) {
+            if (t == src || t == 0) { res[t] = -1; continue; }   // block 0 is K's own: keep it intact
+            float f = 0;
+            STANCHK(stan_spmv_probe_range(ctx, K, (const double *)cand[src], 0, K->nslices, 10, &f, 9, (double *)cand[t]));
+            res[t] = f;
+        }
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int t = 1; t < n; t++) hipFree(cand[t]);
     return STAN_OK;
 }

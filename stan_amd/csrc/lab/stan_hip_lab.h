@@ -36,6 +36,9 @@ int stan_hip_lab_placement_alloc(stan_ctx *ctx, stan_matrix *K, int32_t n, const
  * ms, t_s [nrounds * ntries] (t_s = host seconds since the first measurement; may be NULL). */
 int stan_hip_lab_placement_rounds(stan_ctx *ctx, stan_matrix *K, int32_t ntries, int32_t nrounds,
                                   int32_t reps, int32_t pause_ms, double *ms, double *t_s);
+/* Does the placement of the vectors matter too?  See lab/placement_lab.hip. */
+int stan_hip_lab_placement_cross(stan_ctx *ctx, stan_matrix *K, int32_t ntries, double *out,
+                                 double *cross_fast, double *cross_slow, int32_t *i_fast, int32_t *i_slow);
 #ifdef __cplusplus
 }
 #endif

@@ -170,6 +170,7 @@ int stan_group_assemble(stan_ctx *lead, int64_t n_nodes, const double *xyz, cons
     K->r0 = 0; K->r1 = p0->nb_glob; K->nloc = p0->nb_glob;
     for (const stan_matrix *p : K->parts) {
         K->nblocks += p->nblocks; K->nslots += p->nslots; K->nhalo += p->nhalo; K->nslices += p->nslices;
+        K->n_elem_scanned += p->n_elem_scanned;
         if (p->max_row_blocks > K->max_row_blocks) K->max_row_blocks = p->max_row_blocks;
     }
     lead->matrices.push_back(K);

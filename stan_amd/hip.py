@@ -38,14 +38,14 @@ EXPORTS = [
     "stan_hip_matrix_plan", "stan_hip_spmv_local",
 ]
 # only in the lab build (stan_amd/csrc/lab/stan_hip_lab.h, selected with STAN_HIP_LIB)
-LAB_EXPORTS = ["stan_hip_csr_spmv_bench", "stan_hip_lab_placement_map", "stan_hip_lab_placement_variants", "stan_hip_lab_placement_alloc", "stan_hip_lab_placement_rounds"]
+LAB_EXPORTS = ["stan_hip_csr_spmv_bench", "stan_hip_lab_placement_map", "stan_hip_lab_placement_variants", "stan_hip_lab_placement_alloc", "stan_hip_lab_placement_rounds", "stan_hip_lab_placement_cross"]
 
 
 class MatrixInfo(C.Structure):
     _fields_ = [("n_dof", C.c_int64), ("n_reduced", C.c_int64), ("n_block_rows", C.c_int64),
                 ("row_begin", C.c_int64), ("row_end", C.c_int64), ("n_halo", C.c_int64),
                 ("n_blocks", C.c_int64), ("n_slots", C.c_int64), ("bytes_matrix", C.c_int64),
-                ("scaled", C.c_int32), ("max_row_blocks", C.c_int32)]
+                ("scaled", C.c_int32), ("max_row_blocks", C.c_int32), ("n_elements_on_device", C.c_int64)]
 
 
 class Profile(C.Structure):

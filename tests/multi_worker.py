@@ -34,7 +34,7 @@ except hip.StanHipError as e:
     unsupported = e.code
 np.savez(out, U=U, Ux=Ux, Us=Us, its=rep["iterations"], term=rep["terminationtype"], its_s=reps["iterations"],
          term_s=reps["terminationtype"], its_x=repx["iterations"], strain=strain, stress=stress,
-         n_blocks=info["n_blocks"], n_halo=info["n_halo"], unsupported=unsupported,
+         n_blocks=info["n_blocks"], n_halo=info["n_halo"], n_elem_dev=info["n_elements_on_device"], unsupported=unsupported,
          coll_per_it=prof["loop_collectives"] / max(prof["loop_iterations_enqueued"], 1),
          coll_per_it_s=profs["loop_collectives"] / max(profs["loop_iterations_enqueued"], 1))
 K.free()

@@ -38,6 +38,8 @@ def test_one_process_several_ranks_matches_oracle(built_libs, oracle, tmp_path, 
     for key in ("U", "Ux", "Us"):
         assert np.abs(d[key] - Uo).max() <= 1e-4 * np.abs(Uo).max(), key     # two eps = 1e-6 solves
     assert int(d["n_blocks"]) == (3 * n + 1) ** 3 and int(d["n_halo"]) > 0
+    # every rank uploads and scans only the elements that touch its rows (boundary ones twice)
+    assert n ** 3 < int(d["n_elem_dev"]) < 0.8 * nranks * n ** 3
     assert int(d["unsupported"]) == -8                                        # single-rank helper on a group handle
     # the classic loop reduces twice per iteration, the single-reduction loop once
     assert 1.9 <= float(d["coll_per_it"]) <= 2.1 and 1.0 <= float(d["coll_per_it_s"]) <= 1.1
