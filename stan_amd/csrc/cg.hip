@@ -1520,6 +1520,71 @@ int stan_spmv_probe_range(stan_ctx *ctx, stan_matrix *K, const double *vals, int
     HIPCHK(ctx, hipGetLastError());
     return STAN_OK;
 }
+__global__ void k_fill_nt(double *p, int64_t n, double v) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) __builtin_nontemporal_store(v, p + i);
+}
+__global__ void k_read_only(const double *p, int64_t n, double *sink) {
+    double a = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) a += p[i];
+    if (a == 0.123456789) sink[0] = a;
+}
+// lab: what makes the SpMV slower inside the CG than back to back?  mode 0: launches back to back;
+// 1: the gather vector is rewritten (k_fill, plain stores like k_update) before every launch;
+// 2: plus a k_step-like pass over four other vectors in between; 3: only that pass (x untouched).
+// Events bracket each product alone.  out_ms [4].
+int stan_spmv_incg_lab(stan_ctx *ctx, stan_matrix *K, int reps, double *out_ms) {
+    hipStream_t st_ = ctx->stream;
+    STANCHK(stan_cg_workspace(ctx, K));
+    const int64_t ng = ctx->ws.ng, n3 = 3 * K->nloc;
+    double *x = ctx->ws.p, *y = ctx->ws.v;
+    dev_bufs bufs;
+    double *partial; int64_t *stt;
+    STANCHK(alloc(ctx, bufs, &partial, 2 * (size_t)nblk(K->nslices, 4) + 16));
+    STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
+    int64_t init[T_NSTAT] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0, 0, 0, 0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(stt, init, sizeof(init), hipMemcpyHostToDevice, st_));
+    hipLaunchKernelGGL(k_fill, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, x, ng, 1.0);
+    for (double *q : {ctx->ws.xb[0], ctx->ws.xb[1], ctx->ws.r, ctx->ws.w})
+        hipLaunchKernelGGL(k_fill, dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, q, n3, 0.5);
+    for (int mode = 0; mode < 7; mode++) {
+        event_bag ev;
+        std::vector<hipEvent_t> e;
+        for (int r = 0; r < reps + 2; r++) {
+            if (mode == 1 || mode == 2) hipLaunchKernelGGL(k_fill, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, x, ng, 1.0);
+            if (mode == 2 || mode == 3) {   // the traffic of k_step: x' = x + a p, r -= a v  (reads 4, writes 2)
+                step_args a;
+                a.n3 = n3; a.k = 1; a.sc = nullptr; a.st = stt; a.xcur = ctx->ws.xb[0]; a.xnext = ctx->ws.xb[1];
+                a.r = ctx->ws.r; a.p = ctx->ws.w; a.v = y; a.bh = ctx->ws.bh; a.partial = partial; a.w = ctx->ws.w;
+                a.merit = 0; a.refresh = 0; a.fold = fold_args{nullptr, 0, 0, nullptr};
+                double *scal; STANCHK(alloc(ctx, bufs, &scal, (size_t)S_NSCAL));
+                double hs[S_NSCAL] = {0}; hs[S_VMV] = 1.0; hs[S_RHO0] = hs[S_RHO1] = 1e-30;
+                HIPCHK(ctx, hipMemcpyAsync(scal, hs, sizeof(hs), hipMemcpyHostToDevice, st_));
+                a.sc = scal;
+                hipLaunchKernelGGL(k_step, dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, a);
+            }
+            // 4: rewritten with non-temporal stores; 5: rewritten (plain), then read once front to back
+            // by a streaming kernel (does a read pull it into the memory-side cache?); 6: like 5 with nt stores
+            if (mode == 4 || mode == 6) hipLaunchKernelGGL(k_fill_nt, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, x, ng, 1.0);
+            if (mode == 5) hipLaunchKernelGGL(k_fill, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, x, ng, 1.0);
+            if (mode == 5 || mode == 6) hipLaunchKernelGGL(k_read_only, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, (const double *)x, ng, partial);
+            hipEvent_t a0 = ev.make(), b0 = ev.make();
+            hipEventRecord(a0, st_);
+            hipLaunchKernelGGL((k_spmv<double, 1, 9>), dim3(nblk(K->nslices, 4)), dim3(256), 0, st_, K->nslices, K->nloc,
+                               K->d_slot_ptr, K->d_cols, K->d_vals, x, y, partial, stt, (int64_t)1,
+                               (const int32_t *)nullptr, K->nslices, 0, fold_args{nullptr, 0, 0, nullptr});
+            hipEventRecord(b0, st_);
+            if (r >= 2) { e.push_back(a0); e.push_back(b0); }
+        }
+        HIPCHK(ctx, hipStreamSynchronize(st_));
+        double tot = 0;
+        for (size_t i = 0; i + 1 < e.size(); i += 2) { float f = 0; hipEventElapsedTime(&f, e[i], e[i + 1]); tot += f; }
+        out_ms[mode] = tot / reps;
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return STAN_OK;
+}
 #endif
 
 // un-scale on export

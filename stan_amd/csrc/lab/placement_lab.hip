@@ -230,3 +230,10 @@ extern "C" int stan_hip_lab_placement_cross(stan_ctx *ctx, stan_matrix *K, int32
     for (int t = 1; t < n; t++) hipFree(cand[t]);
     return STAN_OK;
 }
+
+int stan_spmv_incg_lab(stan_ctx *ctx, stan_matrix *K, int reps, double *out_ms);
+extern "C" int stan_hip_lab_incg_penalty(stan_ctx *ctx, stan_matrix *K, int32_t reps, double *out_ms) {
+    if (!ctx || !K || !out_ms || reps < 1 || K->ctx != ctx) return STAN_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return stan_spmv_incg_lab(ctx, K, reps, out_ms);
+}
