@@ -108,6 +108,11 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
 #define STAN_OPT_CG_FOLD_REDUCE 11 /* 1 (default): the block of a producing kernel that finishes last adds up the
                            per-block partial sums (fixed order); 0: separate one-block reduction launches,
                            same order, same bits. */
+#define STAN_OPT_VEC_STORE_NT 12 /* cache policy of the vectors the CG's vector kernels WRITE: bit 0 = the search
+                           direction p (k_update; gathered by the next product), bit 1 = the residual r (k_step).
+                           Default 3: both leave through non-temporal stores (cg.hip: dirty vector lines left in
+                           the cache hierarchy are written back inside the next read-only sweep of the matrix).
+                           Same arithmetic for every value. */
 #define STAN_OPT_PLACEMENT_TRIES 8 /* 1 (default): plain allocation.  n = 2..64: the value array of K is
                            allocated by search (placement.hip) -- the same matrix streams ~8 % faster from some
                            hipMalloc blocks than from others, for the life of the block, and fresh allocations

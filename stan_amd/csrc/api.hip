@@ -105,6 +105,7 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
     else if (option == STAN_OPT_CG_FUSED_REFRESH) ctx->cg_fused_refresh = value != 0;
     else if (option == STAN_OPT_CG_SINGLE_REDUCE) ctx->cg_single_reduce = value != 0;
     else if (option == STAN_OPT_CG_FOLD_REDUCE) ctx->cg_fold_reduce = value != 0;
+    else if (option == STAN_OPT_VEC_STORE_NT && value >= 0 && value <= 3) ctx->vec_store_nt = (int)value;
     else if (option == STAN_OPT_POOL) {
         ctx->pool.enabled = value != 0;
         if (!ctx->pool.enabled) {

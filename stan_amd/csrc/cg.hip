@@ -29,6 +29,17 @@
 #ifndef STAN_Y_NT
 #define STAN_Y_NT 1
 #endif
+// round 2 (tools/fold_ab.py, profiles/r02/fold_ab_incg_*.txt): the in-CG penalty of the SpMV is the
+// REWRITING of its gather vector between two products.  With the rewrite done by plain stores
+// (k_update, round 1: "the new p stays cacheable") the following product ran 1.5 / 2.7 / 11 % slower
+// than back to back on three boxes; rewritten with non-temporal stores 1.0 % slower on the box that
+// showed 11 %: dirty vector lines left behind in the cache hierarchy are written back to DRAM
+// later, INSIDE the read-only sweep of the matrix, and every one of those scattered writes turns
+// a channel around.  So the vectors a kernel writes leave it through non-temporal stores.
+// (STAN_OPT_VEC_STORE_NT: bit 0 = k_update stores p non-temporally, bit 1 = k_step stores r so.)
+#ifndef STAN_R_NT
+#define STAN_R_NT 1   // k_refresh: the new residual stored non-temporally
+#endif
 
 namespace {
 
@@ -557,6 +568,7 @@ struct step_args {
     fold_args fold;       // r.r and the merit sum are added up by the last block (-> sc[S_R2NEW..])
 };
 
+template <bool RNT>
 __global__ void __launch_bounds__(VEC_T) k_step(step_args a) {
     __shared__ double sh[4];
     __shared__ int sh_last;
@@ -594,14 +606,16 @@ __global__ void __launch_bounds__(VEC_T) k_step(step_args a) {
 #else
             const double cr = a.r[i] - alpha * a.v[i];
 #endif
-            a.r[i] = cr;
+            if (RNT) __builtin_nontemporal_store(cr, a.r + i);
+            else a.r[i] = cr;
             s_r2 += cr * cr;
             if (a.merit) s_mf -= (cr + a.bh[i]) * cx;
         } else if (a.refresh == 2) {
             const double b = a.bh[i];
             const double mv = a.w[i] + alpha * a.v[i];  // A^ (x + a p)
             const double cr = b - mv;
-            a.r[i] = cr;
+            if (RNT) __builtin_nontemporal_store(cr, a.r + i);
+            else a.r[i] = cr;
             s_r2 += cr * cr;
             s_mf += (mv - 2 * b) * cx;
         }
@@ -629,7 +643,11 @@ k_refresh(int64_t n3, int64_t k, const int64_t *st, const double *bh, const doub
     for (int64_t i = (int64_t)blockIdx.x * VEC_T + threadIdx.x; i < n3; i += stride) {
         const double b = bh[i], m = mv[i];
         const double cr = b - m;
+#if STAN_R_NT
+        __builtin_nontemporal_store(cr, r + i);
+#else
         r[i] = cr;
+#endif
         s_r2 += cr * cr;
         s_mf += (m - 2 * b) * cx[i];
     }
@@ -643,6 +661,7 @@ k_refresh(int64_t n3, int64_t k, const int64_t *st, const double *bh, const doub
 }
 
 // decisions of the iteration + p = r + beta p
+template <bool PNT>
 __global__ void __launch_bounds__(VEC_T)
 k_update(int64_t n3, int64_t k, double *sc, int64_t *st, double epsf, int64_t maxits,
          int64_t its_before_restart, int merit_stop, const double *r, double *p) {
@@ -676,11 +695,15 @@ k_update(int64_t n3, int64_t k, double *sc, int64_t *st, double epsf, int64_t ma
     if (type) return;
     const int64_t stride = (int64_t)gridDim.x * VEC_T;
     for (int64_t i = (int64_t)blockIdx.x * VEC_T + threadIdx.x; i < n3; i += stride)
+    {
 #if STAN_VEC_NT >= 2
-        p[i] = __builtin_nontemporal_load(r + i) + beta * __builtin_nontemporal_load(p + i);  // the new p stays cacheable
+        const double pn = __builtin_nontemporal_load(r + i) + beta * __builtin_nontemporal_load(p + i);
 #else
-        p[i] = r[i] + beta * p[i];
+        const double pn = r[i] + beta * p[i];
 #endif
+        if (PNT) __builtin_nontemporal_store(pn, p + i);
+        else p[i] = pn;
+    }
 }
 
 // ---- single-reduction CG (Chronopoulos-Gear), STAN_OPT_CG_SINGLE_REDUCE --------------------------
@@ -760,12 +783,12 @@ __global__ void __launch_bounds__(VEC_T) k_vec_sr(sr_args a) {
         const double pi = ri + beta * a.p[i];
         const double si = __builtin_nontemporal_load(a.w + i) + beta * a.s[i];
         const double cx = __builtin_nontemporal_load(a.xcur + i) + alpha * pi;
-        a.p[i] = pi;
-        a.s[i] = si;
+        __builtin_nontemporal_store(pi, a.p + i);
+        __builtin_nontemporal_store(si, a.s + i);
         __builtin_nontemporal_store(cx, a.xnext + i);
         if (!a.refresh) {
             const double cr = ri - alpha * si;
-            a.r[i] = cr;   // gathered by the product that follows: stays cacheable
+            __builtin_nontemporal_store(cr, a.r + i);   // gathered by the product that follows (see STAN_P_NT)
             if (a.merit_stop) s_mf -= (cr + a.bh[i]) * cx;
         }
     }
@@ -1244,7 +1267,8 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             a.refresh = refresh ? (fused ? 2 : 1) : 0;
             a.merit = ctx->cg_merit_stop ? 1 : 0;
             a.fold = vec_fold(sc + S_R2NEW);
-            hipLaunchKernelGGL(k_step, dim3(vg), dim3(VEC_T), 0, st_, a);
+            if (ctx->vec_store_nt & 2) hipLaunchKernelGGL(k_step<true>, dim3(vg), dim3(VEC_T), 0, st_, a);
+            else hipLaunchKernelGGL(k_step<false>, dim3(vg), dim3(VEC_T), 0, st_, a);
             n_launch++;
             if (a.refresh == 1) {
                 // a -5/-4 stop of this iteration is caught by k_refresh/k_update (ITER_B <= k)
@@ -1256,8 +1280,12 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             }
             if (!foldr) { reduce_if_unfolded((int)vg, 2, sc + S_R2NEW); n_launch++; }
             if (dist) { rc = stan_comm_allreduce_sum_f64(ctx, sc + S_R2NEW, 2); n_coll++; if (rc) break; }
-            hipLaunchKernelGGL(k_update, dim3(vg), dim3(VEC_T), 0, st_, n3, k, sc, stt, eps_f,
-                               (int64_t)max_its, its_before_restart, ctx->cg_merit_stop ? 1 : 0, r, p);
+            if (ctx->vec_store_nt & 1)
+                hipLaunchKernelGGL(k_update<true>, dim3(vg), dim3(VEC_T), 0, st_, n3, k, sc, stt, eps_f,
+                                   (int64_t)max_its, its_before_restart, ctx->cg_merit_stop ? 1 : 0, r, p);
+            else
+                hipLaunchKernelGGL(k_update<false>, dim3(vg), dim3(VEC_T), 0, st_, n3, k, sc, stt, eps_f,
+                                   (int64_t)max_its, its_before_restart, ctx->cg_merit_stop ? 1 : 0, r, p);
             n_launch++;
         }
         if (rc) break;
@@ -1562,7 +1590,7 @@ int stan_spmv_incg_lab(stan_ctx *ctx, stan_matrix *K, int reps, double *out_ms) 
                 double hs[S_NSCAL] = {0}; hs[S_VMV] = 1.0; hs[S_RHO0] = hs[S_RHO1] = 1e-30;
                 HIPCHK(ctx, hipMemcpyAsync(scal, hs, sizeof(hs), hipMemcpyHostToDevice, st_));
                 a.sc = scal;
-                hipLaunchKernelGGL(k_step, dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, a);
+                hipLaunchKernelGGL(k_step<false>, dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, a);
             }
             // 4: rewritten with non-temporal stores; 5: rewritten (plain), then read once front to back
             // by a streaming kernel (does a read pull it into the memory-side cache?); 6: like 5 with nt stores

@@ -24,6 +24,7 @@ OPT_PLACEMENT_TRIES = 8
 OPT_POOL_MAX_BYTES = 9
 OPT_CG_SINGLE_REDUCE = 10
 OPT_CG_FOLD_REDUCE = 11
+OPT_VEC_STORE_NT = 12
 E_HIP, E_ARG, E_ALLOC, E_DETJ, E_DOF_LAYOUT, E_VALENCE, E_COMM, E_UNSUPPORTED = (
     -1, -2, -3, -4, -5, -6, -7, -8)
 

@@ -28,6 +28,24 @@ for r in range(rounds):
         print("round %d %-14s its %d  cg %.1f ms  in-CG SpMV %.4f ms (%d launches)  2-product %.4f ms  launches/it %.2f" %
               (r, tag, rep["iterations"], p["cg_ms"], p["spmv_ms_total"] / max(p["spmv_launches"], 1), p["spmv_launches"],
                p["spmv2_ms_total"] / max(p["spmv2_launches"], 1), p["loop_kernel_launches"] / max(p["loop_iterations_enqueued"], 1)))
+ctx.set_option(hip.OPT_CG_FOLD_REDUCE, 1); ctx.set_option(hip.OPT_CG_SINGLE_REDUCE, 0)
+for r in range(rounds):
+    for v in (9, 12, 0):
+        ctx.set_option(hip.OPT_SPMV_VARIANT, v)
+        U, rep = K.cg_solve(job.F, 1e-8)
+        p = ctx.profile()
+        print("round %d kernel variant %2d: cg %.1f ms  in-CG SpMV %.4f ms  2-product %.4f ms" %
+              (r, v, p["cg_ms"], p["spmv_ms_total"] / max(p["spmv_launches"], 1), p["spmv2_ms_total"] / max(p["spmv2_launches"], 1)))
+ctx.set_option(hip.OPT_SPMV_VARIANT, -1)
+for r in range(rounds):
+    for pol in (0, 1, 2, 3):
+        ctx.set_option(hip.OPT_VEC_STORE_NT, pol)
+        U, rep = K.cg_solve(job.F, 1e-8)
+        p = ctx.profile()
+        sp = p["spmv_ms_total"] + p["spmv2_ms_total"]
+        print("round %d vector store policy %d (bit0 p nt, bit1 r nt): cg %.1f ms  in-CG SpMV %.4f ms  non-SpMV per iteration %.4f ms" %
+              (r, pol, p["cg_ms"], p["spmv_ms_total"] / max(p["spmv_launches"], 1), (p["cg_ms"] - sp) / rep["iterations"]))
+ctx.set_option(hip.OPT_VEC_STORE_NT, 3)
 if hasattr(ctx.lib, "stan_hip_lab_incg_penalty"):   # lab build only
     import ctypes as C
     out = np.zeros(7)
