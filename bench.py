@@ -161,12 +161,18 @@ def main():
         ctx.set_option(hip.OPT_CG_SINGLE_REDUCE, 1)
     ctx.set_profiling(True)
 
-    # inputs resident in HBM before the timed region
+    # inputs resident in HBM before the timed region; a rank of a sharded run holds only the elements
+    # that touch its rows (the node arrays stay whole: any node may be a halo column)
+    conn, emat, etyp = job.conn, job.elem_mat, job.elem_type
+    if world > 1:
+        from stan_amd import host
+        mine = host.partition_elements(job.node_index, job.conn, world, rank)
+        conn, emat, etyp = job.conn[mine], job.elem_mat[mine], job.elem_type[mine]
     d_xyz = torch.from_numpy(job.xyz).to(dev)
     d_dof = torch.from_numpy(job.node_dof).to(dev)
-    d_conn = torch.from_numpy(job.conn).to(dev)
-    d_mat = torch.from_numpy(job.elem_mat).to(dev)
-    d_typ = torch.from_numpy(job.elem_type).to(dev)
+    d_conn = torch.from_numpy(np.ascontiguousarray(conn)).to(dev)
+    d_mat = torch.from_numpy(np.ascontiguousarray(emat)).to(dev)
+    d_typ = torch.from_numpy(np.ascontiguousarray(etyp)).to(dev)
     d_red = torch.from_numpy(job.red).to(dev)
     d_F = torch.from_numpy(job.F).to(dev)
     d_U = torch.zeros(job.n_red, dtype=torch.float64, device=dev)
@@ -175,7 +181,7 @@ def main():
 
     def step():
         K = ctx.assemble_hex8_dev(job.xyz.shape[0], d_xyz.data_ptr(), d_dof.data_ptr(),
-                                  job.conn.shape[0], d_conn.data_ptr(), d_mat.data_ptr(),
+                                  conn.shape[0], d_conn.data_ptr(), d_mat.data_ptr(),
                                   d_typ.data_ptr(), job.mat_E_nu, job.n_dof, d_red.data_ptr())
         rep = K.cg_solve_dev(d_F.data_ptr(), d_U.data_ptr(), args.eps, args.max_its, prec)
         prof = ctx.profile()
@@ -278,6 +284,7 @@ def main():
                                         ("fp32" if args.mixed else "48-bit fixed-point" if args.fixed48
                                          else "fp64"),
                        "parallelism": "rows sharded x%d" % world,
+                       "elements_on_rank0": int(conn.shape[0]),
                        # the block pool keeps K's arrays between steps; with tries > 1 the first
                        # assembly picks the fastest-streaming of several hipMalloc blocks
                        "placement_tries": args.placement_tries,
@@ -285,7 +292,7 @@ def main():
                                             "probe_ms_kept": prof["placement_ms_best"],
                                             "probe_ms_slowest": prof["placement_ms_worst"]},
                        # SURVEY section 8d assembly bytes: coords + connectivity read, K written once
-                       "assembly_GBs": (job.conn.shape[0] * (192 + 32) + info["n_slots"] * 64 * 72)
+                       "assembly_GBs": (conn.shape[0] * (192 + 32) + info["n_slots"] * 64 * 72)
                                        / (asm_ms / args.steps * 1e-3) / 1e9 if asm_ms > 0 else None,
                        "device_read_GBs": dev_read},
             "roofline": {"bound": "hbm", "kernel": "k_spmv (BSELL-64 SpMV + fused p.Ap)",

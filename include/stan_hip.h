@@ -161,7 +161,10 @@ int stan_hip_assemble_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz,
                            const double *mat_E_nu, int64_t n_dof,
                            const int32_t *ndof_reduction, stan_matrix **outK);
 /* Same, but every array pointer (except mat_E_nu, host) is DEVICE memory already resident
- * in HBM on the context's GPU.  This is the entry bench.py times. */
+ * in HBM on the context's GPU.  This is the entry bench.py times.  A rank of a sharded run may
+ * pass only the elements that touch its block rows, in ascending order of their index in the whole
+ * model (stan_host_partition_elements): K's bits do not change, and the element number reported
+ * with STAN_E_DETJ is then an index into the arrays that were passed. */
 int stan_hip_assemble_hex8_dev(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
                                const int32_t *d_node_dof, int64_t n_elem, const int32_t *d_conn,
                                const int32_t *d_elem_mat, const uint8_t *d_elem_type,

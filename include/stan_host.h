@@ -79,6 +79,13 @@ int stan_host_partition_plan(int64_t n_nodes, const int32_t *node_index, int64_t
                              int32_t *nbr_ranks, int64_t *send_off, int32_t *send_rows,
                              int64_t *recv_off);
 
+/* Elements `rank` has to hold: every element with a node in its block-row range (boundary elements
+ * go to both owners).  elem_idx_out [<= n_elem] ascending; a launcher that keeps its inputs on the
+ * device passes exactly these to stan_hip_assemble_hex8_dev (the host-pointer entry filters itself). */
+int stan_host_partition_elements(int64_t n_nodes, const int32_t *node_index, int64_t n_elem,
+                                 const int32_t *conn, int32_t nranks, int32_t rank,
+                                 int32_t *elem_idx_out, int64_t *n_out);
+
 /* ---- STAN_Database object model + STdb codec (stan_amd/host/model.h) -----------------------
  * stan_db wraps a Database (Database.cs:10-21).  Text comes back through
  * stan_host_db_last_error.  Strings are UTF-8, NUL-terminated. */

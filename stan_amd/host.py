@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libstan_host.so")
 
 EXPORTS = ["stan_host_assign_dof", "stan_host_dof_reduction", "stan_host_load_vector",
            "stan_host_nodal_displacements", "stan_host_partition_rows", "stan_host_partition_plan",
-           "stan_host_cholesky_skyline_solve", "stan_host_lu_upper_solve"]
+           "stan_host_cholesky_skyline_solve", "stan_host_lu_upper_solve", "stan_host_partition_elements"]
 
 _lib = None
 
@@ -149,6 +149,20 @@ def partition_plan(node_index, conn, nranks, rank):
     return dict(row_starts=row_starts, halo_glob=halo[:nh.value].copy(), nbr=nbr[:k].copy(),
                 send_off=send_off[:k + 1].copy(), recv_off=recv_off[:k + 1].copy(),
                 send_rows=send_rows[:send_off[k]].copy())
+
+
+def partition_elements(node_index, conn, nranks, rank):
+    """Ascending indices of the elements `rank` must hold (stan_host_partition_elements)."""
+    node_index = np.ascontiguousarray(node_index, dtype=np.int32)
+    conn = np.ascontiguousarray(conn, dtype=np.int32).reshape(-1, 8)
+    out = np.zeros(conn.shape[0], np.int32)
+    n = C.c_int64(0)
+    rc = load().stan_host_partition_elements(C.c_int64(node_index.shape[0]), _p(node_index, C.c_int32),
+                                             C.c_int64(conn.shape[0]), _p(conn, C.c_int32), C.c_int32(nranks),
+                                             C.c_int32(rank), _p(out, C.c_int32), C.byref(n))
+    if rc:
+        raise StanHostError(rc, "partition_elements")
+    return out[:n.value].copy()
 
 
 # ---- STAN_Database mirror + STdb codec (stan_db part of include/stan_host.h) -----------------

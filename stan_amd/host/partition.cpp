@@ -92,3 +92,32 @@ extern "C" int stan_host_partition_plan(int64_t n_nodes, const int32_t *node_ind
     *n_nbr = nn;
     return STAN_HOST_OK;
 }
+
+// Elements a rank has to hold: those with at least one node in its block-row range (boundary
+// elements belong to both owners -- every rank assembles its rows without communication).
+// elem_idx_out [<= n_elem] ascending element indices; *n_out their number.  The host-pointer entry
+// of libstan_hip.so does this filtering itself; a launcher that keeps its inputs resident on the
+// device (stan_hip_assemble_hex8_dev) uses this to upload only the subset.
+extern "C" int stan_host_partition_elements(int64_t n_nodes, const int32_t *node_index, int64_t n_elem,
+                                            const int32_t *conn, int32_t nranks, int32_t rank,
+                                            int32_t *elem_idx_out, int64_t *n_out) {
+    if (n_nodes <= 0 || !node_index || n_elem < 0 || (n_elem && !conn) || nranks < 1 || rank < 0 ||
+        rank >= nranks || !n_out || (n_elem && !elem_idx_out))
+        return STAN_HOST_E_ARG;
+    std::vector<int64_t> rs((size_t)nranks + 1);
+    stan_host_partition_rows(n_nodes, nranks, rs.data());
+    const int64_t r0 = rs[(size_t)rank], r1 = rs[(size_t)rank + 1];
+    int64_t n = 0;
+    for (int64_t e = 0; e < n_elem; e++) {
+        bool mine = false;
+        for (int a = 0; a < 8; a++) {
+            const int32_t nd = conn[e * 8 + a];
+            if (nd < 0 || nd >= n_nodes) return STAN_HOST_E_ARG;
+            const int64_t row = node_index[nd];
+            mine |= row >= r0 && row < r1;
+        }
+        if (mine) elem_idx_out[n++] = (int32_t)e;
+    }
+    *n_out = n;
+    return STAN_HOST_OK;
+}

@@ -130,3 +130,22 @@ def test_fuzz_disconnected_mesh_is_an_error_on_both_sides(oracle, built_libs):
     rc, _ = oracle.assign_dof(2 * xyz.shape[0], two)
     assert rc != 0
     assert fuzz.random_job(5) is None and rng is not None   # seed 5 of the sweep is such a mesh
+
+
+def test_partition_elements_matches_brute_force(built_libs):
+    """stan_host_partition_elements: the elements a rank must hold = those with a node in its rows."""
+    from stan_amd import host, problem
+    job = problem.cube_job(7, jitter=0.1)
+    nb = job.xyz.shape[0]
+    for nranks in (1, 2, 3, 5):
+        seen = np.zeros(job.conn.shape[0], dtype=int)
+        for rank in range(nranks):
+            nsl = (nb + 63) // 64
+            r0 = min(nb, nsl * rank // nranks * 64)
+            r1 = nb if rank + 1 == nranks else min(nb, nsl * (rank + 1) // nranks * 64)
+            rows = job.node_index[job.conn]
+            want = np.nonzero(((rows >= r0) & (rows < r1)).any(axis=1))[0]
+            got = host.partition_elements(job.node_index, job.conn, nranks, rank)
+            assert np.array_equal(got, want.astype(np.int32))
+            seen[got] += 1
+        assert seen.min() >= 1 and (nranks == 1) == (seen.max() == 1)
