@@ -48,6 +48,7 @@ int load_rccl(stan_ctx *ctx) {
     SYM(GetUniqueId, "ncclGetUniqueId");
     SYM(CommInitRank, "ncclCommInitRank");
     SYM(CommDestroy, "ncclCommDestroy");
+    *(void **)(&n.CommAbort) = dlsym(n.handle, "ncclCommAbort");   // optional
     SYM(AllReduce, "ncclAllReduce");
     SYM(Broadcast, "ncclBroadcast");
     SYM(Send, "ncclSend");
@@ -80,6 +81,10 @@ __global__ void k_pack(int64_t n, const int32_t *rows, const double *vec, double
 
 // no communicator: fine for a single rank, an error for a detached rank of several
 int no_comm(stan_ctx *ctx) {
+    if (ctx->comm_broken) {
+        ctx->err = "the communicator was aborted after a peer rank failed";
+        return STAN_E_COMM;
+    }
     if (ctx->nranks == 1) return STAN_OK;
     ctx->err = "this context is a detached rank (comm_init without an id): no collectives";
     return STAN_E_COMM;
@@ -160,4 +165,13 @@ int stan_comm_allgather_rows(stan_ctx *ctx, stan_matrix *K, double *d_full) {
     }
     NCCLCHK(ctx, ctx->nccl.GroupEnd());
     return STAN_OK;
+}
+
+// A peer rank failed while this one may be blocked in a collective: abort the communicator so that
+// its queued work returns (ncclCommAbort), and refuse every later collective on this context.
+void stan_comm_abort(stan_ctx *ctx) {
+    if (!ctx->comm) return;
+    if (ctx->nccl.CommAbort) ctx->nccl.CommAbort(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_broken = true;
 }

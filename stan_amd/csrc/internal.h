@@ -38,6 +38,7 @@ struct rccl_api {
     int (*GetUniqueId)(void *) = nullptr;
     int (*CommInitRank)(void **, int, const void *, int) = nullptr;  // ncclUniqueId by value
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommAbort)(void *) = nullptr;   // optional: frees ranks blocked in a collective (multi.hip)
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
@@ -124,6 +125,7 @@ struct stan_ctx {
     // communicator
     int rank = 0, nranks = 1;
     void *comm = nullptr;
+    bool comm_broken = false;  // the communicator was aborted after a peer failed: no further collectives
     rccl_api nccl;
     // solver options (include/stan_hip.h STAN_OPT_*)
     bool cg_merit_stop = true;
@@ -243,6 +245,7 @@ int stan_comm_allreduce_sum_f64(stan_ctx *ctx, double *d_buf, size_t count);
 // receive into d_vec + 3*nloc (halo region).
 int stan_comm_halo_exchange(stan_ctx *ctx, stan_matrix *K, double *d_vec);
 int stan_comm_allgather_rows(stan_ctx *ctx, stan_matrix *K, double *d_full_blockvec);
+void stan_comm_abort(stan_ctx *ctx);
 
 // device memory helpers (see stan_pool)
 static inline int stan_dmalloc_bytes(stan_ctx *ctx, void **p, size_t bytes) {

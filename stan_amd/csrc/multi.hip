@@ -9,7 +9,9 @@
 // torch.distributed.run) makes on its ranks -- and hands back rank 0's results: the sharding,
 // the halo exchange, the all-reduces and the result gather are the code of comm.hip / cg.hip,
 // unchanged.  The host sees the single-GPU API: init_multi, assemble, cg_solve, matrix_free.
+#include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -28,6 +30,7 @@ struct stan_group {
     std::vector<stan_ctx *> ctx;         // one ordinary context per device, rank = index
     std::vector<worker *> w;
     std::string err;
+    bool broken = false;                 // a rank failed inside a sharded call: the communicators were aborted
 };
 
 namespace {
@@ -60,10 +63,34 @@ int run_all(stan_group *g, const std::function<int(int)> &fn) {
         w->cv.notify_all();
     }
     int rc = STAN_OK;
+    // A rank that fails inside a sharded call returns while its peers wait for it in a collective
+    // (ADVICE r01): once one worker has come back with an error, the others get a grace period and
+    // then their communicators are aborted, which makes their queued RCCL work return.
+    bool failed = false, aborted = false;
     for (int r = 0; r < n; r++) {
         stan_group::worker *w = g->w[r];
         std::unique_lock<std::mutex> lk(w->m);
-        w->cv.wait(lk, [&] { return w->done; });
+        while (!w->done) {
+            if (!failed) {
+                w->cv.wait_for(lk, std::chrono::milliseconds(200), [&] { return w->done; });
+                if (w->done) break;
+                lk.unlock();   // has some other rank already failed?
+                for (int q = 0; q < n && !failed; q++) {
+                    std::lock_guard<std::mutex> lq(g->w[q]->m);
+                    failed = g->w[q]->done && g->w[q]->rc != STAN_OK;
+                }
+                lk.lock();
+            } else if (!aborted) {
+                if (w->cv.wait_for(lk, std::chrono::seconds(5), [&] { return w->done; })) break;
+                lk.unlock();
+                for (int q = 0; q < n; q++)
+                    if (g->ctx[q]) stan_comm_abort(g->ctx[q]);
+                g->broken = aborted = true;
+                lk.lock();
+            } else
+                w->cv.wait(lk, [&] { return w->done; });
+        }
+        if (w->rc != STAN_OK) failed = true;
         if (w->rc != STAN_OK && rc == STAN_OK) {
             rc = w->rc;
             g->err = "rank " + std::to_string(r) + ": " + (g->ctx[r] ? g->ctx[r]->err : std::string("no context"));
@@ -151,6 +178,7 @@ int stan_group_assemble(stan_ctx *lead, int64_t n_nodes, const double *xyz, cons
                         const int32_t *red, stan_matrix **outK) {
     stan_group *g = lead->group;
     lead->err.clear();
+    if (g->broken) { lead->err = "a rank failed earlier and the communicators were aborted: destroy this handle"; return STAN_E_COMM; }
     stan_matrix *K = new stan_matrix();
     K->ctx = lead;
     K->parts.assign(g->ctx.size(), nullptr);
@@ -195,11 +223,19 @@ int stan_group_cg_solve(stan_ctx *lead, stan_matrix *K, const double *F, double 
                         double *rel_residual) {
     stan_group *g = lead->group;
     lead->err.clear();
+    if (g->broken) { lead->err = "a rank failed earlier and the communicators were aborted: destroy this handle"; return STAN_E_COMM; }
     const size_t N = (size_t)K->n_red;
     // every rank ends with the whole U (the result gather of the sharded CG); rank 0 writes the
     // caller's buffer, the others a scratch copy
     std::vector<std::vector<double>> scratch(g->ctx.size());
+    // STAN_TEST_FAIL_RANK: test hook only (tests/test_gpu_multi.py: a rank that fails while its peers
+    // are inside the solve must not hang the host), like STAN_RCCL_LIB
+    const char *inject = getenv("STAN_TEST_FAIL_RANK");
     return run_all(g, [&](int r) {
+        if (inject && *inject && atoi(inject) == r) {
+            g->ctx[r]->err = "injected failure (STAN_TEST_FAIL_RANK)";
+            return (int)STAN_E_HIP;
+        }
         double *u = U;
         if (r != 0) { scratch[(size_t)r].resize(N ? N : 1); u = scratch[(size_t)r].data(); }
         return stan_hip_cg_solve(g->ctx[r], K->parts[r], F, eps_f, max_its, precision_mode, u,

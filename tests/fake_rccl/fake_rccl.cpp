@@ -32,7 +32,7 @@ constexpr int MAXOPS = 256;
 
 struct Desc { int peer; int kind; size_t off, bytes; };  // kind 0 = send to peer, 1 = broadcast
 struct Header {
-    std::atomic<int> init, arrived, sense;
+    std::atomic<int> init, arrived, sense, aborted;   // aborted: ncclCommAbort by any rank frees every waiter
     int nranks;
     int nops[MAXR];
     Desc ops[MAXR][MAXOPS];
@@ -62,6 +62,7 @@ bool wait_until(Comm *c, P pred, const char *what, int peer) {
     const auto t0 = std::chrono::steady_clock::now();
     long spins = 0;
     while (!pred()) {
+        if (c->h->aborted.load()) return false;
         sched_yield();
         if ((++spins & 0xfff) == 0 &&
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > STALL_S) {
@@ -192,10 +193,16 @@ int ncclCommInitRank(void **comm, int nranks, nccl_uid id, int rank) {
 
 int ncclCommDestroy(void *comm) {
     Comm *c = (Comm *)comm;
-    barrier(c, "destroy");
+    if (!c->h->aborted.load()) barrier(c, "destroy");
     if (c->rank == 0) shm_unlink(c->name);
     munmap((void *)c->h, c->bytes);
     delete c;
+    return 0;
+}
+
+int ncclCommAbort(void *comm) {   // like NCCL's: queued and blocked operations of this communicator return
+    Comm *c = (Comm *)comm;
+    c->h->aborted.store(1);
     return 0;
 }
 

@@ -98,3 +98,61 @@ def test_init_multi_fails_loudly_on_a_missing_device(built_libs):
     with pytest.raises(hip.StanHipError) as ei:
         hip.Context(devices=[0, 99])
     assert ei.value.code in (hip.E_HIP, hip.E_COMM)
+
+
+def test_a_failing_rank_does_not_hang_the_host(built_libs, tmp_path):
+    """a rank that fails inside the solve leaves its peers blocked in a collective.  The
+    group handle notices the failure, aborts the communicators after a grace period, reports the
+    failing rank and refuses further sharded calls."""
+    code = r'''
+import os, sys, time
+sys.path.insert(0, %r)
+import numpy as np, torch
+from stan_amd import hip, problem
+job = problem.cube_job(8)
+ctx = hip.Context(devices=[0, 0])
+K = ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+U, rep = K.cg_solve(job.F, 1e-8)
+assert rep["terminationtype"] == 1
+os.environ["STAN_TEST_FAIL_RANK"] = "1"
+t0 = time.time()
+try:
+    K.cg_solve(job.F, 1e-8)
+    print("NOERROR")
+except hip.StanHipError as e:
+    print("ERR1", e.code, "rank 1" in str(e), "%%.1f" %% (time.time() - t0))
+del os.environ["STAN_TEST_FAIL_RANK"]
+try:
+    K.cg_solve(job.F, 1e-8)
+    print("NOERROR")
+except hip.StanHipError as e:
+    print("ERR2", e.code, "aborted" in str(e))
+K.free(); ctx.close()
+print("CLOSED")
+''' % ROOT
+    env = dict(os.environ, STAN_RCCL_LIB=FAKE)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180, env=env, cwd=ROOT)
+    out = p.stdout
+    assert p.returncode == 0, out[-2000:] + p.stderr[-3000:]
+    l1 = [l for l in out.splitlines() if l.startswith("ERR1")][0].split()
+    assert l1[1] == "-1" and l1[2] == "True" and float(l1[3]) < 30.0
+    l2 = [l for l in out.splitlines() if l.startswith("ERR2")][0].split()
+    assert l2[1] == "-7" and l2[2] == "True"
+    assert "CLOSED" in out
+
+
+def test_more_ranks_than_slices_through_the_group_handle(built_libs, oracle, tmp_path):
+    """3^3 cube = 64 nodes = ONE slice: ranks 1..3 of four own no rows (empty shards, zero-size
+    launches, no boundary product to fold the reduction into), classic and single-reduction loop."""
+    out = str(tmp_path / "multi.npz")
+    env = dict(os.environ, STAN_RCCL_LIB=FAKE)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multi_worker.py"), "3", "4", out, "small"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    d = np.load(out)
+    job = problem.cube_job(3, jitter=0.05)
+    rc, A = oracle.assemble(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+    Uo, rep = oracle.cg(A, job.F, 1e-6)
+    assert int(d["term"]) == int(d["term_s"]) == rep["terminationtype"] == 1
+    for key in ("U", "Ux", "Us"):
+        assert np.abs(d[key] - Uo).max() <= 1e-4 * np.abs(Uo).max(), key
