@@ -91,7 +91,9 @@ int run_all(stan_group *g, const std::function<int(int)> &fn) {
                 w->cv.wait(lk, [&] { return w->done; });
         }
         if (w->rc != STAN_OK) failed = true;
-        if (w->rc != STAN_OK && rc == STAN_OK) {
+        // the code that is reported: the first rank's, except that a communicator error gives way to
+        // any other one (after an abort every surviving rank reports STAN_E_COMM: a consequence)
+        if (w->rc != STAN_OK && (rc == STAN_OK || (rc == STAN_E_COMM && w->rc != STAN_E_COMM))) {
             rc = w->rc;
             g->err = "rank " + std::to_string(r) + ": " + (g->ctx[r] ? g->ctx[r]->err : std::string("no context"));
         }

@@ -112,7 +112,7 @@ from stan_amd import hip, problem
 job = problem.cube_job(8)
 ctx = hip.Context(devices=[0, 0])
 K = ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
-U, rep = K.cg_solve(job.F, 1e-8)
+U, rep = K.cg_solve(job.F, 1e-6)
 assert rep["terminationtype"] == 1
 os.environ["STAN_TEST_FAIL_RANK"] = "1"
 t0 = time.time()
