@@ -30,12 +30,14 @@
 #define STAN_Y_NT 1
 #endif
 // round 2 (tools/fold_ab.py, profiles/r02/fold_ab_incg_*.txt): the in-CG penalty of the SpMV is the
-// REWRITING of its gather vector between two products.  With the rewrite done by plain stores
-// (k_update, round 1: "the new p stays cacheable") the following product ran 1.5 / 2.7 / 11 % slower
-// than back to back on three boxes; rewritten with non-temporal stores 1.0 % slower on the box that
-// showed 11 %: dirty vector lines left behind in the cache hierarchy are written back to DRAM
-// later, INSIDE the read-only sweep of the matrix, and every one of those scattered writes turns
-// a channel around.  So the vectors a kernel writes leave it through non-temporal stores.
+// REWRITING of its gather vector between two products, nothing else (a k_step pass in between costs
+// nothing).  Rewritten by plain stores the following product ran 1.5 / 1.6 / 2.7 / 3.9 / 11 %
+// slower than back to back on five boxes; by non-temporal stores (no load of the line before)
+// 1.0 / 1.1 / 1.1 / 1.0 %; non-temporal stores followed by one streaming read of the vector: 0 %
+// (but that read costs what it saves).  Agent- / system-scope (write-through) stores: like plain.
+// k_update is a read-modify-write of p: a non-temporal store to a line its own plain load has just
+// brought into L2 changes nothing, non-temporal loads AND stores recover a part (0.2 % where the
+// penalty is 1.6 %).  That is what STAN_OPT_VEC_STORE_NT selects; it never costs anything.
 // (STAN_OPT_VEC_STORE_NT: bit 0 = k_update stores p non-temporally, bit 1 = k_step stores r so.)
 #ifndef STAN_R_NT
 #define STAN_R_NT 1   // k_refresh: the new residual stored non-temporally
@@ -696,11 +698,11 @@ k_update(int64_t n3, int64_t k, double *sc, int64_t *st, double epsf, int64_t ma
     const int64_t stride = (int64_t)gridDim.x * VEC_T;
     for (int64_t i = (int64_t)blockIdx.x * VEC_T + threadIdx.x; i < n3; i += stride)
     {
-#if STAN_VEC_NT >= 2
-        const double pn = __builtin_nontemporal_load(r + i) + beta * __builtin_nontemporal_load(p + i);
-#else
-        const double pn = r[i] + beta * p[i];
-#endif
+        // PNT: p is read, rewritten and not touched again until the next product gathers it: take it
+        // past the caches both ways (a non-temporal store to a line a plain load has just brought
+        // into L2 only dirties that line: lab modes 9-12 of tools/fold_ab.py)
+        const double pn = PNT ? __builtin_nontemporal_load(r + i) + beta * __builtin_nontemporal_load(p + i)
+                              : r[i] + beta * p[i];
         if (PNT) __builtin_nontemporal_store(pn, p + i);
         else p[i] = pn;
     }
@@ -1552,6 +1554,24 @@ __global__ void k_fill_nt(double *p, int64_t n, double v) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) __builtin_nontemporal_store(v, p + i);
 }
+__global__ void k_fill_scope(double *p, int64_t n, double v, int scope) {   // 0: agent-scope (sc1), 1: system-scope stores
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (scope == 0) __hip_atomic_store(p + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_store(p + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// the rewrite k_update really does: x = r + beta x (read-modify-write of the gather vector)
+template <bool LNT, bool SNT>
+__global__ void k_rmw(double *x, const double *r, int64_t n, double beta) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double xo = LNT ? __builtin_nontemporal_load(x + i) : x[i];
+        const double ro = LNT ? __builtin_nontemporal_load(r + i) : r[i];
+        const double v = ro * 0.0 + 1.0 + beta * (xo - 1.0);   // stays 1.0
+        if (SNT) __builtin_nontemporal_store(v, x + i); else x[i] = v;
+    }
+}
 __global__ void k_read_only(const double *p, int64_t n, double *sink) {
     double a = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1576,7 +1596,7 @@ int stan_spmv_incg_lab(stan_ctx *ctx, stan_matrix *K, int reps, double *out_ms) 
     hipLaunchKernelGGL(k_fill, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, x, ng, 1.0);
     for (double *q : {ctx->ws.xb[0], ctx->ws.xb[1], ctx->ws.r, ctx->ws.w})
         hipLaunchKernelGGL(k_fill, dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, q, n3, 0.5);
-    for (int mode = 0; mode < 7; mode++) {
+    for (int mode = 0; mode < 13; mode++) {
         event_bag ev;
         std::vector<hipEvent_t> e;
         for (int r = 0; r < reps + 2; r++) {
@@ -1596,6 +1616,13 @@ int stan_spmv_incg_lab(stan_ctx *ctx, stan_matrix *K, int reps, double *out_ms) 
             // by a streaming kernel (does a read pull it into the memory-side cache?); 6: like 5 with nt stores
             if (mode == 4 || mode == 6) hipLaunchKernelGGL(k_fill_nt, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, x, ng, 1.0);
             if (mode == 5) hipLaunchKernelGGL(k_fill, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, x, ng, 1.0);
+            // 9-12: read-modify-write like k_update: plain/plain, plain load + nt store, nt load + nt store, nt load + plain store
+            if (mode == 9) hipLaunchKernelGGL((k_rmw<false, false>), dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, x, ctx->ws.r, n3, 0.5);
+            if (mode == 10) hipLaunchKernelGGL((k_rmw<false, true>), dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, x, ctx->ws.r, n3, 0.5);
+            if (mode == 11) hipLaunchKernelGGL((k_rmw<true, true>), dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, x, ctx->ws.r, n3, 0.5);
+            if (mode == 12) hipLaunchKernelGGL((k_rmw<true, false>), dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, x, ctx->ws.r, n3, 0.5);
+            // 7 / 8: rewritten with agent-scope (sc1, write-through) / system-scope stores
+            if (mode == 7 || mode == 8) hipLaunchKernelGGL(k_fill_scope, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, x, ng, 1.0, mode - 7);
             if (mode == 5 || mode == 6) hipLaunchKernelGGL(k_read_only, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, (const double *)x, ng, partial);
             hipEvent_t a0 = ev.make(), b0 = ev.make();
             hipEventRecord(a0, st_);
