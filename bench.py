@@ -280,9 +280,10 @@ def main():
                        "termination_type": rep["terminationtype"],
                        "rel_residual": rep["rel_residual"], "converged": bool(ok),
                        "assemble_ms": asm_ms / args.steps, "cg_ms": cg_ms / args.steps,
-                       "matrix_format": "BSELL-64 3x3 blocks (%s values + int32 block cols)" %
+                       "matrix_format": "BSELL-64 3x3 blocks (%s values + block cols as 16-bit offsets from a "
+                                        "per-slot base in %.1f %% of the slots, int32 in the rest)" %
                                         ("fp32" if args.mixed else "48-bit fixed-point" if args.fixed48
-                                         else "fp64"),
+                                         else "fp64", 100.0 * prof["col_slots_packed"] / max(info["n_slots"], 1)),
                        "parallelism": "rows sharded x%d" % world,
                        "elements_on_rank0": int(conn.shape[0]),
                        # the block pool keeps K's arrays between steps; with tries > 1 the first
@@ -303,6 +304,8 @@ def main():
                          "traffic_source": traffic_source,
                          "frac_reduced_system_bytes": frac_reduced,
                          "csr_equivalent_GBs": csr_equiv,
+                         # bytes of the format actually streamed (packed columns: 74 B per block, not 76);
+                         # frac_reduced_system_bytes prices SURVEY section 8d's 76-B formula instead
                          "bytes_per_launch": prof["spmv_bytes"], "avg_launch_ms": avg_ms,
                          "launches": int(spmv_n),
                          # refresh iterations: A p and A x from one matrix pass (not in the average)

@@ -113,6 +113,10 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
                            Default 3: both leave through non-temporal stores (cg.hip: dirty vector lines left in
                            the cache hierarchy are written back inside the next read-only sweep of the matrix).
                            Same arithmetic for every value. */
+#define STAN_OPT_PACKED_COLUMNS 13 /* 1 (default): the SpMV reads block-column indices as 16-bit offsets from a
+                           per-slot base, two slots per dword (2 B per block instead of 4; lossless, same
+                           products in the same order, same bits); slices whose offsets do not fit 16 bits keep
+                           the int32 stream.  0: int32 columns everywhere. */
 #define STAN_OPT_PLACEMENT_TRIES 8 /* 1 (default): plain allocation.  n = 2..64: the value array of K is
                            allocated by search (placement.hip) -- the same matrix streams ~8 % faster from some
                            hipMalloc blocks than from others, for the life of the block, and fresh allocations
@@ -290,6 +294,7 @@ typedef struct stan_profile {
     int64_t loop_iterations_enqueued; /* iterations those two counts cover                   */
     int32_t placement_candidates;     /* blocks the last allocation-by-search timed (0: none) */
     float placement_ms_best, placement_ms_worst; /* SpMV probe time of the kept / the slowest candidate */
+    int64_t col_slots_packed;         /* ELL slots whose columns the last solve read from the packed stream */
 } stan_profile;
 int stan_hip_set_profiling(stan_ctx *ctx, int32_t enabled);
 int stan_hip_get_profile(stan_ctx *ctx, stan_profile *out);

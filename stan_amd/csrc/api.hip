@@ -106,6 +106,7 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
     else if (option == STAN_OPT_CG_SINGLE_REDUCE) ctx->cg_single_reduce = value != 0;
     else if (option == STAN_OPT_CG_FOLD_REDUCE) ctx->cg_fold_reduce = value != 0;
     else if (option == STAN_OPT_VEC_STORE_NT && value >= 0 && value <= 3) ctx->vec_store_nt = (int)value;
+    else if (option == STAN_OPT_PACKED_COLUMNS) ctx->cols16 = value != 0;
     else if (option == STAN_OPT_POOL) {
         ctx->pool.enabled = value != 0;
         if (!ctx->pool.enabled) {
@@ -264,7 +265,8 @@ void stan_hip_matrix_free(stan_matrix *K) {
     // the solves that used these buffers have been synchronised by their own calls; the blocks go
     // back to the context's pool (stan_pool) or to the driver
     for (void *q : {(void *)K->d_slot_ptr, (void *)K->d_rowlen, (void *)K->d_cols, (void *)K->d_vals,
-                    (void *)K->d_vals32, (void *)K->d_vals48, (void *)K->d_red, (void *)K->d_fixmask,
+                    (void *)K->d_vals32, (void *)K->d_vals48, (void *)K->d_cols16, (void *)K->d_colbase,
+                    (void *)K->d_pair_ptr, (void *)K->d_slice_packed, (void *)K->d_red, (void *)K->d_fixmask,
                     (void *)K->d_scale, (void *)K->d_send_rows, (void *)K->d_halo_glob, (void *)K->d_sendbuf,
                     (void *)K->d_sl_int, (void *)K->d_sl_bnd})
         stan_dfree(K->ctx, q);

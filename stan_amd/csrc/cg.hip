@@ -253,6 +253,43 @@ k_to_fx48(int64_t nslots, const double *vals, uint32_t *out, unsigned long long 
     if (nbad) atomicAdd(bad, (unsigned long long)nbad);
 }
 
+// packed column stream (struct colstream): one wavefront per slice
+__global__ void __launch_bounds__(256)
+k_pack_cols(int32_t nslices, const int32_t *slot_ptr, const int32_t *cols, const int32_t *pair_ptr,
+            uint32_t *packed, int32_t *base, uint8_t *ok) {
+    const int lane = threadIdx.x & 63;
+    const int64_t slice = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slice >= nslices) return;
+    const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
+    uint32_t *out = packed + (int64_t)pair_ptr[slice] * 64 + lane;
+    bool fits = true;
+    uint32_t lo = 0;
+    for (int32_t k = k0; k < k1; k++) {
+        const int32_t c = cols[(int64_t)k * 64 + lane];
+        int32_t mn = c, mx = c;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            mn = min(mn, __shfl_xor(mn, d, 64));
+            mx = max(mx, __shfl_xor(mx, d, 64));
+        }
+        if (lane == 0) base[k] = mn;
+        fits = fits && (mx - mn) < 65536;
+        const uint32_t dlt = (uint32_t)(c - mn) & 0xffffu;
+        if (((k - k0) & 1) == 0) lo = dlt;
+        else { *out = lo | (dlt << 16); out += 64; }
+    }
+    if ((k1 - k0) & 1) *out = lo;
+    if (lane == 0) ok[slice] = fits ? 1 : 0;
+}
+__global__ void k_pair_counts(int32_t nslices, const int32_t *slot_ptr, int32_t *cnt) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < nslices) cnt[s] = (slot_ptr[s + 1] - slot_ptr[s] + 1) >> 1;
+}
+__global__ void k_count_ok(int32_t nslices, const uint8_t *ok, const int32_t *slot_ptr, unsigned long long *out) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < nslices && ok[s]) atomicAdd(out, (unsigned long long)(slot_ptr[s + 1] - slot_ptr[s]));
+}
+
 // b^[i] = s_i * F[d - red[d]] on free DOFs, 0 on fixed ones; also x0 = 0, r = p = b^ and
 // partial sums of b^.b^ (x0 = 0 => r0 = b^, merit0 = 0).
 __global__ void __launch_bounds__(VEC_T)
@@ -359,19 +396,44 @@ __device__ __forceinline__ void load9(const VT *vp, double a[9]) {
     }
 }
 
+// Packed column stream (round 2): the block-column indices of a slot are, in reference (BFS) DOF
+// order, within a few thousand of each other across the 64 rows of a slice, so a slot stores its
+// smallest column once (a wave-uniform scalar) and every lane a 16-bit offset, two slots per
+// dword: 2 B per block instead of 4 (74 B instead of 76 with fp64 values: -2.6 % of the SpMV's
+// bytes, lossless, same products in the same order -> same bits).  Slices whose offsets do not fit
+// (the ragged last slice, rows coupling owned and halo columns far apart) keep the int32 stream.
+struct colstream {
+    const uint32_t *packed;   // [pair][64]: offset of slot 2j in the low half, of slot 2j+1 in the high half
+    const int32_t *base;      // [slot] smallest column of the slot
+    const int32_t *pair_ptr;  // [nslices + 1] first pair of every slice
+    const uint8_t *ok;        // [nslices] 1 = this slice is in the packed stream
+};
+
+#define STAN_SPMV_BLOCK(C, VP)                                                        \
+    {                                                                                 \
+        double a[9];                                                                  \
+        load9<NT, VT>(VP, a);                                                         \
+        double x0 = x[3 * (C)], x1 = x[3 * (C) + 1], x2 = x[3 * (C) + 2];             \
+        if (vstream<VT>::FX) { x0 *= FX48_INV; x1 *= FX48_INV; x2 *= FX48_INV; }      \
+        y0 += a[0] * x0 + a[1] * x1 + a[2] * x2;                                      \
+        y1 += a[3] * x0 + a[4] * x1 + a[5] * x2;                                      \
+        y2 += a[6] * x0 + a[7] * x1 + a[8] * x2;                                      \
+    }
+
 template <typename VT, int DOT, int VAR>
 __global__ void __launch_bounds__(256)
 k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
        const int32_t *__restrict__ cols, const VT *__restrict__ vals,
        const double *__restrict__ x, double *__restrict__ y, double *partial,
        const int64_t *st, int64_t kiter, const int32_t *__restrict__ slist, int32_t nlist,
-       int32_t poff, fold_args fold) {
+       int32_t poff, fold_args fold, colstream cs) {
     __shared__ double sh[4];
     __shared__ int sh_last;
     if (stopped(st, kiter)) return;
     constexpr bool NT = ((VAR & 1) != 0 && VAR < 8) || (VAR >= 9 && VAR != 13);  // 13 = 9 without the hint; 14-16 lab
     constexpr bool XCD = (VAR & 2) != 0 && VAR < 8;
     constexpr int UNR = (((VAR & 4) != 0 && VAR < 8) || VAR == 12) ? 4 : 2;
+    constexpr int UNR2 = 1;         // the packed-column loop handles two slots per trip (unrolling it further costs 40 VGPRs)
     // VAR 9/10/11: XCD-chunked mapping.  Workgroups go round-robin to the 8 XCDs; here every
     // window of 8*C consecutive workgroups is dealt so that each XCD gets C CONSECUTIVE ones
     // (C = 32 / 8 / 128): an XCD's L2 then holds the x window of one contiguous run of rows
@@ -438,17 +500,30 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
             }
         } else
 #endif
-        {
+        if (cs.packed && cs.ok[slice]) {   // wave-uniform: a slice is packed or not
+            const uint32_t *cq = cs.packed + (int64_t)cs.pair_ptr[slice] * 64 + lane;
+            const int32_t *bp = cs.base + __builtin_amdgcn_readfirstlane(k0);   // scalar loads
+            int32_t k = k0;
+#pragma unroll UNR2
+            for (; k + 1 < k1; k += 2) {
+                const uint32_t wd = ld_stream<NT>(cq);
+                const int64_t c = (int64_t)bp[0] + (int64_t)(wd & 0xffffu);
+                const int64_t c2 = (int64_t)bp[1] + (int64_t)(wd >> 16);
+                STAN_SPMV_BLOCK(c, vp)
+                STAN_SPMV_BLOCK(c2, vp + vstream<VT>::STRIDE)
+                cq += 64;
+                bp += 2;
+                vp += 2 * vstream<VT>::STRIDE;
+            }
+            if (k < k1) {
+                const int64_t c = (int64_t)bp[0] + (int64_t)(ld_stream<NT>(cq) & 0xffffu);
+                STAN_SPMV_BLOCK(c, vp)
+            }
+        } else {
 #pragma unroll UNR
             for (int32_t k = k0; k < k1; k++) {
                 const int64_t c = ld_stream<NT>(cp);
-                double a[9];
-                load9<NT, VT>(vp, a);
-                double x0 = x[3 * c], x1 = x[3 * c + 1], x2 = x[3 * c + 2];
-                if (vstream<VT>::FX) { x0 *= FX48_INV; x1 *= FX48_INV; x2 *= FX48_INV; }
-                y0 += a[0] * x0 + a[1] * x1 + a[2] * x2;
-                y1 += a[3] * x0 + a[4] * x1 + a[5] * x2;
-                y2 += a[6] * x0 + a[7] * x1 + a[8] * x2;
+                STAN_SPMV_BLOCK(c, vp)
                 cp += 64;
                 vp += vstream<VT>::STRIDE;
             }
@@ -491,7 +566,7 @@ k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
         const int32_t *__restrict__ cols, const VT *__restrict__ vals,
         const double *__restrict__ x, const double *__restrict__ x2, double *__restrict__ y,
         double *__restrict__ y2, double *partial, const int64_t *st, int64_t kiter,
-        const int32_t *__restrict__ slist, int32_t nlist, int32_t poff, fold_args fold) {
+        const int32_t *__restrict__ slist, int32_t nlist, int32_t poff, fold_args fold, colstream cs) {
     __shared__ double sh[4];
     __shared__ int sh_last;
     if (stopped(st, kiter)) return;
@@ -510,26 +585,51 @@ k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
         const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
         const int32_t *cp = cols + (int64_t)k0 * 64 + lane;
         const VT *vp = vals + (int64_t)k0 * vstream<VT>::STRIDE + lane;
-#pragma unroll 2
-        for (int32_t k = k0; k < k1; k++) {
-            const int64_t c = ld_stream<true>(cp);
-            double a[9];
-            load9<true, VT>(vp, a);
-            double x0 = x[3 * c], x1 = x[3 * c + 1], xx2 = x[3 * c + 2];
-            double u0 = x2[3 * c], u1 = x2[3 * c + 1], u2 = x2[3 * c + 2];
-            if (vstream<VT>::FX) {
-                x0 *= FX48_INV; x1 *= FX48_INV; xx2 *= FX48_INV;
-                u0 *= FX48_INV; u1 *= FX48_INV; u2 *= FX48_INV;
+#define STAN_SPMV2_BLOCK(C, VP)                                                       \
+    {                                                                                 \
+        double a[9];                                                                  \
+        load9<true, VT>(VP, a);                                                       \
+        double x0 = x[3 * (C)], x1 = x[3 * (C) + 1], xx2 = x[3 * (C) + 2];            \
+        double u0 = x2[3 * (C)], u1 = x2[3 * (C) + 1], u2 = x2[3 * (C) + 2];          \
+        if (vstream<VT>::FX) {                                                        \
+            x0 *= FX48_INV; x1 *= FX48_INV; xx2 *= FX48_INV;                          \
+            u0 *= FX48_INV; u1 *= FX48_INV; u2 *= FX48_INV;                           \
+        }                                                                             \
+        y0 += a[0] * x0 + a[1] * x1 + a[2] * xx2;                                     \
+        y1 += a[3] * x0 + a[4] * x1 + a[5] * xx2;                                     \
+        yy2 += a[6] * x0 + a[7] * x1 + a[8] * xx2;                                    \
+        z0 += a[0] * u0 + a[1] * u1 + a[2] * u2;                                      \
+        z1 += a[3] * u0 + a[4] * u1 + a[5] * u2;                                      \
+        z2 += a[6] * u0 + a[7] * u1 + a[8] * u2;                                      \
+    }
+        if (cs.packed && cs.ok[slice]) {
+            const uint32_t *cq = cs.packed + (int64_t)cs.pair_ptr[slice] * 64 + lane;
+            const int32_t *bp = cs.base + __builtin_amdgcn_readfirstlane(k0);
+            int32_t k = k0;
+            for (; k + 1 < k1; k += 2) {
+                const uint32_t wd = ld_stream<true>(cq);
+                const int64_t c = (int64_t)bp[0] + (int64_t)(wd & 0xffffu);
+                const int64_t c2 = (int64_t)bp[1] + (int64_t)(wd >> 16);
+                STAN_SPMV2_BLOCK(c, vp)
+                STAN_SPMV2_BLOCK(c2, vp + vstream<VT>::STRIDE)
+                cq += 64;
+                bp += 2;
+                vp += 2 * vstream<VT>::STRIDE;
             }
-            y0 += a[0] * x0 + a[1] * x1 + a[2] * xx2;
-            y1 += a[3] * x0 + a[4] * x1 + a[5] * xx2;
-            yy2 += a[6] * x0 + a[7] * x1 + a[8] * xx2;
-            z0 += a[0] * u0 + a[1] * u1 + a[2] * u2;
-            z1 += a[3] * u0 + a[4] * u1 + a[5] * u2;
-            z2 += a[6] * u0 + a[7] * u1 + a[8] * u2;
-            cp += 64;
-            vp += vstream<VT>::STRIDE;
+            if (k < k1) {
+                const int64_t c = (int64_t)bp[0] + (int64_t)(ld_stream<true>(cq) & 0xffffu);
+                STAN_SPMV2_BLOCK(c, vp)
+            }
+        } else {
+#pragma unroll 2
+            for (int32_t k = k0; k < k1; k++) {
+                const int64_t c = ld_stream<true>(cp);
+                STAN_SPMV2_BLOCK(c, vp)
+                cp += 64;
+                vp += vstream<VT>::STRIDE;
+            }
         }
+#undef STAN_SPMV2_BLOCK
         if (row < nloc) {
 #if STAN_Y_NT  // both products are read exactly once, by k_step
             __builtin_nontemporal_store(y0, y + 3 * row); __builtin_nontemporal_store(y1, y + 3 * row + 1);
@@ -886,11 +986,13 @@ unsigned launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double
     if (grid == 0) return 0;
     fold.nblocks = grid;
     fold.np = (int)grid + poff;
+    const colstream cs = ctx->cols16 && K->d_cols16 ? colstream{K->d_cols16, K->d_colbase, K->d_pair_ptr, K->d_slice_packed}
+                                                    : colstream{nullptr, nullptr, nullptr, nullptr};
 #define SPMV_CASE(V)                                                                          \
     case V:                                                                                   \
         hipLaunchKernelGGL((k_spmv<VT, DOT, V>), dim3(grid), dim3(256), 0, stream, K->nslices, \
                            K->nloc, K->d_slot_ptr, K->d_cols, vals, x, y, partial, st, k,     \
-                           slist, nlist, poff, fold);                                         \
+                           slist, nlist, poff, fold, cs);                                     \
         break;
     // auto (-1): non-temporal matrix stream + XCD-chunked workgroup mapping (variant 9), with the
     // loop unrolled by 4 for the FIXED-48 stream, whose iterations carry 21 % fewer bytes in
@@ -922,8 +1024,10 @@ unsigned launch_spmv2(stan_ctx *ctx, stan_matrix *K, const VT *vals, const doubl
     if (grid == 0) return 0;
     fold.nblocks = grid;
     fold.np = (int)grid + poff;
+    const colstream cs = ctx->cols16 && K->d_cols16 ? colstream{K->d_cols16, K->d_colbase, K->d_pair_ptr, K->d_slice_packed}
+                                                    : colstream{nullptr, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL((k_spmv2<VT>), dim3(grid), dim3(256), 0, stream, K->nslices, K->nloc, K->d_slot_ptr,
-                       K->d_cols, vals, x, x2, y, y2, partial, st, k, slist, nlist, poff, fold);
+                       K->d_cols, vals, x, x2, y, y2, partial, st, k, slist, nlist, poff, fold, cs);
     return grid;
 }
 
@@ -1022,6 +1126,44 @@ int stan_matrix_make_fx48(stan_ctx *ctx, stan_matrix *K) {
     return STAN_OK;
 }
 
+// Packed column stream of K (struct colstream), built once per matrix; the int32 columns stay (the
+// assembly, scaling and export kernels use them).
+int stan_matrix_make_cols16(stan_ctx *ctx, stan_matrix *K) {
+    if (K->d_cols16 || K->nslices <= 0) return STAN_OK;
+    hipStream_t st_ = ctx->stream;
+    dev_bufs bufs;
+    int32_t *cnt; int64_t *ptr64;
+    STANCHK(alloc(ctx, bufs, &cnt, (size_t)K->nslices + 1));
+    STANCHK(alloc(ctx, bufs, &ptr64, (size_t)K->nslices + 2));
+    hipLaunchKernelGGL(k_pair_counts, dim3(nblk(K->nslices, 256)), dim3(256), 0, st_, K->nslices, K->d_slot_ptr, cnt);
+    STANCHK(stan_scan_exclusive(ctx, cnt, ptr64, K->nslices));
+    std::vector<int64_t> h((size_t)K->nslices + 1);
+    HIPCHK(ctx, hipMemcpyAsync(h.data(), ptr64, h.size() * 8, hipMemcpyDeviceToHost, st_));
+    HIPCHK(ctx, hipStreamSynchronize(st_));
+    const int64_t npairs = h[(size_t)K->nslices];
+    if (npairs >= ((int64_t)1 << 31)) return STAN_OK;   // pair index is int32: keep the plain columns
+    std::vector<int32_t> h32(h.size());
+    for (size_t i = 0; i < h.size(); i++) h32[i] = (int32_t)h[i];
+    STANCHK(stan_dmalloc(ctx, &K->d_pair_ptr, h32.size()));
+    STANCHK(stan_dmalloc(ctx, &K->d_colbase, (size_t)(K->nslots > 0 ? K->nslots : 1)));
+    STANCHK(stan_dmalloc(ctx, &K->d_slice_packed, (size_t)K->nslices));
+    uint32_t *packed;
+    STANCHK(stan_dmalloc(ctx, &packed, (size_t)(npairs > 0 ? npairs : 1) * 64));
+    HIPCHK(ctx, hipMemcpyAsync(K->d_pair_ptr, h32.data(), h32.size() * 4, hipMemcpyHostToDevice, st_));
+    hipLaunchKernelGGL(k_pack_cols, dim3(nblk(K->nslices, 4)), dim3(256), 0, st_, K->nslices, K->d_slot_ptr, K->d_cols,
+                       K->d_pair_ptr, packed, K->d_colbase, K->d_slice_packed);
+    unsigned long long *d_cnt = (unsigned long long *)(ctx->d_status + SS_COUNTER);
+    HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 8, st_));
+    hipLaunchKernelGGL(k_count_ok, dim3(nblk(K->nslices, 256)), dim3(256), 0, st_, K->nslices, K->d_slice_packed,
+                       K->d_slot_ptr, d_cnt);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_COUNTER, d_cnt, 8, hipMemcpyDeviceToHost, st_));
+    HIPCHK(ctx, hipStreamSynchronize(st_));   // h32 must outlive the copy
+    K->slots_packed = ctx->h_status[SS_COUNTER];
+    K->d_cols16 = packed;
+    return STAN_OK;
+}
+
 // NOTE on the halo layout: vectors that are gathered by the SpMV (p, x) hold the owned
 // block rows first, padded to whole slices, then the halo block columns:
 //   [ 3*nslices*64 owned+pad | 3*nhalo ]
@@ -1051,6 +1193,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         hipEventRecord(ev0, st_);
     }
     STANCHK(ensure_scaled(ctx, K));
+    if (ctx->cols16) STANCHK(stan_matrix_make_cols16(ctx, K));
     if (precision_mode == STAN_PREC_MIXED) STANCHK(stan_matrix_make_fp32(ctx, K));
     if (precision_mode == STAN_PREC_FIXED48) STANCHK(stan_matrix_make_fx48(ctx, K));
     // the stream the products really read (FIXED-48 falls back to fp64 when K is not SPD-scalable)
@@ -1367,7 +1510,13 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         ctx->prof.iterations = (int32_t)its;
         ctx->prof.termination_type = type;
         const int64_t blk_bytes = vs == STAN_PREC_FIXED48 ? 60 : vs == STAN_PREC_MIXED ? 40 : 76;
-        ctx->prof.spmv_bytes = K->nblocks * blk_bytes + 3 * K->nloc * 16 + K->nloc * 4;
+        // bytes of the format actually streamed: a block of a packed slice carries a 2-B column offset
+        // instead of a 4-B index (+ 4 B per slot for its base, shared by 64 rows)
+        const bool packed = ctx->cols16 && K->d_cols16;
+        const double packed_frac = packed && K->nslots > 0 ? (double)K->slots_packed / (double)K->nslots : 0.0;
+        ctx->prof.spmv_bytes = K->nblocks * blk_bytes + 3 * K->nloc * 16 + K->nloc * 4
+                               - (int64_t)(packed_frac * (double)K->nblocks * 2.0) + (packed ? K->slots_packed * 4 : 0);
+        ctx->prof.col_slots_packed = packed ? K->slots_packed : 0;
         ctx->prof.value_stream = vs;
         ctx->prof.cg_iteration_vector_bytes = 3 * K->nloc * 8 * 10;
         ctx->prof.loop_kernel_launches = n_launch;
@@ -1539,7 +1688,7 @@ int stan_spmv_probe_range(stan_ctx *ctx, stan_matrix *K, const double *vals, int
         if (r == 2) hipEventRecord(a, st_);
 #define LABV(V) case V: hipLaunchKernelGGL((k_spmv<double, 1, V>), dim3(grid), dim3(256), 0, st_, K->nslices, K->nloc, \
                            K->d_slot_ptr, K->d_cols, vals, x, y, partial, stt, (int64_t)1, list, s1 - s0, 0,           \
-                           fold_args{nullptr, 0, 0, nullptr}); break;
+                           fold_args{nullptr, 0, 0, nullptr}, colstream{nullptr, nullptr, nullptr, nullptr}); break;
         switch (variant) { LABV(0) LABV(13) LABV(14) LABV(15) LABV(16) LABV(12) default: LABV(9) }
 #undef LABV
     }
@@ -1628,7 +1777,8 @@ int stan_spmv_incg_lab(stan_ctx *ctx, stan_matrix *K, int reps, double *out_ms) 
             hipEventRecord(a0, st_);
             hipLaunchKernelGGL((k_spmv<double, 1, 9>), dim3(nblk(K->nslices, 4)), dim3(256), 0, st_, K->nslices, K->nloc,
                                K->d_slot_ptr, K->d_cols, K->d_vals, x, y, partial, stt, (int64_t)1,
-                               (const int32_t *)nullptr, K->nslices, 0, fold_args{nullptr, 0, 0, nullptr});
+                               (const int32_t *)nullptr, K->nslices, 0, fold_args{nullptr, 0, 0, nullptr},
+                               colstream{nullptr, nullptr, nullptr, nullptr});
             hipEventRecord(b0, st_);
             if (r >= 2) { e.push_back(a0); e.push_back(b0); }
         }

@@ -132,6 +132,7 @@ struct stan_ctx {
     int cg_rupdate = 10;
     bool cg_fused_refresh = true;  // A x and A p of a refresh iteration in one matrix pass
     bool cg_single_reduce = false; // Chronopoulos-Gear loop: one reduction point per iteration
+    bool cols16 = true;            // SpMV reads the packed column stream where a slice allows it
     int vec_store_nt = 3;          // bit 0: p (k_update), bit 1: r (k_step) leave through non-temporal stores
     bool cg_fold_reduce = true;    // reductions finished by the producing kernel's last block
     bool overlap_halo = true;  // interior SpMV on a side stream while the halo is exchanged
@@ -169,6 +170,11 @@ struct stan_matrix {
     int32_t *d_slot_ptr = nullptr;  // [nslices+1]
     int32_t *d_rowlen = nullptr;    // [nslices*64] blocks per row
     int32_t *d_cols = nullptr;      // [nslots][64] local block-column index
+    uint32_t *d_cols16 = nullptr;   // packed column stream of the SpMV (cg.hip colstream): [pair][64]
+    int32_t *d_colbase = nullptr;   //   [nslots] smallest column of each slot
+    int32_t *d_pair_ptr = nullptr;  //   [nslices+1]
+    uint8_t *d_slice_packed = nullptr;  // [nslices] 1 = slice is in the packed stream
+    int64_t slots_packed = 0;
     double *d_vals = nullptr;       // [nslots][9][64]
     float *d_vals32 = nullptr;      // same layout, fp32 copy (mixed precision)
     uint32_t *d_vals48 = nullptr;   // FIXED-48 stream of the scaled values, [slot][14][64] dwords
@@ -228,6 +234,7 @@ int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode
 int stan_spmv_local(stan_ctx *ctx, stan_matrix *K, const double *d_x, double *d_y);
 int stan_matrix_make_fp32(stan_ctx *ctx, stan_matrix *K);
 int stan_matrix_make_fx48(stan_ctx *ctx, stan_matrix *K);
+int stan_matrix_make_cols16(stan_ctx *ctx, stan_matrix *K);
 int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K);
 int stan_cg_workspace(stan_ctx *ctx, const stan_matrix *K);  // (re)allocates ctx->ws for K's sizes
 void stan_cg_workspace_free(stan_ctx *ctx);

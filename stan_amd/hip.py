@@ -25,6 +25,7 @@ OPT_POOL_MAX_BYTES = 9
 OPT_CG_SINGLE_REDUCE = 10
 OPT_CG_FOLD_REDUCE = 11
 OPT_VEC_STORE_NT = 12
+OPT_PACKED_COLUMNS = 13
 E_HIP, E_ARG, E_ALLOC, E_DETJ, E_DOF_LAYOUT, E_VALENCE, E_COMM, E_UNSUPPORTED = (
     -1, -2, -3, -4, -5, -6, -7, -8)
 
@@ -58,7 +59,8 @@ class Profile(C.Structure):
                 ("value_stream", C.c_int32), ("spmv2_ms_total", C.c_double), ("spmv2_launches", C.c_int64),
                 ("loop_kernel_launches", C.c_int64), ("loop_collectives", C.c_int64),
                 ("loop_iterations_enqueued", C.c_int64), ("placement_candidates", C.c_int32),
-                ("placement_ms_best", C.c_float), ("placement_ms_worst", C.c_float)]
+                ("placement_ms_best", C.c_float), ("placement_ms_worst", C.c_float),
+                ("col_slots_packed", C.c_int64)]
 
 
 class StanHipError(RuntimeError):

@@ -24,6 +24,10 @@ ctx.set_option(hip.OPT_CG_SINGLE_REDUCE, 1)
 Us, reps = K.cg_solve(job.F, 1e-6)
 profs = ctx.profile()
 ctx.set_option(hip.OPT_CG_SINGLE_REDUCE, 0)
+ctx.set_option(hip.OPT_PACKED_COLUMNS, 0)      # int32 column stream: the same bits on every shard
+Up, repp = K.cg_solve(job.F, 1e-6)
+ctx.set_option(hip.OPT_PACKED_COLUMNS, 1)
+assert repp == rep and np.array_equal(Up, U), "packed column stream changed the sharded solve"
 # per-element stress recovery split over the devices
 disp = np.zeros(job.n_dof); disp[job.red != -1] = U
 strain, stress = ctx.recover_hex8(job.xyz, disp[job.node_dof], job.conn, job.elem_mat, job.elem_type, job.mat_E_nu)

@@ -284,3 +284,36 @@ def test_config5_g1_mixed_precision_three_face_clamp(gpu_ctx, oracle):
     assert d64 <= kappa * 1e-8
     assert dm <= kappa * 6e-8
     K.free()
+
+
+@pytest.mark.parametrize("n,prec,jit", [(20, "fp64", 0.05), (33, "fp64", 0.0), (24, "fixed48", 0.1), (24, "mixed", 0.05)])
+def test_packed_column_stream_gives_the_same_bits(gpu_ctx, n, prec, jit):
+    """STAN_OPT_PACKED_COLUMNS: 16-bit column offsets from a per-slot base, two slots per dword --
+    lossless, the same products in the same order: U, the iteration count and a plain product must
+    be bit-identical to the int32 column stream; nearly every slot of a BFS-ordered mesh packs
+    (the ragged last slice, padded with column 0, is one that may not)."""
+    from stan_amd import hip
+    pm = {"fp64": hip.PREC_FP64, "fixed48": hip.PREC_FIXED48, "mixed": hip.PREC_MIXED}[prec]
+    job = problem.cube_job(n, jitter=jit)
+    K = gpu_ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type,
+                              job.mat_E_nu, job.red)
+    gpu_ctx.set_profiling(True)
+    out = {}
+    try:
+        for packed in (1, 0, 1):
+            gpu_ctx.set_option(hip.OPT_PACKED_COLUMNS, packed)
+            U, rep = K.cg_solve(job.F, 1e-10, precision_mode=pm)
+            pr = gpu_ctx.profile()
+            x = np.random.default_rng(3).standard_normal(job.n_red)
+            out.setdefault(packed, []).append((U, rep, pr["col_slots_packed"], pr["spmv_bytes"], K.spmv(x)))
+    finally:
+        gpu_ctx.set_option(hip.OPT_PACKED_COLUMNS, 1)
+        gpu_ctx.set_profiling(False)
+    (Ua, ra, na, ba, ya), (Uc, rc_, nc, bc, yc) = out[1]
+    Ub, rb, nb_, bb, yb = out[0][0]
+    assert ra == rb == rc_ and ra["iterations"] > 30
+    assert np.array_equal(Ua, Ub) and np.array_equal(Ua, Uc) and np.array_equal(ya, yb)
+    info = K.info()
+    assert nb_ == 0 and na == nc and 0.9 * info["n_slots"] <= na <= info["n_slots"]
+    assert ba < bb     # the profile prices the bytes of the stream that ran
+    K.free()
