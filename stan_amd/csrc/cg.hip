@@ -38,6 +38,8 @@
 // k_update is a read-modify-write of p: a non-temporal store to a line its own plain load has just
 // brought into L2 changes nothing, non-temporal loads AND stores recover a part (0.2 % where the
 // penalty is 1.6 %).  That is what STAN_OPT_VEC_STORE_NT selects; it never costs anything.
+// Writing the new p into the OTHER of two buffers (no line of it in any cache) was tried as well:
+// +1.2 % against +1.3 % for the in-place form with non-temporal loads and stores: not built.
 // (STAN_OPT_VEC_STORE_NT: bit 0 = k_update stores p non-temporally, bit 1 = k_step stores r so.)
 #ifndef STAN_R_NT
 #define STAN_R_NT 1   // k_refresh: the new residual stored non-temporally
@@ -1721,6 +1723,17 @@ __global__ void k_rmw(double *x, const double *r, int64_t n, double beta) {
         if (SNT) __builtin_nontemporal_store(v, x + i); else x[i] = v;
     }
 }
+// ping-pong form of the same rewrite: xo = r + beta xi into ANOTHER buffer
+template <bool LNT, bool SNT>
+__global__ void k_pingpong(double *xo, const double *xi, const double *r, int64_t n, double beta) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double xv = LNT ? __builtin_nontemporal_load(xi + i) : xi[i];
+        const double ro = LNT ? __builtin_nontemporal_load(r + i) : r[i];
+        const double v = ro * 0.0 + 1.0 + beta * (xv - 1.0);
+        if (SNT) __builtin_nontemporal_store(v, xo + i); else xo[i] = v;
+    }
+}
 __global__ void k_read_only(const double *p, int64_t n, double *sink) {
     double a = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1743,9 +1756,10 @@ int stan_spmv_incg_lab(stan_ctx *ctx, stan_matrix *K, int reps, double *out_ms) 
     int64_t init[T_NSTAT] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0, 0, 0, 0, 0, 0};
     HIPCHK(ctx, hipMemcpyAsync(stt, init, sizeof(init), hipMemcpyHostToDevice, st_));
     hipLaunchKernelGGL(k_fill, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, x, ng, 1.0);
-    for (double *q : {ctx->ws.xb[0], ctx->ws.xb[1], ctx->ws.r, ctx->ws.w})
+    for (double *q : {ctx->ws.xb[1], ctx->ws.r, ctx->ws.w})
         hipLaunchKernelGGL(k_fill, dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, q, n3, 0.5);
-    for (int mode = 0; mode < 13; mode++) {
+    hipLaunchKernelGGL(k_fill, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, ctx->ws.xb[0], ng, 1.0);
+    for (int mode = 0; mode < 15; mode++) {
         event_bag ev;
         std::vector<hipEvent_t> e;
         for (int r = 0; r < reps + 2; r++) {
@@ -1773,10 +1787,18 @@ int stan_spmv_incg_lab(stan_ctx *ctx, stan_matrix *K, int reps, double *out_ms) 
             // 7 / 8: rewritten with agent-scope (sc1, write-through) / system-scope stores
             if (mode == 7 || mode == 8) hipLaunchKernelGGL(k_fill_scope, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, x, ng, 1.0, mode - 7);
             if (mode == 5 || mode == 6) hipLaunchKernelGGL(k_read_only, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, (const double *)x, ng, partial);
+            // 13 / 14: the rewrite goes to the OTHER of two buffers (nt load + nt store / plain load + nt store)
+            double *xg = x;
+            if (mode == 13 || mode == 14) {
+                double *xa = (r & 1) ? x : ctx->ws.xb[0], *xi = (r & 1) ? ctx->ws.xb[0] : x;
+                if (mode == 13) hipLaunchKernelGGL((k_pingpong<true, true>), dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, xa, xi, ctx->ws.r, n3, 0.5);
+                else hipLaunchKernelGGL((k_pingpong<false, true>), dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, xa, xi, ctx->ws.r, n3, 0.5);
+                xg = xa;
+            }
             hipEvent_t a0 = ev.make(), b0 = ev.make();
             hipEventRecord(a0, st_);
             hipLaunchKernelGGL((k_spmv<double, 1, 9>), dim3(nblk(K->nslices, 4)), dim3(256), 0, st_, K->nslices, K->nloc,
-                               K->d_slot_ptr, K->d_cols, K->d_vals, x, y, partial, stt, (int64_t)1,
+                               K->d_slot_ptr, K->d_cols, K->d_vals, xg, y, partial, stt, (int64_t)1,
                                (const int32_t *)nullptr, K->nslices, 0, fold_args{nullptr, 0, 0, nullptr},
                                colstream{nullptr, nullptr, nullptr, nullptr});
             hipEventRecord(b0, st_);

@@ -39,7 +39,7 @@ int stan_hip_lab_placement_rounds(stan_ctx *ctx, stan_matrix *K, int32_t ntries,
 /* Does the placement of the vectors matter too?  See lab/placement_lab.hip. */
 int stan_hip_lab_placement_cross(stan_ctx *ctx, stan_matrix *K, int32_t ntries, double *out,
                                  double *cross_fast, double *cross_slow, int32_t *i_fast, int32_t *i_slow);
-/* The in-CG penalty of the SpMV, isolated: out_ms [13] = product alone back to back / gather vector
+/* The in-CG penalty of the SpMV, isolated: out_ms [15] = product alone back to back / gather vector
  * rewritten before every product / plus a k_step pass over other vectors / only that pass. */
 int stan_hip_lab_incg_penalty(stan_ctx *ctx, stan_matrix *K, int32_t reps, double *out_ms);
 #ifdef __cplusplus

@@ -48,11 +48,12 @@ for r in range(rounds):
 ctx.set_option(hip.OPT_VEC_STORE_NT, 3)
 if hasattr(ctx.lib, "stan_hip_lab_incg_penalty"):   # lab build only
     import ctypes as C
-    out = np.zeros(13)
+    out = np.zeros(15)
     ctx._chk(ctx.lib.stan_hip_lab_incg_penalty(ctx.h, K.k, C.c_int32(30), out.ctypes.data_as(C.POINTER(C.c_double))))
     print("SpMV alone, events around each product: back to back %.4f | gather vector rewritten before each %.4f | "
           "rewritten + a k_step pass in between %.4f | only the k_step pass %.4f | rewritten with nt stores %.4f | "
           "rewritten, then read once by a streaming kernel %.4f | nt stores, then read once %.4f | rewritten with agent-scope (sc1) stores %.4f | "
           "with system-scope stores %.4f | read-modify-write like k_update: plain load + plain store %.4f | plain load + nt store %.4f | "
-          "nt load + nt store %.4f | nt load + plain store %.4f ms" % tuple(out))
+          "nt load + nt store %.4f | nt load + plain store %.4f | ping-pong (written to the other of two buffers): nt load + nt store %.4f | "
+          "plain load + nt store %.4f ms" % tuple(out))
 K.free(); ctx.close()
