@@ -117,6 +117,11 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
                            per-slot base, two slots per dword (2 B per block instead of 4; lossless, same
                            products in the same order, same bits); slices whose offsets do not fit 16 bits keep
                            the int32 stream.  0: int32 columns everywhere. */
+#define STAN_OPT_CG_DEFER_X 14 /* 1 (default): when STAN_OPT_CG_MERIT_STOP is 0 (nothing needs the new iterate before
+                           the direction update) x' = x + alpha p is formed in the kernel that forms
+                           p' = r + beta p, so p is read once per iteration for both; same operands, same
+                           bits.  With the merit-function stop on (the library default) x' is formed earlier, as
+                           alglib does, whatever this option says. */
 #define STAN_OPT_PLACEMENT_TRIES 8 /* 1 (default): plain allocation.  n = 2..64: the value array of K is
                            allocated by search (placement.hip) -- the same matrix streams ~8 % faster from some
                            hipMalloc blocks than from others, for the life of the block, and fresh allocations

@@ -669,6 +669,8 @@ struct step_args {
     int merit;            // 0: the merit-function stop is off, skip its sum (and the b^ read)
     int refresh;          // 0: r -= a v; 1: only cx is formed here (r from a second SpMV);
                           // 2: fused refresh, r = b^ - (w + a v) with w = A^ x from the same pass
+    int defer_x;          // 1: x' = x + a p is formed by k_update (one read of p for both updates); only
+                          //    when the merit sum is off and the iteration needs no x' before k_update
     fold_args fold;       // r.r and the merit sum are added up by the last block (-> sc[S_R2NEW..])
 };
 
@@ -695,15 +697,18 @@ __global__ void __launch_bounds__(VEC_T) k_step(step_args a) {
     double s_r2 = 0, s_mf = 0;
     const int64_t stride = (int64_t)gridDim.x * VEC_T;
     for (int64_t i = (int64_t)blockIdx.x * VEC_T + threadIdx.x; i < a.n3; i += stride) {
+        double cx = 0;
+        if (!a.defer_x) {
 #if STAN_VEC_NT  // the iterate vectors pass through once per kernel: keep them out of the caches p lives in
-        const double pi = __builtin_nontemporal_load(a.p + i);
-        const double cx = __builtin_nontemporal_load(a.xcur + i) + alpha * pi;
-        __builtin_nontemporal_store(cx, a.xnext + i);
+            const double pi = __builtin_nontemporal_load(a.p + i);
+            cx = __builtin_nontemporal_load(a.xcur + i) + alpha * pi;
+            __builtin_nontemporal_store(cx, a.xnext + i);
 #else
-        const double pi = a.p[i];
-        const double cx = a.xcur[i] + alpha * pi;
-        a.xnext[i] = cx;
+            const double pi = a.p[i];
+            cx = a.xcur[i] + alpha * pi;
+            a.xnext[i] = cx;
 #endif
+        }
         if (a.refresh == 0) {
 #if STAN_VEC_NT
             const double cr = __builtin_nontemporal_load(a.r + i) - alpha * __builtin_nontemporal_load(a.v + i);
@@ -721,7 +726,7 @@ __global__ void __launch_bounds__(VEC_T) k_step(step_args a) {
             if (RNT) __builtin_nontemporal_store(cr, a.r + i);
             else a.r[i] = cr;
             s_r2 += cr * cr;
-            s_mf += (mv - 2 * b) * cx;
+            if (a.merit) s_mf += (mv - 2 * b) * cx;
         }
     }
     if (a.refresh != 1) {
@@ -768,7 +773,8 @@ k_refresh(int64_t n3, int64_t k, const int64_t *st, const double *bh, const doub
 template <bool PNT>
 __global__ void __launch_bounds__(VEC_T)
 k_update(int64_t n3, int64_t k, double *sc, int64_t *st, double epsf, int64_t maxits,
-         int64_t its_before_restart, int merit_stop, const double *r, double *p) {
+         int64_t its_before_restart, int merit_stop, const double *r, double *p,
+         const double *xcur, double *xnext /* non-null: the deferred x' = x + a p of this iteration */) {
     if (st[T_ITER_A] < k || st[T_ITER_B] <= k) return;
     const double r2 = sc[S_R2NEW], merit = sc[S_MERIT];
     const double rho = sc[S_RHO0 + (k & 1)], prevmf = sc[S_PMF0 + (k & 1)];
@@ -796,17 +802,26 @@ k_update(int64_t n3, int64_t k, double *sc, int64_t *st, double epsf, int64_t ma
             sc[S_PMF0 + ((k + 1) & 1)] = merit;
         }
     }
-    if (type) return;
     const int64_t stride = (int64_t)gridDim.x * VEC_T;
+    // alpha of this iteration, as k_step formed it (same operands, same bits)
+    const double alpha = xnext ? rho / sc[S_VMV] : 0.0;
+    if (type) {
+        // the iteration that stops (types 1, 5, -4 select x' = buffer k & 1) still owes its x'
+        if (xnext && xsel == (k & 1))
+            for (int64_t i = (int64_t)blockIdx.x * VEC_T + threadIdx.x; i < n3; i += stride)
+                __builtin_nontemporal_store(__builtin_nontemporal_load(xcur + i) + alpha * __builtin_nontemporal_load(p + i), xnext + i);
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * VEC_T + threadIdx.x; i < n3; i += stride)
     {
         // PNT: p is read, rewritten and not touched again until the next product gathers it: take it
         // past the caches both ways (a non-temporal store to a line a plain load has just brought
         // into L2 only dirties that line: lab modes 9-12 of tools/fold_ab.py)
-        const double pn = PNT ? __builtin_nontemporal_load(r + i) + beta * __builtin_nontemporal_load(p + i)
-                              : r[i] + beta * p[i];
+        const double po = PNT ? __builtin_nontemporal_load(p + i) : p[i];
+        const double pn = (PNT ? __builtin_nontemporal_load(r + i) : r[i]) + beta * po;
         if (PNT) __builtin_nontemporal_store(pn, p + i);
         else p[i] = pn;
+        if (xnext) __builtin_nontemporal_store(__builtin_nontemporal_load(xcur + i) + alpha * po, xnext + i);
     }
 }
 
@@ -1413,6 +1428,9 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             a.r = r; a.p = p; a.v = v; a.w = w; a.bh = bh; a.partial = partial;
             a.refresh = refresh ? (fused ? 2 : 1) : 0;
             a.merit = ctx->cg_merit_stop ? 1 : 0;
+            // x' = x + a p moves into k_update (p is read once for both updates: -79 MB of 714 per
+            // iteration at 148^3) unless the merit sum needs x' here or a literal refresh multiplies it
+            a.defer_x = (ctx->cg_defer_x && !a.merit && a.refresh != 1) ? 1 : 0;
             a.fold = vec_fold(sc + S_R2NEW);
             if (ctx->vec_store_nt & 2) hipLaunchKernelGGL(k_step<true>, dim3(vg), dim3(VEC_T), 0, st_, a);
             else hipLaunchKernelGGL(k_step<false>, dim3(vg), dim3(VEC_T), 0, st_, a);
@@ -1427,12 +1445,14 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             }
             if (!foldr) { reduce_if_unfolded((int)vg, 2, sc + S_R2NEW); n_launch++; }
             if (dist) { rc = stan_comm_allreduce_sum_f64(ctx, sc + S_R2NEW, 2); n_coll++; if (rc) break; }
+            const double *ux = a.defer_x ? a.xcur : nullptr;
+            double *uxn = a.defer_x ? a.xnext : nullptr;
             if (ctx->vec_store_nt & 1)
                 hipLaunchKernelGGL(k_update<true>, dim3(vg), dim3(VEC_T), 0, st_, n3, k, sc, stt, eps_f,
-                                   (int64_t)max_its, its_before_restart, ctx->cg_merit_stop ? 1 : 0, r, p);
+                                   (int64_t)max_its, its_before_restart, ctx->cg_merit_stop ? 1 : 0, r, p, ux, uxn);
             else
                 hipLaunchKernelGGL(k_update<false>, dim3(vg), dim3(VEC_T), 0, st_, n3, k, sc, stt, eps_f,
-                                   (int64_t)max_its, its_before_restart, ctx->cg_merit_stop ? 1 : 0, r, p);
+                                   (int64_t)max_its, its_before_restart, ctx->cg_merit_stop ? 1 : 0, r, p, ux, uxn);
             n_launch++;
         }
         if (rc) break;
@@ -1520,7 +1540,9 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
                                - (int64_t)(packed_frac * (double)K->nblocks * 2.0) + (packed ? K->slots_packed * 4 : 0);
         ctx->prof.col_slots_packed = packed ? K->slots_packed : 0;
         ctx->prof.value_stream = vs;
-        ctx->prof.cg_iteration_vector_bytes = 3 * K->nloc * 8 * 10;
+        // vector passes of one classic iteration: k_step reads r, v (+ p, x unless deferred; + b^ for the
+        // merit sum) and writes r (+ x); k_update reads r, p (+ x when deferred) and writes p (+ x)
+        ctx->prof.cg_iteration_vector_bytes = 3 * K->nloc * 8 * ((ctx->cg_defer_x && !ctx->cg_merit_stop ? 8 : 9) + (ctx->cg_merit_stop ? 1 : 0));
         ctx->prof.loop_kernel_launches = n_launch;
         ctx->prof.loop_collectives = n_coll;
         ctx->prof.loop_iterations_enqueued = k - 1;
@@ -1768,7 +1790,7 @@ int stan_spmv_incg_lab(stan_ctx *ctx, stan_matrix *K, int reps, double *out_ms) 
                 step_args a;
                 a.n3 = n3; a.k = 1; a.sc = nullptr; a.st = stt; a.xcur = ctx->ws.xb[0]; a.xnext = ctx->ws.xb[1];
                 a.r = ctx->ws.r; a.p = ctx->ws.w; a.v = y; a.bh = ctx->ws.bh; a.partial = partial; a.w = ctx->ws.w;
-                a.merit = 0; a.refresh = 0; a.fold = fold_args{nullptr, 0, 0, nullptr};
+                a.merit = 0; a.refresh = 0; a.defer_x = 0; a.fold = fold_args{nullptr, 0, 0, nullptr};
                 double *scal; STANCHK(alloc(ctx, bufs, &scal, (size_t)S_NSCAL));
                 double hs[S_NSCAL] = {0}; hs[S_VMV] = 1.0; hs[S_RHO0] = hs[S_RHO1] = 1e-30;
                 HIPCHK(ctx, hipMemcpyAsync(scal, hs, sizeof(hs), hipMemcpyHostToDevice, st_));

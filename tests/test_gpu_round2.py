@@ -317,3 +317,35 @@ def test_packed_column_stream_gives_the_same_bits(gpu_ctx, n, prec, jit):
     assert nb_ == 0 and na == nc and 0.9 * info["n_slots"] <= na <= info["n_slots"]
     assert ba < bb     # the profile prices the bytes of the stream that ran
     K.free()
+
+
+@pytest.mark.parametrize("fused_refresh", [1, 0])
+def test_deferred_x_update_gives_the_same_bits(gpu_ctx, oracle, fused_refresh):
+    """STAN_OPT_CG_DEFER_X (merit stop off): x' = x + alpha p formed by k_update instead of k_step --
+    the same operands in the same expression, so every stop (residual, MaxIts in the middle of a
+    refresh cycle, right on a refresh iteration) must return the same bits; and the answer is the
+    oracle's."""
+    from stan_amd import hip
+    job = problem.cube_job(18, jitter=0.05)
+    K, A = _assemble_both(gpu_ctx, oracle, job)
+    gpu_ctx.set_option(hip.OPT_CG_MERIT_STOP, 0)
+    gpu_ctx.set_option(hip.OPT_CG_FUSED_REFRESH, fused_refresh)
+    try:
+        for eps, maxits in ((1e-9, 0), (1e-30, 7), (1e-30, 10), (1e-30, 31), (1e-4, 0)):
+            res = {}
+            for d in (1, 0):
+                gpu_ctx.set_option(hip.OPT_CG_DEFER_X, d)
+                res[d] = K.cg_solve(job.F, eps, max_its=maxits)
+            (U1, r1), (U0, r0) = res[1], res[0]
+            assert r1 == r0, (r1, r0)
+            assert np.array_equal(U1, U0), (eps, maxits)
+            Uo, repo = oracle.cg(A, job.F, eps, maxits=maxits, merit_stop=False)
+            assert r1["terminationtype"] == repo["terminationtype"]
+            assert abs(r1["iterations"] - repo["iterations"]) <= max(2, repo["iterations"] // 50)
+            if maxits:
+                assert np.abs(U1 - Uo).max() <= 1e-9 * np.abs(Uo).max()      # the same iterates
+    finally:
+        gpu_ctx.set_option(hip.OPT_CG_DEFER_X, 1)
+        gpu_ctx.set_option(hip.OPT_CG_FUSED_REFRESH, 1)
+        gpu_ctx.set_option(hip.OPT_CG_MERIT_STOP, 1)
+    K.free()

@@ -46,6 +46,15 @@ for r in range(rounds):
         print("round %d vector store policy %d (bit0 p nt, bit1 r nt): cg %.1f ms  in-CG SpMV %.4f ms  non-SpMV per iteration %.4f ms" %
               (r, pol, p["cg_ms"], p["spmv_ms_total"] / max(p["spmv_launches"], 1), (p["cg_ms"] - sp) / rep["iterations"]))
 ctx.set_option(hip.OPT_VEC_STORE_NT, 3)
+for r in range(rounds):
+    for d in (0, 1):
+        ctx.set_option(hip.OPT_CG_DEFER_X, d)
+        U, rep = K.cg_solve(job.F, 1e-8)
+        p = ctx.profile()
+        sp = p["spmv_ms_total"] + p["spmv2_ms_total"]
+        print("round %d deferred x update %d: cg %.1f ms  in-CG SpMV %.4f ms  non-SpMV per iteration %.4f ms" %
+              (r, d, p["cg_ms"], p["spmv_ms_total"] / max(p["spmv_launches"], 1), (p["cg_ms"] - sp) / rep["iterations"]))
+ctx.set_option(hip.OPT_CG_DEFER_X, 1)
 if hasattr(ctx.lib, "stan_hip_lab_incg_penalty"):   # lab build only
     import ctypes as C
     out = np.zeros(15)
