@@ -9,7 +9,7 @@
 // hot path: K is exported as the upper CRS the reference holds and solved on the CPU (direct.cpp).
 // Extra switches (never stored in the STdb): --device N, --gpus N (devices 0..N-1) or --devices a,b,c
 // (several GPUs from this ONE process: stan_hip_init_multi, rows of K sharded, RCCL inside the CG),
-// --mixed, --fixed48, --no-merit-stop, --packed,
+// --mixed, --fixed48, --no-merit-stop, --packed, --placement-tries N (default 16; 1 = plain allocation),
 // --json (one JSON line with sizes, iterations, phase times and the SpMV's HBM rate).
 #include <chrono>
 #include <cstdio>
@@ -34,7 +34,7 @@ static int fail(const char *what, const std::string &msg) {
 
 int main(int argc, char **argv) {
     std::string path;
-    int device = 0, precision = STAN_PREC_FP64;
+    int device = 0, precision = STAN_PREC_FP64, placement_tries = 16;
     bool merit_stop = true, packed = false, json = false;
     std::vector<int> devices;
     for (int i = 1; i < argc; i++) {
@@ -50,6 +50,7 @@ int main(int argc, char **argv) {
                 if (*p == ',') p++;
             }
         }
+        else if (!strcmp(argv[i], "--placement-tries") && i + 1 < argc) placement_tries = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--mixed")) precision = STAN_PREC_MIXED;
         else if (!strcmp(argv[i], "--fixed48")) precision = STAN_PREC_FIXED48;
         else if (!strcmp(argv[i], "--no-merit-stop")) merit_stop = false;
@@ -63,7 +64,7 @@ int main(int argc, char **argv) {
         return 2;
     }
     SolverOptions opt;
-    opt.device = device; opt.devices = devices; opt.precision = precision; opt.merit_stop = merit_stop; opt.profile = json;
+    opt.device = device; opt.devices = devices; opt.precision = precision; opt.placement_tries = placement_tries; opt.merit_stop = merit_stop; opt.profile = json;
     SolverFunctions Functions(opt);  // Solver.cs:16
     Functions.Welcome_Messsage();
 
