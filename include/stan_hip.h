@@ -122,14 +122,15 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
                            p' = r + beta p, so p is read once per iteration for both; same operands, same
                            bits.  With the merit-function stop on (the library default) x' is formed earlier, as
                            alglib does, whatever this option says. */
-#define STAN_OPT_PLACEMENT_TRIES 8 /* 1 (default): plain allocation.  n = 2..64: the value array of K is
+#define STAN_OPT_PLACEMENT_TRIES 8 /* 8 (default; bench.py: 24).  1: plain allocation.  n = 2..64: the value array of K is
                            allocated by search (placement.hip) -- the same matrix streams ~8 % faster from some
                            hipMalloc blocks than from others, for the life of the block, and fresh allocations
                            land in the slow class in runs.  Candidates are allocated one after the other and
                            the SpMV is timed on each; the slow ones stay allocated while the search goes on,
                            until one is 5 % faster than the slowest seen, n candidates have been timed, or
-                           free device memory falls under 4 block sizes; the fastest is kept.  Costs ~5 ms per
-                           candidate once per context and size; the block pool keeps the winner.  Destroying a
+                           free device memory falls under 4 block sizes; the fastest is kept.  Only blocks of
+                           256 MB and more are searched for; costs ~5 ms per candidate once per context and size;
+                           the block pool keeps the winner; the results do not depend on it.  Destroying a
                            context detaches its matrices: they may be freed afterwards. */
 #define STAN_OPT_POOL 7 /* 1 (default): device blocks >= 8 MB freed by the library stay with the
                            context and are reused by its next allocations (a hipMalloc of tens of GB
