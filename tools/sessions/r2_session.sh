@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-2 GPU session: placement map (lab build), parity prints, rocprofv3 kernel trace + PMC passes.
-# usage (GPU box, repo root): bash tools/r2_session.sh <tag>
+# usage (GPU box, repo root): bash tools/sessions/r2_session.sh <tag>
 TAG=${1:-a}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/r02_$TAG
