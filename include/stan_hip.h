@@ -123,10 +123,11 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
                            bits.  With the merit-function stop on (the library default) x' is formed earlier, as
                            alglib does, whatever this option says. */
 #define STAN_OPT_PLACEMENT_TRIES 8 /* 8 (default; bench.py: 24).  1: plain allocation.  n = 2..64: the value array of K is
-                           allocated by search (placement.hip) -- the same matrix streams ~8 % faster from some
-                           hipMalloc blocks than from others, for the life of the block, and fresh allocations
-                           land in the slow class in runs.  Candidates are allocated one after the other and
-                           the SpMV is timed on each; the slow ones stay allocated while the search goes on,
+                           allocated by search (placement.hip) -- the SpMV is ~8 % slower, for the life of the
+                           blocks, when the matrix stream and the CG's vectors (allocated first, owned by the
+                           context) lie in the same group of device memory, and fresh allocations fall into one
+                           group in runs of tens of GB.  Candidates are allocated one after the other and the
+                           SpMV is timed on each with those vectors; the slow ones stay allocated while the search goes on,
                            until one is 5 % faster than the slowest seen, n candidates have been timed, or
                            free device memory falls under 4 block sizes; the fastest is kept.  Only blocks of
                            256 MB and more are searched for; costs ~5 ms per candidate once per context and size;
