@@ -129,7 +129,7 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
     else if (option == STAN_OPT_OVERLAP_HALO) ctx->overlap_halo = value != 0;
     else if (option == STAN_OPT_PLACEMENT_TRIES && value >= 1 && value <= 64) ctx->placement_tries = (int)value;
 #ifdef STAN_LAB
-    else if (option == STAN_OPT_SPMV_VARIANT && value >= -1 && value <= 16) ctx->spmv_variant = (int)value;
+    else if (option == STAN_OPT_SPMV_VARIANT && value >= -1 && value <= 18) ctx->spmv_variant = (int)value;
 #else   // the product library carries the three variants that give right answers (cg.hip)
     else if (option == STAN_OPT_SPMV_VARIANT && (value == -1 || value == 0 || value == 9 || value == 12))
         ctx->spmv_variant = (int)value;

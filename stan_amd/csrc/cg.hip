@@ -423,7 +423,9 @@ struct colstream {
     }
 
 template <typename VT, int DOT, int VAR>
-__global__ void __launch_bounds__(256)
+// lab 17 / 18: capped at 68 / 62 VGPRs for 7 / 8 waves per SIMD instead of 78 / 6: in-CG SpMV 1.071 /
+// 1.072 ms against 1.032 ms (profiles/r02/fold_ab_incg_n148_box9_register_caps.txt): more waves do not help
+__global__ void __launch_bounds__(256, (VAR == 17 ? 7 : VAR == 18 ? 8 : 1))
 k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
        const int32_t *__restrict__ cols, const VT *__restrict__ vals,
        const double *__restrict__ x, double *__restrict__ y, double *partial,
@@ -440,7 +442,7 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
     // window of 8*C consecutive workgroups is dealt so that each XCD gets C CONSECUTIVE ones
     // (C = 32 / 8 / 128): an XCD's L2 then holds the x window of one contiguous run of rows
     // while the chip as a whole still sweeps the matrix front to back.
-    constexpr int CH = (VAR == 9 || VAR == 12 || VAR >= 13) ? 32 : VAR == 10 ? 8 : VAR == 11 ? 128 : 0;  // 12 = 9 + unroll 4
+    constexpr int CH = (VAR == 9 || VAR == 12 || VAR >= 13) ? 32 :   /* 17, 18: = 9 with a register cap */ VAR == 10 ? 8 : VAR == 11 ? 128 : 0;  // 12 = 9 + unroll 4
     const int lane = threadIdx.x & 63;
     int64_t bid = blockIdx.x;
     if (XCD) {
@@ -1022,6 +1024,7 @@ unsigned launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double
 #ifdef STAN_LAB
         SPMV_CASE(1) SPMV_CASE(2) SPMV_CASE(3) SPMV_CASE(4) SPMV_CASE(5) SPMV_CASE(6) SPMV_CASE(7)
         SPMV_CASE(8) SPMV_CASE(10) SPMV_CASE(11) SPMV_CASE(13) SPMV_CASE(14) SPMV_CASE(15) SPMV_CASE(16)
+        SPMV_CASE(17) SPMV_CASE(18)
 #endif
         default:
         SPMV_CASE(0)

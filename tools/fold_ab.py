@@ -30,7 +30,7 @@ for r in range(rounds):
                p["spmv2_ms_total"] / max(p["spmv2_launches"], 1), p["loop_kernel_launches"] / max(p["loop_iterations_enqueued"], 1)))
 ctx.set_option(hip.OPT_CG_FOLD_REDUCE, 1); ctx.set_option(hip.OPT_CG_SINGLE_REDUCE, 0)
 for r in range(rounds):
-    for v in (9, 12, 0):
+    for v in ((9, 17, 18, 12, 0) if hasattr(ctx.lib, "stan_hip_lab_incg_penalty") else (9, 12, 0)):
         ctx.set_option(hip.OPT_SPMV_VARIANT, v)
         U, rep = K.cg_solve(job.F, 1e-8)
         p = ctx.profile()

@@ -1,6 +1,6 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r02_p
+OUT=$R/gpurun_out/r02_w
 mkdir -p $OUT
 cd $R
 export STAN_HIP_LIB=$R/stan_amd/csrc/build_lab/libstan_hip_lab.so
