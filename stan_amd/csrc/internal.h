@@ -140,7 +140,7 @@ struct stan_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     int assembly_mode = 0;     // 0 row-owner gather (default), 1 element-wave colour scatter
-    int placement_tries = 8;   // > 1: allocate the value stream by search (placement.hip); blocks >= 256 MB only
+    int placement_tries = 16;  // > 1: allocate the value stream by search (placement.hip); blocks >= 256 MB only
     float prof_placement_ms_best = 0, prof_placement_ms_worst = 0;
     int prof_placement_candidates = 0;
     int prof_colours = 0;
