@@ -117,7 +117,7 @@ def main():
                     help="STAN_OPT_CG_SINGLE_REDUCE: Chronopoulos-Gear loop (not the oracle's recurrences)")
     ap.add_argument("--cpu-n", type=int, default=56, help="cube edge of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--placement-tries", type=int, default=24,
+    ap.add_argument("--placement-tries", type=int, default=32,
                     help="STAN_OPT_PLACEMENT_TRIES: allocate the value array of K by trial in the first "
                          "(warm-up) assembly; 1 = plain allocation (the library default)")
     args = ap.parse_args()

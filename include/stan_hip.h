@@ -122,7 +122,7 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
                            p' = r + beta p, so p is read once per iteration for both; same operands, same
                            bits.  With the merit-function stop on (the library default) x' is formed earlier, as
                            alglib does, whatever this option says. */
-#define STAN_OPT_PLACEMENT_TRIES 8 /* 16 (default; bench.py: 24).  1: plain allocation.  n = 2..64: the value array of K is
+#define STAN_OPT_PLACEMENT_TRIES 8 /* 16 (default; bench.py: 32).  1: plain allocation.  n = 2..64: the value array of K is
                            allocated by search (placement.hip) -- the SpMV is ~8 % slower, for the life of the
                            blocks, when the matrix stream and the CG's vectors (allocated first, owned by the
                            context) lie in the same group of device memory, and fresh allocations fall into one
