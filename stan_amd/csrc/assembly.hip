@@ -794,8 +794,8 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
                            d_status);
     // (after the FILL pass: an allocation by trial times the SpMV itself, which needs the columns)
     STANCHK(stan_dmalloc_streamed(ctx, (void **)&K->d_vals, (size_t)K->nslots * 9 * 64 * 8,
-                                  [&](const void *q, float *ms) {
-                                      return stan_spmv_probe(ctx, K, q, STAN_PREC_FP64, ms);
+                                  [&](const void *q, float *ms, bool self) {
+                                      return stan_spmv_probe(ctx, K, q, STAN_PREC_FP64, ms, self);
                                   }));
     if (ctx->profiling) hipEventRecord(ev1, st);
 

@@ -1115,8 +1115,8 @@ int stan_matrix_make_fp32(stan_ctx *ctx, stan_matrix *K) {
     if (K->d_vals32) return STAN_OK;
     const int64_t n = K->nslots * 9 * 64;
     STANCHK(stan_dmalloc_streamed(ctx, (void **)&K->d_vals32, (size_t)n * 4,
-                                  [&](const void *q, float *ms) {
-                                      return stan_spmv_probe(ctx, K, q, STAN_PREC_MIXED, ms);
+                                  [&](const void *q, float *ms, bool self) {
+                                      return stan_spmv_probe(ctx, K, q, STAN_PREC_MIXED, ms, self);
                                   }));
     hipLaunchKernelGGL(k_to_fp32, dim3(vec_grid(n) * 4), dim3(VEC_T), 0, ctx->stream, K->d_vals,
                        K->d_vals32, n);
@@ -1131,8 +1131,8 @@ int stan_matrix_make_fx48(stan_ctx *ctx, stan_matrix *K) {
     if (K->nslots == 0) return STAN_OK;
     uint32_t *out;
     STANCHK(stan_dmalloc_streamed(ctx, (void **)&out, (size_t)K->nslots * 14 * 64 * 4,
-                                  [&](const void *q, float *ms) {
-                                      return stan_spmv_probe(ctx, K, q, STAN_PREC_FIXED48, ms);
+                                  [&](const void *q, float *ms, bool self) {
+                                      return stan_spmv_probe(ctx, K, q, STAN_PREC_FIXED48, ms, self);
                                   }));
     unsigned long long *d_bad = (unsigned long long *)(ctx->d_status + SS_COUNTER);
     HIPCHK(ctx, hipMemsetAsync(d_bad, 0, 8, ctx->stream));
@@ -1641,7 +1641,11 @@ int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode
 
 // Time of the fp64 SpMV of K streaming its values from `vals` (any contents: only the addresses
 // matter), median of 3 launches after a warm-up.  Used by the allocation-by-trial of placement.hip.
-int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, int32_t precision, float *ms_out) {
+// self_pair: the gather vector and the product are carved out of the FRONT of the candidate block
+// itself instead of the context's vectors -- by construction the same-group (slow) pairing, i.e.
+// the reference the search compares the real pairing with (profiles/r02/placement_cross_self_n148.txt).
+int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, int32_t precision, float *ms_out,
+                    bool self_pair) {
     hipStream_t st_ = ctx->stream;
     *ms_out = 0;
     if (K->nslices <= 0) return STAN_OK;
@@ -1653,6 +1657,10 @@ int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, int32_t pre
     // timed here is the pair the solve will run on
     STANCHK(stan_cg_workspace(ctx, K));
     x = ctx->ws.p; y = ctx->ws.v;
+    if (self_pair) {   // the block holds no values yet (only addresses matter to the timing)
+        x = (double *)const_cast<void *>(vals);
+        y = x + ((ng + 511) & ~(int64_t)511);
+    }
     STANCHK(alloc(ctx, bufs, &partial, (size_t)nblk(K->nslices, 4) + 1));
     STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
     int64_t init[T_NSTAT] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0, 0, 0, 0, 0, 0};

@@ -349,5 +349,6 @@ int stan_group_size(stan_ctx *lead);
 // placement.hip
 int stan_probe_block(stan_ctx *ctx, const void *p, size_t bytes, float *ms_out);
 int stan_dmalloc_streamed(stan_ctx *ctx, void **p, size_t bytes,
-                          const std::function<int(const void *, float *)> &probe);
-int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, int32_t precision, float *ms_out);
+                          const std::function<int(const void *, float *, bool)> &probe);
+int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, int32_t precision, float *ms_out,
+                    bool self_pair = false);

@@ -220,7 +220,10 @@ extern "C" int stan_hip_lab_placement_cross(stan_ctx *ctx, stan_matrix *K, int32
         const int src = pass == 0 ? bf : bs;
         double *res = pass == 0 ? cross_fast : cross_slow;
         for (int t = 0; t < n; t++) {
-            if (t == src || t == 0) { res[t] = -1; continue; }   // block 0 is K's own: keep it intact
+            if (t == 0 && src != 0) { res[t] = -1; continue; }   // block 0 is K's own: keep it intact
+            if (t == 0 && src == 0) { res[t] = -1; continue; }
+            // t == src: the vectors sit inside the very block the values stream from (front of it; the
+            // values there are overwritten, which does not matter for a timing)
             float f = 0;
             STANCHK(stan_spmv_probe_range(ctx, K, (const double *)cand[src], 0, K->nslices, 10, &f, 9, (double *)cand[t]));
             res[t] = f;

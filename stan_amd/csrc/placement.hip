@@ -69,47 +69,50 @@ int stan_probe_block(stan_ctx *ctx, const void *p, size_t bytes, float *ms_out) 
 }
 
 // Allocation by search for a block that will be streamed many times (see the header comment and
-// profiles/r02/PLACEMENT.md).  Round 2 measurements: the time a block streams in is a property of
-// the block for its whole life (round-robin timing of six blocks over 5 s: 0.2 % noise), it is
-// BIMODAL (148^3 fp64: ~1.02 ms or ~1.10-1.12 ms, nothing in between but stragglers), it does not
-// depend on the walk order of the kernel, on the allocation size class or flags, or on translation
-// cost, and which class a fresh hipMalloc lands in comes in runs: on one box the first 40 GB of a
-// process were all slow and everything after that fast, on another all of the first 38 GB.  So
-// four candidates side by side (round 1) often see one class only.  The search therefore goes on,
-// KEEPING the slow candidates allocated so that the allocator cannot hand their memory out again,
-// until a candidate is at least 5 % faster than the slowest one seen (a member of the fast class
-// next to a known slow one), or `tries` candidates have been timed, or the device would be left
-// with less than three block sizes of free memory; the fastest is kept, the rest freed.  A
-// hipMalloc of 6.4 GB takes 0.3 ms and a probe 4 SpMV launches: 16 candidates cost ~80 ms, once
-// per context and size (the pool keeps the winner).
+// profiles/r02/PLACEMENT.md).  Round 2 measurements: what a block streams in is a property of the
+// PAIR (value block, vector blocks) for the life of both: the sweep takes ~4-8 % longer exactly
+// when the two lie in the same group of device memory (groups: runs of tens of GB of consecutive
+// allocations), whichever group that is; it does not depend on the walk order of the kernel, on
+// the allocation size class or flags, on translation cost or on the moment.  So every candidate is
+// timed twice: with the context's vectors (the pairing the solve will run) and with the vectors
+// carved out of the candidate ITSELF (by construction the same-group pairing: the slow reference).
+// A candidate whose real pairing is 3 % faster than its own reference is clear of the vectors'
+// group and is taken at once -- usually the first or second; otherwise it STAYS allocated, so that
+// the allocator has to move on to other memory, and the next one is tried, up to `tries`
+// candidates or a free-memory floor of four block sizes; then the fastest real pairing is kept.
+// A hipMalloc of 6.4 GB takes 0.3 ms and a probe four launches: ~10 ms per candidate at 148^3,
+// once per context and size (the pool keeps the winner).
 int stan_dmalloc_streamed(stan_ctx *ctx, void **p, size_t bytes,
-                          const std::function<int(const void *, float *)> &probe) {
+                          const std::function<int(const void *, float *, bool)> &probe) {
     const int tries = ctx->placement_tries;
-    if (tries <= 1 || bytes < ((size_t)256 << 20)) return stan_dmalloc_bytes(ctx, p, bytes);
+    if (tries <= 1 || bytes < ((size_t)256 << 20) || !probe) return stan_dmalloc_bytes(ctx, p, bytes);
     // a parked block of the right size was chosen by an earlier search: take it
     for (const stan_pool::blk &b : ctx->pool.avail)
         if (b.cap >= bytes && b.cap <= bytes + bytes / 2) return stan_dmalloc_bytes(ctx, p, bytes);
     std::vector<void *> cand;
     std::vector<float> ms;
-    float best = 0, worst = 0;
-    for (int i = 0; i < tries; i++) {
+    float worst = 0;
+    bool clear = false;
+    for (int i = 0; i < tries && !clear; i++) {
         size_t free_b = 0, total_b = 0;
         if (i > 0 && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 4 * bytes)) break;
         void *q = nullptr;
         if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-        float t = 0;
-        const int rc = probe ? probe(q, &t) : stan_probe_block(ctx, q, bytes, &t);
+        float t = 0, t_self = 0;
+        int rc = probe(q, &t, false);
+        if (rc == STAN_OK) rc = probe(q, &t_self, true);
         if (rc) { hipFree(q); for (void *c : cand) hipFree(c); return rc; }
         cand.push_back(q);
         ms.push_back(t);
-        if (i == 0 || t < best) best = t;
-        if (i == 0 || t > worst) worst = t;
-        if (i > 0 && best <= 0.95f * worst) break;   // both classes seen: the best is a fast one
+        if (t_self > worst) worst = t_self;
+        if (t > worst) worst = t;
+        clear = t <= 0.97f * t_self;
     }
     if (cand.empty()) return stan_dmalloc_bytes(ctx, p, bytes);  // reports the allocation failure
-    size_t ibest = 0;
-    for (size_t i = 1; i < cand.size(); i++)
-        if (ms[i] < ms[ibest]) ibest = i;
+    size_t ibest = cand.size() - 1;   // the clear one, if the loop ended on it
+    if (!clear)
+        for (size_t i = 0; i < cand.size(); i++)
+            if (ms[i] < ms[ibest]) ibest = i;
     for (size_t i = 0; i < cand.size(); i++)
         if (i != ibest) hipFree(cand[i]);
     *p = cand[ibest];

@@ -18,7 +18,7 @@ P = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
 ctx._chk(ctx.lib.stan_hip_lab_placement_cross(ctx.h, K.k, C.c_int32(ntries), P(out), P(cf), P(cs), C.byref(bf), C.byref(bs)))
 np.set_printoptions(linewidth=220, precision=4, suppress=True)
 print("class probe (values in block t, vectors from the pool), ms:\n", out)
-print("values in the FASTEST block (%d), x and y inside block t, ms:\n" % bf.value, cf)
+print("values in the FASTEST block (%d), x and y inside block t (t = %d: inside the value block itself), ms:\n" % (bf.value, bf.value), cf)
 print("values in the SLOWEST block (%d), x and y inside block t, ms:\n" % bs.value, cs)
 ok = (cf > 0) & (cs > 0)
 if ok.sum() > 2:
