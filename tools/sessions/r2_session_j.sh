@@ -1,6 +1,6 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r02_r
+OUT=$R/gpurun_out/r02_ab
 mkdir -p $OUT
 cd $R
 timeout 1500 python3 -m pytest tests -m gpu -x -q > $OUT/pytest_all.txt 2>&1
@@ -14,7 +14,7 @@ F=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
 python3 tools/trace_summary.py $F > $OUT/kernel_trace_summary.txt 2>&1
 S=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && cp $S $OUT/kernel_stats.csv
 rm -rf $OUT/trace
-bash tools/pmc_run.sh gpurun_out/r02_r/pmc > $OUT/pmc_summary_stdout.txt 2>&1
+bash tools/pmc_run.sh gpurun_out/r02_ab/pmc > $OUT/pmc_summary_stdout.txt 2>&1
 find $OUT/pmc -name "*.csv" -delete
 python3 bench.py --no-cpu --fixed48 > $OUT/bench_fixed48.json 2> $OUT/bench_fixed48.err
 python3 bench.py --no-cpu --mixed > $OUT/bench_mixed.json 2> $OUT/bench_mixed.err
