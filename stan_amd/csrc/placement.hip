@@ -14,6 +14,7 @@
 // others are freed.  (A plain front-to-back read of the block, k_probe below, tells the bad blocks
 // from the rest but does not rank the rest: tools/placement_probe3.py.)  Off by default (1 try): the search costs `tries` allocations once per context
 // and size -- the block pool keeps the chosen block for the following assemblies.
+#include <cstdlib>
 #include <functional>
 
 #include "internal.h"
@@ -89,36 +90,32 @@ int stan_dmalloc_streamed(stan_ctx *ctx, void **p, size_t bytes,
     // a parked block of the right size was chosen by an earlier search: take it
     for (const stan_pool::blk &b : ctx->pool.avail)
         if (b.cap >= bytes && b.cap <= bytes + bytes / 2) return stan_dmalloc_bytes(ctx, p, bytes);
-    std::vector<void *> cand, spacers;
+    std::vector<void *> cand;
     std::vector<float> ms;
     float worst = 0;
     bool clear = false;
     for (int i = 0; i < tries && !clear; i++) {
         size_t free_b = 0, total_b = 0;
         if (i > 0 && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 4 * bytes)) break;
-        // groups come in runs of up to 150 GB of consecutive allocations (a box needed 24 candidates):
-        // after two failures the search takes longer and longer strides -- a spacer of 1, 2, 4 ...
-        // block sizes is allocated (and kept) in front of the next candidate
-        if (i >= 2) {
-            size_t sp = bytes << (i - 2 < 5 ? i - 2 : 5);
-            while (sp >= bytes && free_b < sp + 5 * bytes) sp >>= 1;
-            void *g = nullptr;
-            if (sp >= bytes && hipMalloc(&g, sp) == hipSuccess) spacers.push_back(g);
-            else (void)hipGetLastError();
-        }
+        // (Groups come in runs of up to 150 GB of consecutive allocations: one box needed 24 candidates.
+        // Longer strides -- spacers of 1, 2, 4 ... block sizes in front of the next candidate -- were
+        // tried and dropped: a hipMalloc / hipFree of 50-200 GB takes seconds on this stack, 24 blocks
+        // of 6.4 GB a quarter of a second.)
         void *q = nullptr;
         if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
         float t = 0, t_self = 0;
         int rc = probe(q, &t, false);
         if (rc == STAN_OK) rc = probe(q, &t_self, true);
-        if (rc) { hipFree(q); for (void *c : cand) hipFree(c); for (void *g : spacers) hipFree(g); return rc; }
+        if (rc) { hipFree(q); for (void *c : cand) hipFree(c); return rc; }
         cand.push_back(q);
         ms.push_back(t);
         if (t_self > worst) worst = t_self;
         if (t > worst) worst = t;
         clear = t <= 0.97f * t_self;
+#ifdef STAN_LAB   // exercise the long-run path on any box: the first N candidates count as not clear
+        if (const char *fm = getenv("STAN_LAB_PLACEMENT_FORCE_MISSES")) clear = clear && i >= atoi(fm);
+#endif
     }
-    for (void *g : spacers) hipFree(g);
     if (cand.empty()) return stan_dmalloc_bytes(ctx, p, bytes);  // reports the allocation failure
     size_t ibest = cand.size() - 1;   // the clear one, if the loop ended on it
     if (!clear)
