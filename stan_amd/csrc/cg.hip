@@ -1691,7 +1691,7 @@ int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, int32_t pre
 // lab: time the fp64 SpMV over the slices [s0, s1) only, streaming the values from `vals`
 // (lab/placement_lab.hip: where inside a block does a slow block lose its time?)
 int stan_spmv_probe_range(stan_ctx *ctx, stan_matrix *K, const double *vals, int32_t s0, int32_t s1,
-                          int reps, float *ms_out, int variant, double *xy_region) {
+                          int reps, float *ms_out, int variant, double *xy_region, double *y_region) {
     hipStream_t st_ = ctx->stream;
     *ms_out = 0;
     if (s1 <= s0) return STAN_OK;
@@ -1701,7 +1701,7 @@ int stan_spmv_probe_range(stan_ctx *ctx, stan_matrix *K, const double *vals, int
     double *x, *y, *partial; int64_t *stt; int32_t *list;
     if (xy_region) {   // lab: gather vector and product live inside a block the caller chose
         x = xy_region;
-        y = xy_region + ((ng + 511) & ~(int64_t)511);
+        y = y_region ? y_region : xy_region + ((ng + 511) & ~(int64_t)511);
     } else {
         STANCHK(alloc(ctx, bufs, &x, (size_t)ng));
         STANCHK(alloc(ctx, bufs, &y, (size_t)ng));

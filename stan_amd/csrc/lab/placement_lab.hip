@@ -11,7 +11,7 @@
 #include "stan_hip_lab.h"
 
 int stan_spmv_probe_range(stan_ctx *ctx, stan_matrix *K, const double *vals, int32_t s0, int32_t s1,
-                          int reps, float *ms_out, int variant, double *xy_region = nullptr);
+                          int reps, float *ms_out, int variant, double *xy_region = nullptr, double *y_region = nullptr);
 
 extern "C" int stan_hip_lab_placement_map(stan_ctx *ctx, stan_matrix *K, int32_t ntries, int32_t nseg,
                                           int32_t keep_fastest, double *ms, uint64_t *addr) {
@@ -239,4 +239,98 @@ extern "C" int stan_hip_lab_incg_penalty(stan_ctx *ctx, stan_matrix *K, int32_t 
     if (!ctx || !K || !out_ms || reps < 1 || K->ctx != ctx) return STAN_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return stan_spmv_incg_lab(ctx, K, reps, out_ms);
+}
+
+// Do other allocators put the VECTORS into another group than hipMalloc puts the values?
+// out [5]: SpMV ms with the values in K's own block and x, y (0) inside that block (the same-group
+// reference), (1) in a fresh hipMalloc block, (2) from hipMallocAsync (stream-ordered pool),
+// (3) in a virtual-memory-API mapping (hipMemCreate / hipMemMap), (4) the context's vectors.
+extern "C" int stan_hip_lab_placement_vecalloc(stan_ctx *ctx, stan_matrix *K, double *out) {
+    if (!ctx || !K || !out || K->ctx != ctx) return STAN_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t vbytes = (size_t)1 << 30;
+    for (int k = 0; k < 5; k++) out[k] = -1;
+    float f = 0;
+    // keep a copy of the front of the values (mode 0 overwrites it)
+    void *save = nullptr;
+    HIPCHK(ctx, hipMalloc(&save, vbytes));
+    HIPCHK(ctx, hipMemcpy(save, K->d_vals, vbytes, hipMemcpyDeviceToDevice));
+    STANCHK(stan_spmv_probe_range(ctx, K, K->d_vals, 0, K->nslices, 10, &f, 9, K->d_vals)); out[0] = f;
+    HIPCHK(ctx, hipMemcpy(K->d_vals, save, vbytes, hipMemcpyDeviceToDevice));
+    hipFree(save);
+    void *a = nullptr;
+    if (hipMalloc(&a, vbytes) == hipSuccess) {
+        STANCHK(stan_spmv_probe_range(ctx, K, K->d_vals, 0, K->nslices, 10, &f, 9, (double *)a)); out[1] = f;
+        hipFree(a);
+    }
+    a = nullptr;
+    if (hipMallocAsync(&a, vbytes, ctx->stream) == hipSuccess) {
+        STANCHK(stan_spmv_probe_range(ctx, K, K->d_vals, 0, K->nslices, 10, &f, 9, (double *)a)); out[2] = f;
+        hipFreeAsync(a, ctx->stream);
+        hipStreamSynchronize(ctx->stream);
+    } else (void)hipGetLastError();
+    {
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = ctx->device;
+        size_t gran = 0;
+        hipMemGenericAllocationHandle_t h;
+        hipDeviceptr_t va = nullptr;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0) {
+            const size_t sz = (vbytes + gran - 1) / gran * gran;
+            if (hipMemCreate(&h, sz, &prop, 0) == hipSuccess) {
+                if (hipMemAddressReserve(&va, sz, 0, nullptr, 0) == hipSuccess) {
+                    hipMemAccessDesc acc = {};
+                    acc.location = prop.location;
+                    acc.flags = hipMemAccessFlagsProtReadWrite;
+                    if (hipMemMap(va, sz, 0, h, 0) == hipSuccess && hipMemSetAccess(va, sz, &acc, 1) == hipSuccess) {
+                        STANCHK(stan_spmv_probe_range(ctx, K, K->d_vals, 0, K->nslices, 10, &f, 9, (double *)va)); out[3] = f;
+                        hipMemUnmap(va, sz);
+                    }
+                    hipMemAddressFree(va, sz);
+                }
+                hipMemRelease(h);
+            }
+        }
+        (void)hipGetLastError();
+    }
+    STANCHK(stan_cg_workspace(ctx, K));
+    {   // the context's own vectors: region = ws.p .. (x) and ws.v (y) are separate blocks; use the probe
+        float t = 0;
+        STANCHK(stan_spmv_probe(ctx, K, K->d_vals, STAN_PREC_FP64, &t, false)); out[4] = t;
+    }
+    return STAN_OK;
+}
+
+// One block or several, big or small, earlier or later?  Values in K's own block (plain allocation);
+// out [8]: x, y in (0) two fresh 79 MB-class blocks (ng doubles each), (1) one fresh block of 2 ng,
+// (2) one fresh 1 GiB block, (3) blocks 3 and 5 of eight fresh ng-sized blocks (what stan_cg_workspace
+// allocates), (4)-(7) the same four again in the opposite order of allocation.
+extern "C" int stan_hip_lab_placement_vecshape(stan_ctx *ctx, stan_matrix *K, double *out) {
+    if (!ctx || !K || !out || K->ctx != ctx) return STAN_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int64_t npad = (int64_t)K->nslices * 64;
+    const size_t ng = (size_t)(3 * ((npad > K->nloc + K->nhalo ? npad : K->nloc + K->nhalo)));
+    const size_t vb = (ng * 8 + 4095) & ~(size_t)4095;
+    for (int k = 0; k < 8; k++) out[k] = -1;
+    float f = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        for (int kk = 0; kk < 4; kk++) {
+            const int kind = pass == 0 ? kk : 3 - kk;
+            std::vector<void *> blk;
+            double *x = nullptr, *y = nullptr;
+            auto get = [&](size_t b) { void *q = nullptr; if (hipMalloc(&q, b) != hipSuccess) { (void)hipGetLastError(); q = nullptr; } if (q) blk.push_back(q); return (double *)q; };
+            if (kind == 0) { x = get(vb); y = get(vb); }
+            if (kind == 1) { x = get(2 * vb); y = x ? x + vb / 8 : nullptr; }
+            if (kind == 2) { x = get((size_t)1 << 30); y = x ? x + vb / 8 : nullptr; }
+            if (kind == 3) { double *q[8]; for (int i = 0; i < 8; i++) q[i] = get(vb); x = q[2]; y = q[4]; }
+            if (x && y) {
+                STANCHK(stan_spmv_probe_range(ctx, K, K->d_vals, 0, K->nslices, 10, &f, 9, x, y));
+                out[pass * 4 + kind] = f;
+            }
+            for (void *q : blk) hipFree(q);
+        }
+    }
+    return STAN_OK;
 }

@@ -42,6 +42,9 @@ int stan_hip_lab_placement_cross(stan_ctx *ctx, stan_matrix *K, int32_t ntries, 
 /* The in-CG penalty of the SpMV, isolated: out_ms [15] = product alone back to back / gather vector
  * rewritten before every product / plus a k_step pass over other vectors / only that pass. */
 int stan_hip_lab_incg_penalty(stan_ctx *ctx, stan_matrix *K, int32_t reps, double *out_ms);
+/* Do other allocators put the vectors into another group?  out [5], see lab/placement_lab.hip. */
+int stan_hip_lab_placement_vecalloc(stan_ctx *ctx, stan_matrix *K, double *out);
+int stan_hip_lab_placement_vecshape(stan_ctx *ctx, stan_matrix *K, double *out);   /* out [8], see lab/placement_lab.hip */
 #ifdef __cplusplus
 }
 #endif
