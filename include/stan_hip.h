@@ -302,6 +302,7 @@ typedef struct stan_profile {
     int32_t placement_candidates;     /* blocks the last allocation-by-search timed (0: none) */
     float placement_ms_best, placement_ms_worst; /* SpMV probe time of the kept / the slowest candidate */
     int64_t col_slots_packed;         /* ELL slots whose columns the last solve read from the packed stream */
+    int32_t placement_moved_vectors;  /* 1: no candidate was clear of the vectors' group and the search re-allocated the CG's vectors instead */
 } stan_profile;
 int stan_hip_set_profiling(stan_ctx *ctx, int32_t enabled);
 int stan_hip_get_profile(stan_ctx *ctx, stan_profile *out);

@@ -161,6 +161,7 @@ int stan_hip_get_profile(stan_ctx *ctx, stan_profile *out) {
     out->placement_candidates = ctx->prof_placement_candidates;
     out->placement_ms_best = ctx->prof_placement_ms_best;
     out->placement_ms_worst = ctx->prof_placement_ms_worst;
+    out->placement_moved_vectors = ctx->prof_placement_moved_vectors;
     return STAN_OK;
 }
 

@@ -1087,6 +1087,49 @@ void stan_cg_workspace_free(stan_ctx *ctx) {
     ws.ng = ws.n3 = 0;
 }
 
+// Last resort of the placement search (placement.hip): no value candidate was clear of the vectors'
+// group, and all of them are still allocated -- so NEW vectors, allocated now, lie beyond them.
+// They are taken straight from the driver (a parked pool block would be the old memory again); the
+// caller probes with them and keeps them (commit) or not.
+int stan_cg_workspace_move(stan_ctx *ctx, const stan_matrix *K, bool commit, stan_cg_ws *saved) {
+    stan_cg_ws &ws = ctx->ws;
+    if (saved && !commit && saved->p == nullptr) {          // step 1: swap fresh vectors in, keep the old ones in *saved
+        if (!ws.p) return STAN_OK;
+        *saved = ws;
+        stan_cg_ws nw;
+        nw.ng = ws.ng; nw.n3 = ws.n3;
+        bool ok = true;
+        double **dst[8] = {&nw.xb[0], &nw.xb[1], &nw.p, &nw.r, &nw.v, &nw.w, &nw.bh, &nw.sv};
+        for (int i = 0; i < 8 && ok; i++)
+            ok = hipMalloc((void **)dst[i], (size_t)(i < 4 ? (nw.ng > 0 ? nw.ng : 1) : nw.n3) * 8) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            for (double **q : dst) if (*q) hipFree(*q);
+            saved->p = nullptr;
+            return STAN_OK;   // no memory for it: keep what we have
+        }
+        ws = nw;
+        (void)K;
+        return STAN_OK;
+    }
+    if (!saved || saved->p == nullptr) return STAN_OK;
+    // step 2: keep the new vectors (release the old ones for real) or go back to the old ones
+    stan_cg_ws &drop = commit ? *saved : ws;
+    stan_cg_ws keep = commit ? ws : *saved;
+    for (double *q : {drop.xb[0], drop.xb[1], drop.p, drop.r, drop.v, drop.w, drop.bh, drop.sv}) {
+        if (!q) continue;
+        ctx->pool.live.erase((void *)q);
+        hipFree(q);
+    }
+    ws = keep;
+    if (commit && ctx->pool.enabled)   // the new blocks are pooled-class blocks from now on
+        for (double *q : {ws.xb[0], ws.xb[1], ws.p, ws.r}) if ((size_t)ws.ng * 8 >= stan_pool::MIN_BYTES) ctx->pool.live[(void *)q] = (size_t)ws.ng * 8;
+    if (commit && ctx->pool.enabled)
+        for (double *q : {ws.v, ws.w, ws.bh, ws.sv}) if ((size_t)ws.n3 * 8 >= stan_pool::MIN_BYTES) ctx->pool.live[(void *)q] = (size_t)ws.n3 * 8;
+    saved->p = nullptr;
+    return STAN_OK;
+}
+
 // Diagonal scaling of the matrix (once per matrix): A^ = S K S.
 static int ensure_scaled(stan_ctx *ctx, stan_matrix *K) {
     if (K->scaled) return STAN_OK;

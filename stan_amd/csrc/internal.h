@@ -143,6 +143,7 @@ struct stan_ctx {
     int placement_tries = 16;  // > 1: allocate the value stream by search (placement.hip); blocks >= 256 MB only
     float prof_placement_ms_best = 0, prof_placement_ms_worst = 0;
     int prof_placement_candidates = 0;
+    int prof_placement_moved_vectors = 0;   // 1: the search ended by re-allocating the CG's vectors
     int prof_colours = 0;
     int spmv_variant = -1; // -1 = auto (launch_spmv picks per value stream); >= 0: A/B lab
     // profiling
@@ -239,6 +240,7 @@ int stan_matrix_make_cols16(stan_ctx *ctx, stan_matrix *K);
 int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K);
 int stan_cg_workspace(stan_ctx *ctx, const stan_matrix *K);  // (re)allocates ctx->ws for K's sizes
 void stan_cg_workspace_free(stan_ctx *ctx);
+int stan_cg_workspace_move(stan_ctx *ctx, const stan_matrix *K, bool commit, stan_cg_ws *saved);
 
 // ---- recovery.hip ---------------------------------------------------------------------------
 int stan_recover_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz, const double *d_disp,

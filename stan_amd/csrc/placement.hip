@@ -121,6 +121,22 @@ int stan_dmalloc_streamed(stan_ctx *ctx, void **p, size_t bytes,
     if (!clear)
         for (size_t i = 0; i < cand.size(); i++)
             if (ms[i] < ms[ibest]) ibest = i;
+    ctx->prof_placement_moved_vectors = 0;
+    if (!clear && cand.size() >= 2) {
+        // Every candidate shares the vectors' group and they are all still allocated: vectors
+        // allocated NOW lie beyond them.  Move the vectors instead of the values, if that pairing
+        // is clear of the chosen candidate's own reference.
+        stan_cg_ws saved;
+        float t_new = 0, t_self = 0;
+        int rc = stan_cg_workspace_move(ctx, nullptr, false, &saved);
+        if (rc == STAN_OK && saved.p) {
+            rc = probe(cand[ibest], &t_new, false);
+            if (rc == STAN_OK) rc = probe(cand[ibest], &t_self, true);
+            const bool better = rc == STAN_OK && t_new <= 0.97f * t_self && t_new < ms[ibest];
+            stan_cg_workspace_move(ctx, nullptr, better, &saved);
+            if (better) { ms[ibest] = t_new; ctx->prof_placement_moved_vectors = 1; }
+        }
+    }
     for (size_t i = 0; i < cand.size(); i++)
         if (i != ibest) hipFree(cand[i]);
     *p = cand[ibest];

@@ -61,7 +61,7 @@ class Profile(C.Structure):
                 ("loop_kernel_launches", C.c_int64), ("loop_collectives", C.c_int64),
                 ("loop_iterations_enqueued", C.c_int64), ("placement_candidates", C.c_int32),
                 ("placement_ms_best", C.c_float), ("placement_ms_worst", C.c_float),
-                ("col_slots_packed", C.c_int64)]
+                ("col_slots_packed", C.c_int64), ("placement_moved_vectors", C.c_int32)]
 
 
 class StanHipError(RuntimeError):
