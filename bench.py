@@ -303,6 +303,9 @@ def main():
                          # counters cannot be read from inside this process: the figure is the
                          # committed PMC pass of the same workload, not a measurement of this run
                          "traffic_source": traffic_source,
+                         # the committed counter traffic moved in this run's launch time (what the memory
+                         # system really did; the fraction above prices algorithmic bytes only)
+                         "traffic_rate_GBs": (traffic / (avg_ms * 1e-3) / 1e9) if traffic and avg_ms > 0 else None,
                          "frac_reduced_system_bytes": frac_reduced,
                          "csr_equivalent_GBs": csr_equiv,
                          # bytes of the format actually streamed (packed columns: 74 B per block, not 76);
