@@ -561,6 +561,76 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
     }
 }
 
+// ---- SpMV for SMALL systems -----------------------------------------------------------------------
+// Below ~130 k block rows the chip is not filled by one wavefront per slice (46 875 DOF: 245 slices
+// on 1024 SIMDs), and a wavefront walking its 27 slots is a chain of dependent memory round trips:
+// k_spmv takes 19 us there, two thirds of an iteration (rocprofv3, tools/small_sizes.py).  Here a
+// slice belongs to a WORKGROUP: its four wavefronts take every fourth slot, the four partial rows are
+// added through LDS in a fixed order (wave 0 + 1 + 2 + 3: deterministic; another order than k_spmv's,
+// so the choice between the two depends on the GLOBAL row count only -- every shard of a sharded
+// matrix and the unsharded matrix use the same kernel and keep producing the same bits).  Plain
+// loads: a matrix of this size stays in the L2s / the memory-side cache from one product to the next.
+template <typename VT, int DOT>
+__global__ void __launch_bounds__(256)
+k_spmv_small(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
+             const int32_t *__restrict__ cols, const VT *__restrict__ vals,
+             const double *__restrict__ x, double *__restrict__ y, double *partial,
+             const int64_t *st, int64_t kiter, const int32_t *__restrict__ slist, int32_t nlist,
+             int32_t poff, fold_args fold, colstream cs) {
+    __shared__ double sh[4];
+    __shared__ int sh_last;
+    __shared__ double acc[3][4][64];
+    if (stopped(st, kiter)) return;
+    constexpr bool NT = false;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int64_t slice = blockIdx.x;
+    if (slist) slice = slice < nlist ? (int64_t)slist[slice] : (int64_t)nslices;
+    double y0 = 0, y1 = 0, y2 = 0;
+    const int64_t row = slice * 64 + lane;
+    if (slice < nslices) {
+        const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
+        const bool packed = cs.packed && cs.ok[slice];
+        const int64_t pp = packed ? (int64_t)cs.pair_ptr[slice] : 0;
+        for (int32_t k = k0 + w; k < k1; k += 4) {
+            int64_t c;
+            if (packed) {
+                const uint32_t wd = cs.packed[(pp + ((k - k0) >> 1)) * 64 + lane];
+                c = (int64_t)cs.base[k] + (int64_t)(((k - k0) & 1) ? (wd >> 16) : (wd & 0xffffu));
+            } else
+                c = cols[(int64_t)k * 64 + lane];
+            const VT *vp = vals + (int64_t)k * vstream<VT>::STRIDE + lane;
+            STAN_SPMV_BLOCK(c, vp)
+        }
+    }
+    acc[0][w][lane] = y0; acc[1][w][lane] = y1; acc[2][w][lane] = y2;
+    __syncthreads();
+    double d = 0, e = 0;
+    if (w == 0) {
+        y0 = ((acc[0][0][lane] + acc[0][1][lane]) + acc[0][2][lane]) + acc[0][3][lane];
+        y1 = ((acc[1][0][lane] + acc[1][1][lane]) + acc[1][2][lane]) + acc[1][3][lane];
+        y2 = ((acc[2][0][lane] + acc[2][1][lane]) + acc[2][2][lane]) + acc[2][3][lane];
+        if (slice < nslices && row < nloc) {
+            y[3 * row] = y0; y[3 * row + 1] = y1; y[3 * row + 2] = y2;
+            if (DOT) {
+                const double x0 = x[3 * row], x1 = x[3 * row + 1], x2 = x[3 * row + 2];
+                d = y0 * x0 + y1 * x1 + y2 * x2;
+                if (DOT == 2) e = x0 * x0 + x1 * x1 + x2 * x2;
+            }
+        }
+    }
+    if (DOT) {
+        const double t = block_sum(d, sh);
+        if (DOT == 2) {
+            const double u = block_sum(e, sh);
+            if (threadIdx.x == 0) {
+                st_agent(partial + 2 * (int64_t)(blockIdx.x + poff), u);
+                st_agent(partial + 2 * (int64_t)(blockIdx.x + poff) + 1, t);
+            }
+        } else if (threadIdx.x == 0) st_agent(partial + blockIdx.x + poff, t);
+        if (fold.counter && fold_arrive(fold, &sh_last)) fold_finish<(DOT == 2 ? 2 : 1)>(fold, partial, sh);
+    }
+}
+
 // Two right-hand sides in ONE pass over the matrix: y = A x and y2 = A x2 (+ the x.y partial).
 // Used on the residual-refresh iterations: r = b - A(x + a p) = b - (A x + a A p), so the
 // refresh needs A x next to the A p every iteration needs -- one matrix stream instead of two.
@@ -988,6 +1058,12 @@ int alloc(stan_ctx *ctx, dev_bufs &b, T **p, size_t n) {
     return rc;
 }
 
+// k_spmv_small instead of k_spmv: decided by the GLOBAL number of block rows, so that a shard and the
+// whole matrix sum their rows in the same order
+inline bool stan_small_system(const stan_ctx *ctx, const stan_matrix *K) {
+    return ctx->spmv_small && ctx->spmv_variant < 0 && K->nb_glob <= 131072;
+}
+
 // which: 0 = all slices, 1 = interior list, 2 = boundary list (partials offset by the
 // interior launch's block count).  Returns the number of partial slots this launch writes.
 // `fold`: counter/out of the folded reduction (counter == nullptr: partials only); nblocks and np
@@ -1000,13 +1076,23 @@ unsigned launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double
     if (!stream) stream = ctx->stream;
     const int32_t *slist = which == 1 ? K->d_sl_int : which == 2 ? K->d_sl_bnd : nullptr;
     const int32_t nlist = which == 1 ? K->n_sl_int : which == 2 ? K->n_sl_bnd : K->nslices;
+    const colstream cs = ctx->cols16 && K->d_cols16 ? colstream{K->d_cols16, K->d_colbase, K->d_pair_ptr, K->d_slice_packed}
+                                                    : colstream{nullptr, nullptr, nullptr, nullptr};
+    if (stan_small_system(ctx, K)) {   // one workgroup per slice (k_spmv_small); partials per slice
+        const int32_t poff_s = which == 2 ? K->n_sl_int : 0;
+        const unsigned grid_s = (unsigned)nlist;
+        if (grid_s == 0) return 0;
+        fold.nblocks = grid_s;
+        fold.np = (int)grid_s + poff_s;
+        hipLaunchKernelGGL((k_spmv_small<VT, DOT>), dim3(grid_s), dim3(256), 0, stream, K->nslices, K->nloc,
+                           K->d_slot_ptr, K->d_cols, vals, x, y, partial, st, k, slist, nlist, poff_s, fold, cs);
+        return grid_s;
+    }
     const int32_t poff = which == 2 ? (int32_t)nblk(K->n_sl_int, 4) : 0;
     const unsigned grid = nblk(nlist, 4);
     if (grid == 0) return 0;
     fold.nblocks = grid;
     fold.np = (int)grid + poff;
-    const colstream cs = ctx->cols16 && K->d_cols16 ? colstream{K->d_cols16, K->d_colbase, K->d_pair_ptr, K->d_slice_packed}
-                                                    : colstream{nullptr, nullptr, nullptr, nullptr};
 #define SPMV_CASE(V)                                                                          \
     case V:                                                                                   \
         hipLaunchKernelGGL((k_spmv<VT, DOT, V>), dim3(grid), dim3(256), 0, stream, K->nslices, \
@@ -1278,7 +1364,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     xb[0] = ctx->ws.xb[0]; xb[1] = ctx->ws.xb[1]; p = ctx->ws.p; r = ctx->ws.r;
     v = ctx->ws.v; w = ctx->ws.w; bh = ctx->ws.bh;
     if (sr) sv = ctx->ws.sv;
-    const unsigned spmv_blocks = nblk(K->nslices, 4);
+    const unsigned spmv_blocks = stan_small_system(ctx, K) ? (unsigned)K->nslices : nblk(K->nslices, 4);
     const size_t npart = 2 * (size_t)(spmv_blocks > VEC_BLOCKS ? spmv_blocks : VEC_BLOCKS) + 16;
     STANCHK(alloc(ctx, bufs, &partial, npart));
     STANCHK(alloc(ctx, bufs, &sc, (size_t)S_NSCAL));
@@ -1658,7 +1744,7 @@ int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode
     // timed here is the pair the solve will run on
     STANCHK(stan_cg_workspace(ctx, K));
     x = ctx->ws.p; y = ctx->ws.v;
-    STANCHK(alloc(ctx, bufs, &partial, (size_t)nblk(K->nslices, 4) + 1));
+    STANCHK(alloc(ctx, bufs, &partial, 2 * (size_t)K->nslices + 2));   // k_spmv_small leaves one partial per slice
     STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
     int64_t init[T_NSTAT] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0, 0, 0, 0, 0, 0};
     HIPCHK(ctx, hipMemcpyAsync(stt, init, sizeof(init), hipMemcpyHostToDevice, st_));
@@ -1704,7 +1790,7 @@ int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, int32_t pre
         x = (double *)const_cast<void *>(vals);
         y = x + ((ng + 511) & ~(int64_t)511);
     }
-    STANCHK(alloc(ctx, bufs, &partial, (size_t)nblk(K->nslices, 4) + 1));
+    STANCHK(alloc(ctx, bufs, &partial, 2 * (size_t)K->nslices + 2));   // k_spmv_small leaves one partial per slice
     STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
     int64_t init[T_NSTAT] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0, 0, 0, 0, 0, 0};
     HIPCHK(ctx, hipMemcpyAsync(stt, init, sizeof(init), hipMemcpyHostToDevice, st_));
@@ -1749,7 +1835,7 @@ int stan_spmv_probe_range(stan_ctx *ctx, stan_matrix *K, const double *vals, int
         STANCHK(alloc(ctx, bufs, &x, (size_t)ng));
         STANCHK(alloc(ctx, bufs, &y, (size_t)ng));
     }
-    STANCHK(alloc(ctx, bufs, &partial, (size_t)nblk(K->nslices, 4) + 1));
+    STANCHK(alloc(ctx, bufs, &partial, 2 * (size_t)K->nslices + 2));   // k_spmv_small leaves one partial per slice
     STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
     STANCHK(alloc(ctx, bufs, &list, (size_t)(s1 - s0)));
     std::vector<int32_t> h((size_t)(s1 - s0));

@@ -27,6 +27,7 @@ OPT_CG_FOLD_REDUCE = 11
 OPT_VEC_STORE_NT = 12
 OPT_PACKED_COLUMNS = 13
 OPT_CG_DEFER_X = 14
+OPT_SPMV_SMALL = 15
 E_HIP, E_ARG, E_ALLOC, E_DETJ, E_DOF_LAYOUT, E_VALENCE, E_COMM, E_UNSUPPORTED = (
     -1, -2, -3, -4, -5, -6, -7, -8)
 

@@ -90,7 +90,7 @@ def test_console_driver_on_two_ranks(built_libs, oracle, tmp_path):
     out1 = subprocess.run([exe, path], capture_output=True, text=True, timeout=600)
     assert out1.returncode == 0, out1.stdout + out1.stderr
     disp1 = host.Db.read_stdb(path).results(1)[0]
-    assert np.abs(disp1 - disp).max() <= 1e-8 * np.abs(disp).max()   # two eps = 1e-12 solves, kappa ~ 8e2
+    assert np.abs(disp1 - disp).max() <= 1e-7 * np.abs(disp).max()   # two solves that end on the type-7 rounding floor (eps = 1e-12 is below it)
 
 
 def test_init_multi_fails_loudly_on_a_missing_device(built_libs):

@@ -44,8 +44,10 @@ def test_spmv_variant_option_only_takes_kernels_that_compute_the_product(gpu_ctx
             assert ei.value.code == hip.E_ARG
     finally:
         gpu_ctx.set_option(hip.OPT_SPMV_VARIANT, -1)
-    for y in ys[1:]:
+    for y in ys[1:3]:
         assert np.array_equal(y, ys[0])     # same arithmetic in the same order
+    # auto on a system this small is the workgroup-per-slice kernel: the same products, summed in another order
+    assert np.abs(ys[3] - ys[0]).max() <= 1e-13 * np.abs(ys[0]).max()
     K.free()
 
 
@@ -348,4 +350,45 @@ def test_deferred_x_update_gives_the_same_bits(gpu_ctx, oracle, fused_refresh):
         gpu_ctx.set_option(hip.OPT_CG_DEFER_X, 1)
         gpu_ctx.set_option(hip.OPT_CG_FUSED_REFRESH, 1)
         gpu_ctx.set_option(hip.OPT_CG_MERIT_STOP, 1)
+    K.free()
+
+
+@pytest.mark.parametrize("n,prec", [(6, "fp64"), (14, "fp64"), (14, "fixed48"), (12, "mixed")])
+def test_small_system_spmv_kernel(gpu_ctx, oracle, n, prec):
+    """STAN_OPT_SPMV_SMALL: up to 131 072 block rows one WORKGROUP owns a slice (four wavefronts take
+    every fourth slot, partial rows added in a fixed order).  Same products as the one-wavefront kernel
+    to rounding (<= 1e-14 of the row scale), the oracle's answer, bit-reproducible, and the same bits
+    with the packed and the int32 column stream."""
+    from stan_amd import hip
+    pm = {"fp64": hip.PREC_FP64, "fixed48": hip.PREC_FIXED48, "mixed": hip.PREC_MIXED}[prec]
+    job = problem.cube_job(n, jitter=0.1)
+    K, A = _assemble_both(gpu_ctx, oracle, job)
+    x = np.random.default_rng(5).standard_normal(job.n_red)
+    out = {}
+    try:
+        for small in (1, 0):
+            gpu_ctx.set_option(hip.OPT_SPMV_SMALL, small)
+            Ka = gpu_ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+            y = Ka.spmv(x)
+            Ua, ra = Ka.cg_solve(job.F, 1e-10, precision_mode=pm)
+            Ub, rb = Ka.cg_solve(job.F, 1e-10, precision_mode=pm)
+            assert ra == rb and np.array_equal(Ua, Ub)                       # bit-reproducible
+            gpu_ctx.set_option(hip.OPT_PACKED_COLUMNS, 0)
+            Uc, rc_ = Ka.cg_solve(job.F, 1e-10, precision_mode=pm)
+            gpu_ctx.set_option(hip.OPT_PACKED_COLUMNS, 1)
+            assert ra == rc_ and np.array_equal(Ua, Uc)                      # same bits with int32 columns
+            out[small] = (y, Ua, ra)
+            Ka.free()
+    finally:
+        gpu_ctx.set_option(hip.OPT_SPMV_SMALL, 1)
+        gpu_ctx.set_option(hip.OPT_PACKED_COLUMNS, 1)
+    yo = oracle.smv_upper(A, x)
+    assert np.abs(out[1][0] - yo).max() <= 1e-12 * np.abs(yo).max()
+    assert np.abs(out[1][0] - out[0][0]).max() <= 1e-13 * np.abs(yo).max()
+    Uo, repo = oracle.cg(A, job.F, 1e-10)
+    tol = {"fp64": 1e-6, "fixed48": 1e-6, "mixed": 1e-3}[prec]
+    for small in (1, 0):
+        assert out[small][2]["terminationtype"] == repo["terminationtype"] or prec == "mixed"
+        assert np.abs(out[small][1] - Uo).max() <= tol * np.abs(Uo).max()
+    assert abs(out[1][2]["iterations"] - out[0][2]["iterations"]) <= max(3, out[0][2]["iterations"] // 20)
     K.free()
