@@ -122,12 +122,13 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
                            p' = r + beta p, so p is read once per iteration for both; same operands, same
                            bits.  With the merit-function stop on (the library default) x' is formed earlier, as
                            alglib does, whatever this option says. */
-#define STAN_OPT_SPMV_SMALL 15 /* 1 (default): systems of up to 131 072 block rows (393 k DOF) -- too few slices to fill
+#define STAN_OPT_SPMV_SMALL 15 /* 1 (default): systems of up to 150 000 block rows (450 k DOF) -- too few slices to fill
                            the chip with one wavefront each -- multiply with one WORKGROUP per slice: four
                            wavefronts take every fourth slot, partial rows added through LDS in a fixed order.
                            Chosen by the global row count (shards agree with the whole matrix); same products,
                            another summation order than the large-system kernel.  0: always the large-system
-                           kernel.  An explicit STAN_OPT_SPMV_VARIANT also selects the large-system kernel. */
+                           kernel; a value > 1: that many block rows as the limit.  An explicit
+                           STAN_OPT_SPMV_VARIANT also selects the large-system kernel. */
 #define STAN_OPT_PLACEMENT_TRIES 8 /* 16 (default; bench.py: 32).  1: plain allocation.  n = 2..64: the value array of K is
                            allocated by search (placement.hip) -- the SpMV is ~8 % slower, for the life of the
                            blocks, when the matrix stream and the CG's vectors (allocated first, owned by the

@@ -108,7 +108,7 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
     else if (option == STAN_OPT_VEC_STORE_NT && value >= 0 && value <= 3) ctx->vec_store_nt = (int)value;
     else if (option == STAN_OPT_PACKED_COLUMNS) ctx->cols16 = value != 0;
     else if (option == STAN_OPT_CG_DEFER_X) ctx->cg_defer_x = value != 0;
-    else if (option == STAN_OPT_SPMV_SMALL) ctx->spmv_small = value != 0;
+    else if (option == STAN_OPT_SPMV_SMALL && value >= 0) ctx->spmv_small_rows = value == 1 ? 150000 : value;
     else if (option == STAN_OPT_POOL) {
         ctx->pool.enabled = value != 0;
         if (!ctx->pool.enabled) {

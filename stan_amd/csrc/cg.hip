@@ -562,7 +562,7 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
 }
 
 // ---- SpMV for SMALL systems -----------------------------------------------------------------------
-// Below ~130 k block rows the chip is not filled by one wavefront per slice (46 875 DOF: 245 slices
+// Below ~150 k block rows the chip is not filled by one wavefront per slice (46 875 DOF: 245 slices
 // on 1024 SIMDs), and a wavefront walking its 27 slots is a chain of dependent memory round trips:
 // k_spmv takes 19 us there, two thirds of an iteration (rocprofv3, tools/small_sizes.py).  Here a
 // slice belongs to a WORKGROUP: its four wavefronts take every fourth slot, the four partial rows are
@@ -1061,7 +1061,7 @@ int alloc(stan_ctx *ctx, dev_bufs &b, T **p, size_t n) {
 // k_spmv_small instead of k_spmv: decided by the GLOBAL number of block rows, so that a shard and the
 // whole matrix sum their rows in the same order
 inline bool stan_small_system(const stan_ctx *ctx, const stan_matrix *K) {
-    return ctx->spmv_small && ctx->spmv_variant < 0 && K->nb_glob <= 131072;
+    return ctx->spmv_variant < 0 && K->nb_glob <= ctx->spmv_small_rows;
 }
 
 // which: 0 = all slices, 1 = interior list, 2 = boundary list (partials offset by the

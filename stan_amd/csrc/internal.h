@@ -132,7 +132,7 @@ struct stan_ctx {
     int cg_rupdate = 10;
     bool cg_fused_refresh = true;  // A x and A p of a refresh iteration in one matrix pass
     bool cg_single_reduce = false; // Chronopoulos-Gear loop: one reduction point per iteration
-    bool spmv_small = true;        // systems of <= 131072 block rows: one workgroup per slice (k_spmv_small)
+    int64_t spmv_small_rows = 150000;   // systems of at most this many block rows: one workgroup per slice (k_spmv_small); 0 = never
     bool cg_defer_x = true;        // merit stop off: x' = x + a p is formed by k_update (one read of p)
     bool cols16 = true;            // SpMV reads the packed column stream where a slice allows it
     int vec_store_nt = 3;          // bit 0: p (k_update), bit 1: r (k_step) leave through non-temporal stores

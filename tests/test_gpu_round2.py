@@ -355,7 +355,7 @@ def test_deferred_x_update_gives_the_same_bits(gpu_ctx, oracle, fused_refresh):
 
 @pytest.mark.parametrize("n,prec", [(6, "fp64"), (14, "fp64"), (14, "fixed48"), (12, "mixed")])
 def test_small_system_spmv_kernel(gpu_ctx, oracle, n, prec):
-    """STAN_OPT_SPMV_SMALL: up to 131 072 block rows one WORKGROUP owns a slice (four wavefronts take
+    """STAN_OPT_SPMV_SMALL: up to 150 000 block rows one WORKGROUP owns a slice (four wavefronts take
     every fourth slot, partial rows added in a fixed order).  Same products as the one-wavefront kernel
     to rounding (<= 1e-14 of the row scale), the oracle's answer, bit-reproducible, and the same bits
     with the packed and the int32 column stream."""

@@ -18,7 +18,7 @@ for n in sizes:
     K = ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
     d_F = torch.from_numpy(job.F).cuda(); d_U = torch.zeros_like(d_F)
     line = "n %3d  %8d DOF:" % (n, job.n_dof)
-    for tag, g in (("workgroup per slice", 1), ("wavefront per slice", 0)):
+    for tag, g in (("workgroup per slice", 1 << 40), ("wavefront per slice", 0)):
         ctx.set_option(hip.OPT_SPMV_SMALL, g)
         best = 1e9
         for rep_ in range(5):
