@@ -133,13 +133,28 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
                            allocated by search (placement.hip) -- the SpMV is ~8 % slower, for the life of the
                            blocks, when the matrix stream and the CG's vectors (allocated first, owned by the
                            context) lie in the same group of device memory, and fresh allocations fall into one
-                           group in runs of tens of GB.  Candidates are allocated one after the other and the
-                           SpMV is timed on each with those vectors; the slow ones stay allocated while the search goes on,
-                           until one is 5 % faster than the slowest seen, n candidates have been timed, or
-                           free device memory falls under 4 block sizes; the fastest is kept.  Only blocks of
-                           256 MB and more are searched for; costs ~5 ms per candidate once per context and size;
-                           the block pool keeps the winner; the results do not depend on it.  Destroying a
-                           context detaches its matrices: they may be freed afterwards. */
+                           group in runs of tens of GB.  Candidates are allocated one after the other; each is
+                           timed twice with the SpMV itself: with the context's vectors (the pairing the solve
+                           will run) and with vectors carved out of the candidate (by construction the slow,
+                           same-group pairing).  The first candidate whose real pairing is 3 % faster than its
+                           own reference is kept; one that is not stays allocated while the search goes on (so
+                           that the allocator moves on), until n candidates have been timed, the byte budget
+                           STAN_OPT_PLACEMENT_MAX_BYTES is reached or free device memory falls under 4 block
+                           sizes; then the fastest real pairing is kept -- after one more attempt: the CG's
+                           vectors are re-allocated beyond the held candidates and kept if that pairing is
+                           clear.  Only blocks of 256 MB and more are searched for; ~10 ms per candidate once
+                           per context and size; the block pool keeps the winner; the results do not depend on
+                           it.  Destroying a context detaches its matrices: they may be freed afterwards. */
+#define STAN_OPT_PLACEMENT_MAX_BYTES 16 /* byte budget of the candidates the placement search holds at the same time
+                           (default 0 = a quarter of the device memory that is free when the search starts; the
+                           first candidate -- the allocation itself -- is always allowed). */
+#define STAN_OPT_SELL_SIGMA 17 /* 32 (default): SELL-C-sigma -- inside windows of this many 64-row slices the block rows
+                           are sorted by length before they are cut into slices (a slice is as wide as its longest row;
+                           padded slots are streamed like real ones).  Reference-order slices of a regular cube carry
+                           1-2 % padding, of a box with 15 % / 40 % of its elements missing 8 % / 26 %; windows of 32
+                           slices: <= 1.5 %.  The permutation is internal: vectors, CRS export, halo plan and the row
+                           partition keep the reference (AssignDOF) order, every row sum keeps its bits (the order of
+                           the dot-product partial sums changes with it).  1 = off; 1..32; applies to the next assembly. */
 #define STAN_OPT_POOL 7 /* 1 (default): device blocks >= 8 MB freed by the library stay with the
                            context and are reused by its next allocations (a hipMalloc of tens of GB
                            costs 0.4-1.8 s here); 0: release them now, plain hipMalloc/hipFree from then on */
@@ -247,6 +262,9 @@ typedef struct stan_matrix_info {
     int64_t n_elements_on_device; /* elements this rank uploaded and scanned: all of them on a single
                                      rank; on a rank of a sharded run (host-pointer entry) only those
                                      that touch its rows; summed over the devices of a group handle */
+    int32_t sell_sigma;   /* sorting window (slices) the matrix was built with (STAN_OPT_SELL_SIGMA); the padding
+                             of the layout is n_slots*64/n_blocks - 1 */
+    int32_t reserved0;
 } stan_matrix_info;
 int stan_hip_matrix_info(stan_matrix *K, stan_matrix_info *out);
 

@@ -128,7 +128,9 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
         }
     }
     else if (option == STAN_OPT_OVERLAP_HALO) ctx->overlap_halo = value != 0;
+    else if (option == STAN_OPT_SELL_SIGMA && value >= 1 && value <= 32) ctx->sell_sigma = (int)value;
     else if (option == STAN_OPT_PLACEMENT_TRIES && value >= 1 && value <= 64) ctx->placement_tries = (int)value;
+    else if (option == STAN_OPT_PLACEMENT_MAX_BYTES && value >= 0) ctx->placement_max_bytes = value;
 #ifdef STAN_LAB
     else if (option == STAN_OPT_SPMV_VARIANT && value >= -1 && value <= 18) ctx->spmv_variant = (int)value;
 #else   // the product library carries the three variants that give right answers (cg.hip)
@@ -267,7 +269,7 @@ void stan_hip_matrix_free(stan_matrix *K) {
     }
     // the solves that used these buffers have been synchronised by their own calls; the blocks go
     // back to the context's pool (stan_pool) or to the driver
-    for (void *q : {(void *)K->d_slot_ptr, (void *)K->d_rowlen, (void *)K->d_cols, (void *)K->d_vals,
+    for (void *q : {(void *)K->d_slot_ptr, (void *)K->d_rowlen, (void *)K->d_rowof, (void *)K->d_posof, (void *)K->d_cols, (void *)K->d_vals,
                     (void *)K->d_vals32, (void *)K->d_vals48, (void *)K->d_cols16, (void *)K->d_colbase,
                     (void *)K->d_pair_ptr, (void *)K->d_slice_packed, (void *)K->d_red, (void *)K->d_fixmask,
                     (void *)K->d_scale, (void *)K->d_send_rows, (void *)K->d_halo_glob, (void *)K->d_sendbuf,
@@ -400,6 +402,8 @@ int stan_hip_matrix_info(stan_matrix *K, stan_matrix_info *o) {
     o->scaled = (K->parts.empty() ? K->scaled : K->parts[0]->scaled) ? 1 : 0;
     o->max_row_blocks = K->max_row_blocks;
     o->n_elements_on_device = K->n_elem_scanned;
+    o->sell_sigma = K->parts.empty() ? K->sigma : K->parts[0]->sigma;
+    o->reserved0 = 0;
     return STAN_OK;
 }
 
@@ -442,11 +446,12 @@ int stan_hip_matrix_to_csr(stan_ctx *ctx, stan_matrix *K, int32_t upper_only, in
     STANCHK(stan_matrix_unscale(ctx, K));  // export K itself, not S K S
     const int64_t nloc = K->nloc;
     std::vector<int32_t> slot_ptr((size_t)K->nslices + 1), rowlen((size_t)K->nslices * 64),
-        cols((size_t)K->nslots * 64), red((size_t)K->n_dof);
+        posof((size_t)K->nslices * 64), cols((size_t)K->nslots * 64), red((size_t)K->n_dof);
     std::vector<double> vals((size_t)K->nslots * 9 * 64);
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemcpyAsync(slot_ptr.data(), K->d_slot_ptr, slot_ptr.size() * 4, hipMemcpyDeviceToHost, st));
     if (!rowlen.empty()) HIPCHK(ctx, hipMemcpyAsync(rowlen.data(), K->d_rowlen, rowlen.size() * 4, hipMemcpyDeviceToHost, st));
+    if (!posof.empty()) HIPCHK(ctx, hipMemcpyAsync(posof.data(), K->d_posof, posof.size() * 4, hipMemcpyDeviceToHost, st));
     if (!cols.empty()) HIPCHK(ctx, hipMemcpyAsync(cols.data(), K->d_cols, cols.size() * 4, hipMemcpyDeviceToHost, st));
     if (!vals.empty()) HIPCHK(ctx, hipMemcpyAsync(vals.data(), K->d_vals, vals.size() * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(red.data(), K->d_red, red.size() * 4, hipMemcpyDeviceToHost, st));
@@ -456,8 +461,8 @@ int stan_hip_matrix_to_csr(stan_ctx *ctx, stan_matrix *K, int32_t upper_only, in
         if (pass == 1 && (!rowptr || !col || !val)) break;
         int64_t q = 0;
         for (int64_t row = 0; row < nloc; row++) {
-            const int64_t sl = row >> 6;
-            const int lane = (int)(row & 63);
+            const int64_t sl = posof[(size_t)row] >> 6;   // SELL-C-sigma: where the row sits in the sliced layout
+            const int lane = (int)(posof[(size_t)row] & 63);
             for (int m = 0; m < 3; m++) {
                 const int64_t d = 3 * row + m;
                 if (red[d] == -1) continue;

@@ -119,28 +119,22 @@ __device__ inline int32_t wave_bitonic_sort(int32_t v) {
     return v;
 }
 
-// ---- step 2: symbolic.  One 64-lane workgroup per owned block row. --------------------------
-// FILL=false: sort the row's incidence list in place, count distinct neighbour block rows,
-//             flag referenced non-owned block rows (halo discovery).
-// FILL=true : write the sorted distinct columns (local numbering) into the ELL slots.
-template <bool FILL>
+// ---- step 2: symbolic.  One 64-lane workgroup per owned block row, ONE sort per row ---------
+// Sorts the row's incidence list in place (ascending element index, then local node: the numeric
+// phase accumulates in that order), sorts the candidate neighbour block rows, and leaves the
+// distinct ones -- ascending GLOBAL index -- in ucols[8 * ptr[row] ...] for k_fill_cols; counts
+// them (rowlen) and flags referenced non-owned block rows (halo discovery).  (Rounds 1-2 ran this
+// kernel twice, count and fill, and sorted every row both times.)
 __global__ void __launch_bounds__(64)
 k_symbolic(int64_t nloc, int64_t r0, int64_t r1, const int64_t *ptr, int32_t *list,
            const int32_t *conn, const int32_t *perm, int32_t *rowlen, int32_t *refflag,
-           const int64_t *halo_rank, const int32_t *slot_ptr, int32_t *cols, int64_t *status) {
+           int32_t *ucols, int64_t *status) {
     __shared__ int32_t ent[64];
     __shared__ int32_t cand[8 * STAN_MAX_INCIDENT];
     const int lane = threadIdx.x;
     const int64_t row = blockIdx.x;  // local row; rows >= nloc are slice padding
-    const int slice_lane = (int)(row & 63);
-    const int64_t slice = row >> 6;
     if (row >= nloc) {
-        if (FILL) {
-            // padding row of the last slice: every slot points at local column 0 with zero values
-            const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
-            for (int k = k0 + lane; k < k1; k += 64) cols[(int64_t)k * 64 + slice_lane] = 0;
-        } else if (lane == 0)
-            rowlen[row] = 0;
+        if (lane == 0) rowlen[row] = 0;
         return;
     }
     const int64_t p0 = ptr[row];
@@ -152,10 +146,8 @@ k_symbolic(int64_t nloc, int64_t r0, int64_t r1, const int64_t *ptr, int32_t *li
     // incidence entries ascending (= ascending element index, then local node)
     {
         int32_t en = lane < deg ? list[p0 + lane] : 0x7fffffff;
-        if (!FILL) {
-            en = wave_bitonic_sort(en);
-            if (lane < deg) list[p0 + lane] = en;
-        }
+        en = wave_bitonic_sort(en);
+        if (lane < deg) list[p0 + lane] = en;
         ent[lane] = en;
     }
     __syncthreads();
@@ -177,6 +169,7 @@ k_symbolic(int64_t nloc, int64_t r0, int64_t r1, const int64_t *ptr, int32_t *li
     } else
         lds_bitonic_sort(cand, P);
     // distinct values, in ascending (global) order
+    int32_t *uc = ucols + 8 * p0;   // capacity 8 * deg >= number of distinct candidates
     int32_t base = 0;
     for (int i0 = 0; i0 < P; i0 += 64) {
         const int i = i0 + lane;
@@ -185,37 +178,79 @@ k_symbolic(int64_t nloc, int64_t r0, int64_t r1, const int64_t *ptr, int32_t *li
         const unsigned long long m = __ballot(isnew);
         const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
         if (isnew) {
-            if (FILL) {
-                const int64_t g = c;
-                const int32_t lc = (g >= r0 && g < r1) ? (int32_t)(g - r0)
-                                                       : (int32_t)(nloc + halo_rank[g]);
-                cols[((int64_t)slot_ptr[slice] + pos) * 64 + slice_lane] = lc;
-            } else if (c < r0 || c >= r1)
-                refflag[c] = 1;
+            uc[pos] = c;
+            if (refflag && (c < r0 || c >= r1)) refflag[c] = 1;
         }
         base += __popcll(m);
     }
-    if (FILL) {
-        // pad the row up to the slice width with its own (diagonal) column and zero values
-        const int32_t k1 = slot_ptr[slice + 1] - slot_ptr[slice];
-        for (int k = base + lane; k < k1; k += 64)
-            cols[((int64_t)slot_ptr[slice] + k) * 64 + slice_lane] = (int32_t)row;
-    } else if (lane == 0) {
+    if (lane == 0) {
         rowlen[row] = base;
         if (base > STAN_MAX_ROW_BLOCKS)
             atomicOr((unsigned long long *)&status[SS_ERRBITS], (unsigned long long)ERR_ROWLEN);
     }
 }
 
+// ---- step 2b: SELL-C-sigma.  Rows sorted by length (descending, stable) inside windows of sigma
+// slices: a slice is as wide as its longest row, so 64 rows of similar length waste no slots.
+// On the regular cube a slice of reference-order rows is 1-2 % padding; on a box with 15 % / 40 %
+// of its elements knocked out 8.3 % / 25.7 % (tools/sellcs_padding.py), every padded slot being
+// streamed by the SpMV like a real one; sorted in windows of 32 slices: 0.9 % / 1.4 %.
+// The permutation stays INSIDE the matrix: rowof[position] = local block row, posof = inverse;
+// vectors, halo plan, CRS export and the row partition keep the reference (AssignDOF) order, and
+// a row's blocks keep their ascending column order, so every row sum keeps its bits.
+// One workgroup per window; rank = #{longer rows} + #{equally long rows in front}.
+__global__ void __launch_bounds__(256)
+k_window_sort(int64_t npad, int sigma, const int32_t *rowlen, int32_t *rowof, int32_t *posof) {
+    __shared__ int32_t len[64 * 32];
+    const int64_t base = (int64_t)blockIdx.x * sigma * 64;
+    const int W = (int)((npad - base) < (int64_t)sigma * 64 ? (npad - base) : (int64_t)sigma * 64);
+    for (int i = threadIdx.x; i < W; i += 256) len[i] = rowlen[base + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < W; i += 256) {
+        const int32_t li = len[i];
+        int rank = 0;
+        for (int j = 0; j < W; j++) {
+            const int32_t lj = len[j];
+            rank += (lj > li || (lj == li && j < i)) ? 1 : 0;
+        }
+        rowof[base + rank] = (int32_t)(base + i);
+        posof[base + i] = (int32_t)(base + rank);
+    }
+}
+
+// ---- step 2c: columns into the ELL slots.  One wavefront per slice, lane = position: every store
+// is a full 256-B line; a lane walks the contiguous distinct-column run k_symbolic left for its row.
+__global__ void __launch_bounds__(256)
+k_fill_cols(int32_t nslices, int64_t nloc, int64_t r0, int64_t r1, const int32_t *slot_ptr,
+            const int32_t *rowof, const int32_t *rowlen, const int64_t *ptr, const int32_t *ucols,
+            const int64_t *halo_rank, int32_t *cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t slice = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slice >= nslices) return;
+    const int64_t row = rowof[slice * 64 + lane];
+    const bool live = row < nloc;   // rows >= nloc: padding of the last slice (zero values, column 0)
+    const int rl = live ? rowlen[row] : 0;
+    const int32_t *uc = ucols + (live ? 8 * ptr[row] : 0);
+    const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
+    for (int32_t k = k0; k < k1; k++) {
+        int32_t lc = live ? (int32_t)row : 0;   // a row shorter than its slice is padded with its own column
+        if (k - k0 < rl) {
+            const int64_t g = uc[k - k0];
+            lc = (g >= r0 && g < r1) ? (int32_t)(g - r0) : (int32_t)(nloc + halo_rank[g]);
+        }
+        cols[(int64_t)k * 64 + lane] = lc;
+    }
+}
+
 // slice width = longest row of the slice; also accumulates block count and max width
 // (4 slices per workgroup, one atomic pair per workgroup: 51 k same-address atomics were 1.2 ms)
 __global__ void __launch_bounds__(256)
-k_slice_width(int32_t nslices, const int32_t *rowlen, int32_t *width, unsigned long long *nblocks,
-              int32_t *maxw) {
+k_slice_width(int32_t nslices, const int32_t *rowlen, const int32_t *rowof, int32_t *width,
+              unsigned long long *nblocks, int32_t *maxw) {
     __shared__ int sh_s[4], sh_m[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t slice = (int64_t)blockIdx.x * 4 + w;
-    int v = slice < nslices ? rowlen[slice * 64 + lane] : 0;
+    int v = slice < nslices ? rowlen[rowof[slice * 64 + lane]] : 0;
     int s = v;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
@@ -255,7 +290,8 @@ __global__ void k_compact_flags(const int32_t *flag, const int64_t *rank, int32_
     if (i < n && flag[i]) out[rank[i]] = (int32_t)i;
 }
 
-// ---- step 3: numeric.  256 threads = 4 wavefronts assemble 16 consecutive block rows --------
+// ---- step 3: numeric.  256 threads = 4 wavefronts assemble the block rows of 16 consecutive --
+// positions of a slice (position -> row through rowof: SELL-C-sigma) ---------------------------
 struct numeric_args {
     int64_t nloc, r0, r1, nhalo;
     const int64_t *ptr;
@@ -270,6 +306,7 @@ struct numeric_args {
     const int32_t *halo_glob;
     const int64_t *halo_rank;
     const int32_t *rowlen;
+    const int32_t *rowof;  // [nslices*64] position in the sliced layout -> local block row (k_window_sort)
     const int32_t *slot_ptr;
     const int32_t *cols;
     double *vals;
@@ -301,7 +338,7 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t slice = blockIdx.x >> 2;
     const int q = blockIdx.x & 3;
-    const int64_t row_base = slice * 64 + q * 16;
+    const int64_t row_base = slice * 64 + q * 16;   // first POSITION of this workgroup
     const int32_t k0 = A.slot_ptr[slice];
     const int sw = A.slot_ptr[slice + 1] - k0;  // this slice's width (<= wmax)
 
@@ -326,9 +363,10 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
     int DEG[4], RL[4];
     int32_t EN[4], NB[4], COLG[4], TY[4], MI[4];
     double X0[4], X1[4], X2[4];
+    int64_t ROW[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int64_t row = row_base + w * 4 + i;
+        const int64_t row = ROW[i] = A.rowof[row_base + w * 4 + i];
         P0[i] = 0; DEG[i] = 0; RL[i] = 0;
         if (row < A.nloc) {
             P0[i] = A.ptr[row];
@@ -362,7 +400,7 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int r16 = w * 4 + i;
-        const int64_t row = row_base + r16;
+        const int64_t row = ROW[i];
         if (row >= A.nloc) continue;  // wave-uniform
         const int64_t p0 = P0[i];
         const int deg = DEG[i];
@@ -516,7 +554,7 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
     // a thread keeps its row (t & 15 is loop-invariant) and walks (k, comp) by 16 per step
     {
         const int r16 = tid & 15;
-        const int64_t row = row_base + r16;
+        const int64_t row = A.rowof[row_base + r16];
         const bool live = row < A.nloc;
         const int rfix = live ? A.fixmask[A.r0 + row] : 0;
         const int rlen = live ? A.rowlen[row] : 0;
@@ -545,11 +583,11 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
 
 // slice class: 1 if any row of the slice references a halo column (local index >= nloc)
 __global__ void __launch_bounds__(64)
-k_slice_class(int64_t nloc, const int32_t *rowlen, const int32_t *slot_ptr, const int32_t *cols,
-              int32_t *is_bnd, int32_t *is_int) {
+k_slice_class(int64_t nloc, const int32_t *rowlen, const int32_t *rowof, const int32_t *slot_ptr,
+              const int32_t *cols, int32_t *is_bnd, int32_t *is_int) {
     const int lane = threadIdx.x;
     const int64_t slice = blockIdx.x;
-    const int64_t row = slice * 64 + lane;
+    const int64_t row = rowof[slice * 64 + lane];
     const int32_t k0 = slot_ptr[slice];
     bool f = false;
     if (row < nloc)
@@ -559,13 +597,14 @@ k_slice_class(int64_t nloc, const int32_t *rowlen, const int32_t *slot_ptr, cons
 }
 
 // ---- per-row rank mask (which ranks need this owned row's x) --------------------------------
-__global__ void k_row_rankflag(int64_t nloc, const int32_t *rowlen, const int32_t *slot_ptr,
-                               const int32_t *cols, const int32_t *halo_glob, int64_t q0,
-                               int64_t q1, int32_t *flag) {
+__global__ void k_row_rankflag(int64_t nloc, const int32_t *rowlen, const int32_t *posof,
+                               const int32_t *slot_ptr, const int32_t *cols, const int32_t *halo_glob,
+                               int64_t q0, int64_t q1, int32_t *flag) {
     int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= nloc) return;
-    const int64_t slice = row >> 6;
-    const int lane = (int)(row & 63);
+    const int64_t pos = posof[row];
+    const int64_t slice = pos >> 6;
+    const int lane = (int)(pos & 63);
     const int32_t k0 = slot_ptr[slice];
     int f = 0;
     for (int k = 0; k < rowlen[row]; k++) {
@@ -742,11 +781,18 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         STANCHK(stan_dmalloc(ctx, &d_halo_rank, (size_t)nb + 1)); tmp.own(d_halo_rank);
         HIPCHK(ctx, hipMemsetAsync(d_refflag, 0, (size_t)nb * 4, st));
     }
+    // distinct columns of row i land in d_ucols[8 * d_ptr[i] ...] (8 candidates per incidence)
+    int32_t *d_ucols; STANCHK(stan_dmalloc(ctx, &d_ucols, (size_t)(n_inc > 0 ? 8 * n_inc : 1))); tmp.own(d_ucols);
     if (nrows_pad > 0)
-        hipLaunchKernelGGL(k_symbolic<false>, dim3((unsigned)nrows_pad), dim3(64), 0, st, nloc, r0,
-                           r1, d_ptr, d_list, d_conn, d_perm, K->d_rowlen, d_refflag,
-                           (const int64_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr,
-                           d_status);
+        hipLaunchKernelGGL(k_symbolic, dim3((unsigned)nrows_pad), dim3(64), 0, st, nloc, r0, r1, d_ptr,
+                           d_list, d_conn, d_perm, K->d_rowlen, d_refflag, d_ucols, d_status);
+    // SELL-C-sigma: positions of the rows inside the sliced layout
+    K->sigma = ctx->sell_sigma < 1 ? 1 : ctx->sell_sigma > 32 ? 32 : ctx->sell_sigma;
+    STANCHK(stan_dmalloc(ctx, &K->d_rowof, (size_t)(nrows_pad > 0 ? nrows_pad : 1)));
+    STANCHK(stan_dmalloc(ctx, &K->d_posof, (size_t)(nrows_pad > 0 ? nrows_pad : 1)));
+    if (nrows_pad > 0)
+        hipLaunchKernelGGL(k_window_sort, dim3(nblk(K->nslices, K->sigma)), dim3(256), 0, st, nrows_pad, K->sigma,
+                           K->d_rowlen, K->d_rowof, K->d_posof);
     // halo numbering
     K->nhalo = 0;
     if (ctx->nranks > 1) {
@@ -764,7 +810,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     HIPCHK(ctx, hipMemsetAsync(d_status + SS_WIDTH_SUM, 0, 16, st));
     if (K->nslices > 0)
         hipLaunchKernelGGL(k_slice_width, dim3(nblk(K->nslices, 4)), dim3(256), 0, st, K->nslices, K->d_rowlen,
-                           d_width, (unsigned long long *)(d_status + SS_WIDTH_SUM), (int32_t *)(d_status + SS_WIDTH_MAX));
+                           K->d_rowof, d_width, (unsigned long long *)(d_status + SS_WIDTH_SUM), (int32_t *)(d_status + SS_WIDTH_MAX));
     STANCHK(stan_scan_exclusive(ctx, d_width, d_sp64, K->nslices));
     STANCHK(stan_dmalloc(ctx, &K->d_slot_ptr, (size_t)K->nslices + 1));
     hipLaunchKernelGGL(k_i64_to_i32, dim3(nblk(K->nslices + 1, 256)), dim3(256), 0, st, d_sp64,
@@ -787,15 +833,14 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         return STAN_E_ARG;
     }
     STANCHK(stan_dmalloc(ctx, &K->d_cols, (size_t)K->nslots * 64));
-    if (nrows_pad > 0)
-        hipLaunchKernelGGL(k_symbolic<true>, dim3((unsigned)nrows_pad), dim3(64), 0, st, nloc, r0, r1,
-                           d_ptr, d_list, d_conn, d_perm, K->d_rowlen, (int32_t *)nullptr,
-                           (const int64_t *)d_halo_rank, (const int32_t *)K->d_slot_ptr, K->d_cols,
-                           d_status);
-    // (after the FILL pass: an allocation by trial times the SpMV itself, which needs the columns)
+    if (K->nslices > 0)
+        hipLaunchKernelGGL(k_fill_cols, dim3(nblk(K->nslices, 4)), dim3(256), 0, st, K->nslices, nloc, r0, r1,
+                           K->d_slot_ptr, K->d_rowof, K->d_rowlen, d_ptr, d_ucols, (const int64_t *)d_halo_rank,
+                           K->d_cols);
+    // (after the columns are in place: an allocation by trial times the SpMV itself, which needs the columns)
     STANCHK(stan_dmalloc_streamed(ctx, (void **)&K->d_vals, (size_t)K->nslots * 9 * 64 * 8,
                                   [&](const void *q, float *ms, bool self) {
-                                      return stan_spmv_probe(ctx, K, q, STAN_PREC_FP64, ms, self);
+                                      return stan_spmv_probe(ctx, K, q, (size_t)K->nslots * 9 * 64 * 8, STAN_PREC_FP64, ms, self);
                                   }));
     if (ctx->profiling) hipEventRecord(ev1, st);
 
@@ -811,7 +856,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         A.ptr = d_ptr; A.list = d_list; A.conn = d_conn; A.perm = d_perm; A.xyz = d_xyz;
         A.elem_mat = d_elem_mat; A.elem_type = d_elem_type; A.mat_lamG = d_lamG;
         A.fixmask = K->d_fixmask; A.halo_glob = K->d_halo_glob; A.halo_rank = d_halo_rank;
-        A.rowlen = K->d_rowlen; A.slot_ptr = K->d_slot_ptr; A.cols = K->d_cols; A.vals = K->d_vals;
+        A.rowlen = K->d_rowlen; A.rowof = K->d_rowof; A.slot_ptr = K->d_slot_ptr; A.cols = K->d_cols; A.vals = K->d_vals;
         A.bad_elem = (long long *)(d_status + SS_BAD_ELEM);
         A.wmax = K->max_row_blocks > 0 ? K->max_row_blocks : 1;
         const size_t lds = (size_t)16 * A.wmax * 9 * 8 + (size_t)4 * 8 * 8 * 3 * 8 +
@@ -837,7 +882,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         STANCHK(stan_dmalloc(ctx, &d_sb, (size_t)K->nslices + 2)); tmp.own(d_sb);
         STANCHK(stan_dmalloc(ctx, &d_si, (size_t)K->nslices + 2)); tmp.own(d_si);
         hipLaunchKernelGGL(k_slice_class, dim3((unsigned)K->nslices), dim3(64), 0, st, nloc,
-                           K->d_rowlen, K->d_slot_ptr, K->d_cols, d_fb, d_fi);
+                           K->d_rowlen, K->d_rowof, K->d_slot_ptr, K->d_cols, d_fb, d_fi);
         STANCHK(stan_scan_exclusive(ctx, d_fb, d_sb, K->nslices));
         STANCHK(stan_scan_exclusive(ctx, d_fi, d_si, K->nslices));
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_H_COUNT_A, d_sb + K->nslices, 8, hipMemcpyDeviceToHost, st));
@@ -872,7 +917,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
             if (q1 > 0x7fffffff) hi = (int64_t)hg.size();
             if (hi == lo) continue;  // structural symmetry: no recv <=> no send
             hipLaunchKernelGGL(k_row_rankflag, dim3(nblk(nloc, 256)), dim3(256), 0, st, nloc,
-                               K->d_rowlen, K->d_slot_ptr, K->d_cols, K->d_halo_glob, q0, q1, d_flag);
+                               K->d_rowlen, K->d_posof, K->d_slot_ptr, K->d_cols, K->d_halo_glob, q0, q1, d_flag);
             STANCHK(stan_scan_exclusive(ctx, d_flag, d_rk, nloc));
             HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_H_COUNT_A, d_rk + nloc, 8, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));

@@ -76,7 +76,7 @@ __global__ void k_col_fill(int64_t n_elem, const int32_t *colour, const int32_t 
 __global__ void __launch_bounds__(256)
 k_scatter(int32_t count, const int32_t *order, const int32_t *conn, const int32_t *perm,
           const double *xyz, const int32_t *elem_mat, const uint8_t *elem_type, const double *mat_lamG,
-          const int32_t *rowlen, const int32_t *slot_ptr, const int32_t *cols, double *vals,
+          const int32_t *rowlen, const int32_t *posof, const int32_t *slot_ptr, const int32_t *cols, double *vals,
           long long *bad_elem) {
     __shared__ double xs[4][24];
     __shared__ double gp[4][80];
@@ -118,8 +118,8 @@ k_scatter(int32_t count, const int32_t *order, const int32_t *conn, const int32_
     // scatter block (a, b): row = DOF block of node a, column = DOF block of node b
     const int64_t row = perm[na];
     const int32_t col = perm[nb];
-    const int64_t slice = row >> 6;
-    const int rl = (int)(row & 63);
+    const int64_t slice = posof[row] >> 6;   // SELL-C-sigma: where the row sits in the sliced layout
+    const int rl = (int)(posof[row] & 63);
     const int32_t k0 = slot_ptr[slice];
     int lo = 0, hi = rowlen[row] - 1, pos = -1;
     while (lo <= hi) {  // columns ascend (single rank: local == global)
@@ -153,12 +153,12 @@ k_scatter(int32_t count, const int32_t *order, const int32_t *conn, const int32_
 
 // essential BCs on the assembled values: fixed rows/columns zero, fixed diagonal one
 __global__ void __launch_bounds__(256)
-k_apply_bc(int32_t nslices, int64_t nloc, const int32_t *slot_ptr, const int32_t *rowlen,
+k_apply_bc(int32_t nslices, int64_t nloc, const int32_t *slot_ptr, const int32_t *rowof, const int32_t *rowlen,
            const int32_t *cols, double *vals, const uint8_t *fixmask) {
     const int lane = threadIdx.x & 63;
     const int64_t slice = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slice >= nslices) return;
-    const int64_t row = slice * 64 + lane;
+    const int64_t row = rowof[slice * 64 + lane];
     if (row >= nloc) return;
     const int rf = fixmask[row];
     const int32_t k0 = slot_ptr[slice];
@@ -229,13 +229,13 @@ int stan_assemble_colour_scatter(stan_ctx *ctx, stan_matrix *K, int64_t n_elem, 
             if (cnt[c] > 0)
                 hipLaunchKernelGGL(k_scatter, dim3(nblk(cnt[c], 4)), dim3(256), 0, st, cnt[c], d_order + off[c],
                                    d_conn, d_perm, d_xyz, d_elem_mat, d_elem_type, d_lamG, K->d_rowlen,
-                                   K->d_slot_ptr, K->d_cols, K->d_vals, d_bad);
+                                   K->d_posof, K->d_slot_ptr, K->d_cols, K->d_vals, d_bad);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(st));  // temporaries are freed on return
     }
     if (K->nslices > 0)
         hipLaunchKernelGGL(k_apply_bc, dim3(nblk(K->nslices, 4)), dim3(256), 0, st, K->nslices, K->nloc,
-                           K->d_slot_ptr, K->d_rowlen, K->d_cols, K->d_vals, K->d_fixmask);
+                           K->d_slot_ptr, K->d_rowof, K->d_rowlen, K->d_cols, K->d_vals, K->d_fixmask);
     HIPCHK(ctx, hipGetLastError());
     return STAN_OK;
 }

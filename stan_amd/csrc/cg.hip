@@ -21,6 +21,7 @@
 #include <cmath>
 
 #include "internal.h"
+#include "p2p_device.h"
 
 // lab switches (tools/lib_lab.sh): non-temporal policy of the vector traffic
 #ifndef STAN_VEC_NT
@@ -135,7 +136,19 @@ struct fold_args {
     unsigned nblocks;             // tickets this launch hands out (its grid size)
     int np;                       // partials to add (>= nblocks: earlier launches may have left some)
     double *out;                  // [NV] results
+    p2p_out po;                   // sharded, peer to peer: the sums go to every rank's mailbox instead (p2p_device.h)
 };
+constexpr p2p_out NO_P2P = {nullptr, 0, 0, 0};
+constexpr fold_args NO_FOLD = {nullptr, 0, 0, nullptr, NO_P2P};
+// the finished sums r[0..NV) (valid in thread 0) to where the consumer will look for them
+template <int NV>
+__device__ __forceinline__ void publish_sums(double *out, const p2p_out &po, const double r[NV], double *sh) {
+    if (po.pp) { p2p_publish<NV>(po, r, sh); return; }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < NV; j++) out[j] = r[j];  // read by the NEXT kernel: a plain store will do
+    }
+}
 // Thread 0 of every block calls this after storing its partials with st_agent(); true (in every
 // thread) for the block that arrived last.  `sh_last` is one int of LDS.
 __device__ __forceinline__ bool fold_arrive(const fold_args &f, int *sh_last) {
@@ -160,10 +173,7 @@ template <int NV>
 __device__ __forceinline__ void fold_finish(const fold_args &f, const double *partial, double *sh) {
     double r[NV];
     sum_partials<NV>(partial, f.np, sh, r);
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int j = 0; j < NV; j++) f.out[j] = r[j];  // read by the NEXT kernel: a plain store will do
-    }
+    publish_sums<NV>(f.out, f.po, r, sh);
     // every ticket of this launch has been drawn: clear the set for the next one
     if (threadIdx.x <= FOLD_SUB)
         __hip_atomic_store(f.counter + threadIdx.x * FOLD_LINE, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -175,12 +185,13 @@ __device__ __forceinline__ bool stopped(const int64_t *st, int64_t k) {
 
 // ---- setup kernels ---------------------------------------------------------------------------
 // s_i = 1/sqrt(K_ii) if K_ii > 0 else 1 (lincgsolvesparse); one lane per block row
-__global__ void k_diag_scale(int64_t nloc, const int32_t *rowlen, const int32_t *slot_ptr,
+__global__ void k_diag_scale(int64_t nloc, const int32_t *rowlen, const int32_t *posof, const int32_t *slot_ptr,
                              const int32_t *cols, const double *vals, double *s) {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= nloc) return;
-    const int64_t slice = row >> 6;
-    const int lane = (int)(row & 63);
+    const int64_t pos = posof[row];   // SELL-C-sigma: where the row sits in the sliced layout
+    const int64_t slice = pos >> 6;
+    const int lane = (int)(pos & 63);
     const int32_t k0 = slot_ptr[slice];
     double d0 = 0, d1 = 0, d2 = 0;
     for (int k = 0; k < rowlen[row]; k++)
@@ -196,12 +207,12 @@ __global__ void k_diag_scale(int64_t nloc, const int32_t *rowlen, const int32_t 
 
 // vals[slot][3m+n][lane] *= s[3 row + m] * s[3 col + n]   (inverse=1: divide)
 __global__ void __launch_bounds__(256)
-k_scale_matrix(int32_t nslices, const int32_t *slot_ptr, const int32_t *cols, double *vals,
+k_scale_matrix(int32_t nslices, const int32_t *slot_ptr, const int32_t *rowof, const int32_t *cols, double *vals,
                const double *s, int inverse) {
     const int lane = threadIdx.x & 63;
     const int64_t slice = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slice >= nslices) return;
-    const int64_t row = slice * 64 + lane;
+    const int64_t row = rowof[slice * 64 + lane];
     double sr[3] = {s[3 * row], s[3 * row + 1], s[3 * row + 2]};  // s is padded to slices
     if (inverse) { sr[0] = 1.0 / sr[0]; sr[1] = 1.0 / sr[1]; sr[2] = 1.0 / sr[2]; }
     for (int32_t k = slot_ptr[slice]; k < slot_ptr[slice + 1]; k++) {
@@ -319,18 +330,20 @@ k_init(int64_t n3, int64_t dof0, const int32_t *red, const double *F, const doub
 // same summation order as fold_finish: both paths give the same bits)
 template <int NV>
 __global__ void __launch_bounds__(256)
-k_reduce(const double *partial, int np, double *out) {
+k_reduce(const double *partial, int np, double *out, p2p_out po) {
     __shared__ double sh[4];
     double r[NV];
-    sum_partials<NV>(partial, np, sh, r);
-    if (threadIdx.x == 0)
-#pragma unroll
-        for (int j = 0; j < NV; j++) out[j] = r[j];
+    sum_partials<NV>(partial, np, sh, r);   // np == 0 (a rank that owns no rows): zeros
+    publish_sums<NV>(out, po, r, sh);
 }
 
 // after the b^.b^ reduction: bnorm, first residual test, rho, prevmf
-__global__ void k_init_scalars(double *sc, int64_t *st, double epsf) {
-    const double r2 = sc[S_VMV];  // k_reduce wrote b^.b^ here
+__global__ void __launch_bounds__(64) k_init_scalars(double *sc, int64_t *st, double epsf, red_src rs) {
+    __shared__ double sh[4];
+    double t[1];
+    red_get<1>(sc + S_VMV, rs, t, sh);   // b^.b^ (all ranks' partials when sharded peer to peer)
+    if (threadIdx.x != 0) return;
+    const double r2 = t[0];
     sc[S_BNORM] = sqrt(r2);
     sc[S_RHO0] = r2; sc[S_RHO1] = r2;  // iteration 1 reads slot 1
     sc[S_PMF0] = 0.0; sc[S_PMF1] = 0.0;
@@ -426,7 +439,7 @@ template <typename VT, int DOT, int VAR>
 // lab 17 / 18: capped at 68 / 62 VGPRs for 7 / 8 waves per SIMD instead of 78 / 6: in-CG SpMV 1.071 /
 // 1.072 ms against 1.032 ms (profiles/r02/fold_ab_incg_n148_box9_register_caps.txt): more waves do not help
 __global__ void __launch_bounds__(256, (VAR == 17 ? 7 : VAR == 18 ? 8 : 1))
-k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
+k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, const int32_t *__restrict__ rowof,
        const int32_t *__restrict__ cols, const VT *__restrict__ vals,
        const double *__restrict__ x, double *__restrict__ y, double *partial,
        const int64_t *st, int64_t kiter, const int32_t *__restrict__ slist, int32_t nlist,
@@ -457,52 +470,13 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
     int64_t slice = bid * 4 + (threadIdx.x >> 6);
     if (slist) slice = slice < nlist ? (int64_t)slist[slice] : (int64_t)nslices;  // interior / boundary list
     double y0 = 0, y1 = 0, y2 = 0;
-    const int64_t row = slice * 64 + lane;
+    const int64_t row = slice < nslices ? (int64_t)rowof[slice * 64 + lane] : nloc;   // SELL-C-sigma: position -> block row
     if (slice < nslices) {
         const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
         const int32_t *cp = cols + (int64_t)k0 * 64 + lane;
         const VT *vp = vals + (int64_t)k0 * vstream<VT>::STRIDE + lane;
 #ifdef STAN_LAB
-        if (VAR == 8 && !vstream<VT>::FX) {  // timing only: 16-B accesses, results are wrong
-            typedef VT v2 __attribute__((ext_vector_type(2)));
-            const v2 *vq = (const v2 *)(vals + (int64_t)k0 * 9 * 64) + lane;
-            for (int32_t k = k0; k + 1 < k1; k += 2) {
-                const int64_t c = __builtin_nontemporal_load(cp), c2 = __builtin_nontemporal_load(cp + 64);
-                double a[9], b[9];
-#pragma unroll
-                for (int j = 0; j < 9; j++) { const v2 t = __builtin_nontemporal_load(vq + j * 64); a[j] = (double)t.x; b[j] = (double)t.y; }
-                const double x0 = x[3 * c], x1 = x[3 * c + 1], x2 = x[3 * c + 2];
-                const double z0 = x[3 * c2], z1 = x[3 * c2 + 1], z2 = x[3 * c2 + 2];
-                y0 += a[0] * x0 + a[1] * x1 + a[2] * x2 + b[0] * z0 + b[1] * z1 + b[2] * z2;
-                y1 += a[3] * x0 + a[4] * x1 + a[5] * x2 + b[3] * z0 + b[4] * z1 + b[5] * z2;
-                y2 += a[6] * x0 + a[7] * x1 + a[8] * x2 + b[6] * z0 + b[7] * z1 + b[8] * z2;
-                cp += 128;
-                vq += 9 * 64;
-            }
-        } else if (VAR == 14 || VAR == 15 || VAR == 16) {
-            // lab: break the lockstep of neighbouring streams (tools/placement_map.py).  14: odd slices
-            // walk their slots back to front; 15: every slice starts at slot (slice % width) and wraps;
-            // 16: like 15 with a hashed start.  Same products, other summation order per row.
-            const int32_t n = k1 - k0;
-            const int32_t rot = VAR == 14 ? 0 : VAR == 15 ? (int32_t)(slice % (n > 0 ? n : 1))
-                                                          : (int32_t)(((uint32_t)slice * 2654435761u >> 16) % (uint32_t)(n > 0 ? n : 1));
-            const bool rev = VAR == 14 && (slice & 1);
-#pragma unroll 2
-            for (int32_t i = 0; i < n; i++) {
-                int32_t kk = rev ? n - 1 - i : i + rot;
-                if (kk >= n) kk -= n;
-                const int32_t *cq = cp + (int64_t)kk * 64;
-                const VT *vq = vp + (int64_t)kk * vstream<VT>::STRIDE;
-                const int64_t c = ld_stream<true>(cq);
-                double a[9];
-                load9<true, VT>(vq, a);
-                double x0 = x[3 * c], x1 = x[3 * c + 1], x2 = x[3 * c + 2];
-                if (vstream<VT>::FX) { x0 *= FX48_INV; x1 *= FX48_INV; x2 *= FX48_INV; }
-                y0 += a[0] * x0 + a[1] * x1 + a[2] * x2;
-                y1 += a[3] * x0 + a[4] * x1 + a[5] * x2;
-                y2 += a[6] * x0 + a[7] * x1 + a[8] * x2;
-            }
-        } else
+#include "lab/spmv_variants_lab.inc"   // lab-only kernel variants (VAR 8, 14-16)
 #endif
         if (cs.packed && cs.ok[slice]) {   // wave-uniform: a slice is packed or not
             const uint32_t *cq = cs.packed + (int64_t)cs.pair_ptr[slice] * 64 + lane;
@@ -572,7 +546,7 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
 // loads: a matrix of this size stays in the L2s / the memory-side cache from one product to the next.
 template <typename VT, int DOT>
 __global__ void __launch_bounds__(256)
-k_spmv_small(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
+k_spmv_small(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, const int32_t *__restrict__ rowof,
              const int32_t *__restrict__ cols, const VT *__restrict__ vals,
              const double *__restrict__ x, double *__restrict__ y, double *partial,
              const int64_t *st, int64_t kiter, const int32_t *__restrict__ slist, int32_t nlist,
@@ -586,7 +560,7 @@ k_spmv_small(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr
     int64_t slice = blockIdx.x;
     if (slist) slice = slice < nlist ? (int64_t)slist[slice] : (int64_t)nslices;
     double y0 = 0, y1 = 0, y2 = 0;
-    const int64_t row = slice * 64 + lane;
+    const int64_t row = slice < nslices ? (int64_t)rowof[slice * 64 + lane] : nloc;   // SELL-C-sigma: position -> block row
     if (slice < nslices) {
         const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
         const bool packed = cs.packed && cs.ok[slice];
@@ -636,7 +610,7 @@ k_spmv_small(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr
 // refresh needs A x next to the A p every iteration needs -- one matrix stream instead of two.
 template <typename VT>
 __global__ void __launch_bounds__(256)
-k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
+k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, const int32_t *__restrict__ rowof,
         const int32_t *__restrict__ cols, const VT *__restrict__ vals,
         const double *__restrict__ x, const double *__restrict__ x2, double *__restrict__ y,
         double *__restrict__ y2, double *partial, const int64_t *st, int64_t kiter,
@@ -654,7 +628,7 @@ k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr,
     int64_t slice = bid * 4 + (threadIdx.x >> 6);
     if (slist) slice = slice < nlist ? (int64_t)slist[slice] : (int64_t)nslices;
     double y0 = 0, y1 = 0, yy2 = 0, z0 = 0, z1 = 0, z2 = 0;
-    const int64_t row = slice * 64 + lane;
+    const int64_t row = slice < nslices ? (int64_t)rowof[slice * 64 + lane] : nloc;   // SELL-C-sigma: position -> block row
     if (slice < nslices) {
         const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
         const int32_t *cp = cols + (int64_t)k0 * 64 + lane;
@@ -744,6 +718,7 @@ struct step_args {
     int defer_x;          // 1: x' = x + a p is formed by k_update (one read of p for both updates); only
                           //    when the merit sum is off and the iteration needs no x' before k_update
     fold_args fold;       // r.r and the merit sum are added up by the last block (-> sc[S_R2NEW..])
+    red_src rs_vmv;       // where p.Ap is found (p2p_device.h)
 };
 
 template <bool RNT>
@@ -751,7 +726,9 @@ __global__ void __launch_bounds__(VEC_T) k_step(step_args a) {
     __shared__ double sh[4];
     __shared__ int sh_last;
     if (stopped(a.st, a.k)) return;
-    const double vmv = a.sc[S_VMV];
+    double vmv_[1];
+    red_get<1>(a.sc + S_VMV, a.rs_vmv, vmv_, sh);
+    const double vmv = vmv_[0];
     const double rho = a.sc[S_RHO0 + (a.k & 1)];
     int bad = 0;
     if (!isfinite(vmv) || vmv <= 0) bad = isfinite(vmv) ? -5 : -4;
@@ -846,9 +823,13 @@ template <bool PNT>
 __global__ void __launch_bounds__(VEC_T)
 k_update(int64_t n3, int64_t k, double *sc, int64_t *st, double epsf, int64_t maxits,
          int64_t its_before_restart, int merit_stop, const double *r, double *p,
-         const double *xcur, double *xnext /* non-null: the deferred x' = x + a p of this iteration */) {
+         const double *xcur, double *xnext /* non-null: the deferred x' = x + a p of this iteration */,
+         red_src rs_r2, red_src rs_vmv) {
+    __shared__ double sh[4];
     if (st[T_ITER_A] < k || st[T_ITER_B] <= k) return;
-    const double r2 = sc[S_R2NEW], merit = sc[S_MERIT];
+    double t2[2];
+    red_get<2>(sc + S_R2NEW, rs_r2, t2, sh);   // r.r, merit sum
+    const double r2 = t2[0], merit = t2[1];
     const double rho = sc[S_RHO0 + (k & 1)], prevmf = sc[S_PMF0 + (k & 1)];
     const double bnorm = sc[S_BNORM];
     int type = 0;
@@ -876,7 +857,12 @@ k_update(int64_t n3, int64_t k, double *sc, int64_t *st, double epsf, int64_t ma
     }
     const int64_t stride = (int64_t)gridDim.x * VEC_T;
     // alpha of this iteration, as k_step formed it (same operands, same bits)
-    const double alpha = xnext ? rho / sc[S_VMV] : 0.0;
+    double alpha = 0.0;
+    if (xnext) {   // block-uniform
+        double v1[1];
+        red_get<1>(sc + S_VMV, rs_vmv, v1, sh);
+        alpha = rho / v1[0];
+    }
     if (type) {
         // the iteration that stops (types 1, 5, -4 select x' = buffer k & 1) still owes its x'
         if (xnext && xsel == (k & 1))
@@ -923,6 +909,7 @@ struct sr_args {
     const double *w, *bh;
     double *partial;      // [blocks] merit partials
     fold_args fold;       // -> sc[S_SR_MERIT]
+    red_src rs;           // where gamma, delta, merit of the last reduction are found
 };
 
 __global__ void __launch_bounds__(VEC_T) k_vec_sr(sr_args a) {
@@ -930,7 +917,9 @@ __global__ void __launch_bounds__(VEC_T) k_vec_sr(sr_args a) {
     __shared__ int sh_last;
     const int64_t k = a.k;
     if (a.st[T_ITER_A] < k) return;   // stopped by an earlier iteration's decisions
-    const double gamma = a.sc[S_SR_GAMMA], delta = a.sc[S_SR_DELTA], merit = a.sc[S_SR_MERIT];
+    double t3[3];
+    red_get<3>(a.sc + S_SR_GAMMA, a.rs, t3, sh);
+    const double gamma = t3[0], delta = t3[1], merit = t3[2];
     const double bnorm = a.sc[S_BNORM];
     int type = 0;
     int64_t its = k - 1, xsel = (k - 1) & 1;
@@ -1072,7 +1061,7 @@ inline bool stan_small_system(const stan_ctx *ctx, const stan_matrix *K) {
 template <typename VT, int DOT>
 unsigned launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double *x, double *y,
                      double *partial, const int64_t *st, int64_t k, int which = 0,
-                     hipStream_t stream = nullptr, fold_args fold = fold_args{nullptr, 0, 0, nullptr}) {
+                     hipStream_t stream = nullptr, fold_args fold = NO_FOLD) {
     if (!stream) stream = ctx->stream;
     const int32_t *slist = which == 1 ? K->d_sl_int : which == 2 ? K->d_sl_bnd : nullptr;
     const int32_t nlist = which == 1 ? K->n_sl_int : which == 2 ? K->n_sl_bnd : K->nslices;
@@ -1085,7 +1074,7 @@ unsigned launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double
         fold.nblocks = grid_s;
         fold.np = (int)grid_s + poff_s;
         hipLaunchKernelGGL((k_spmv_small<VT, DOT>), dim3(grid_s), dim3(256), 0, stream, K->nslices, K->nloc,
-                           K->d_slot_ptr, K->d_cols, vals, x, y, partial, st, k, slist, nlist, poff_s, fold, cs);
+                           K->d_slot_ptr, K->d_rowof, K->d_cols, vals, x, y, partial, st, k, slist, nlist, poff_s, fold, cs);
         return grid_s;
     }
     const int32_t poff = which == 2 ? (int32_t)nblk(K->n_sl_int, 4) : 0;
@@ -1096,7 +1085,7 @@ unsigned launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double
 #define SPMV_CASE(V)                                                                          \
     case V:                                                                                   \
         hipLaunchKernelGGL((k_spmv<VT, DOT, V>), dim3(grid), dim3(256), 0, stream, K->nslices, \
-                           K->nloc, K->d_slot_ptr, K->d_cols, vals, x, y, partial, st, k,     \
+                           K->nloc, K->d_slot_ptr, K->d_rowof, K->d_cols, vals, x, y, partial, st, k, \
                            slist, nlist, poff, fold, cs);                                     \
         break;
     // auto (-1): non-temporal matrix stream + XCD-chunked workgroup mapping (variant 9), with the
@@ -1133,7 +1122,7 @@ unsigned launch_spmv2(stan_ctx *ctx, stan_matrix *K, const VT *vals, const doubl
     const colstream cs = ctx->cols16 && K->d_cols16 ? colstream{K->d_cols16, K->d_colbase, K->d_pair_ptr, K->d_slice_packed}
                                                     : colstream{nullptr, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL((k_spmv2<VT>), dim3(grid), dim3(256), 0, stream, K->nslices, K->nloc, K->d_slot_ptr,
-                       K->d_cols, vals, x, x2, y, y2, partial, st, k, slist, nlist, poff, fold, cs);
+                       K->d_rowof, K->d_cols, vals, x, x2, y, y2, partial, st, k, slist, nlist, poff, fold, cs);
     return grid;
 }
 
@@ -1225,11 +1214,11 @@ static int ensure_scaled(stan_ctx *ctx, stan_matrix *K) {
     hipLaunchKernelGGL(k_fill, dim3(vec_grid(ns)), dim3(VEC_T), 0, ctx->stream, K->d_scale, ns, 1.0);
     if (K->nloc > 0)
         hipLaunchKernelGGL(k_diag_scale, dim3(nblk(K->nloc, 256)), dim3(256), 0, ctx->stream, K->nloc,
-                           K->d_rowlen, K->d_slot_ptr, K->d_cols, K->d_vals, K->d_scale);
+                           K->d_rowlen, K->d_posof, K->d_slot_ptr, K->d_cols, K->d_vals, K->d_scale);
     if (ctx->comm || ctx->nranks > 1) STANCHK(stan_comm_halo_exchange(ctx, K, K->d_scale));
     if (K->nslices > 0)
         hipLaunchKernelGGL(k_scale_matrix, dim3(nblk(K->nslices, 4)), dim3(256), 0, ctx->stream,
-                           K->nslices, K->d_slot_ptr, K->d_cols, K->d_vals, K->d_scale, 0);
+                           K->nslices, K->d_slot_ptr, K->d_rowof, K->d_cols, K->d_vals, K->d_scale, 0);
     HIPCHK(ctx, hipGetLastError());
     K->scaled = true;
     // copies of the value stream made before the scaling (stan_hip_spmv_bench on a fresh matrix)
@@ -1245,7 +1234,7 @@ int stan_matrix_make_fp32(stan_ctx *ctx, stan_matrix *K) {
     const int64_t n = K->nslots * 9 * 64;
     STANCHK(stan_dmalloc_streamed(ctx, (void **)&K->d_vals32, (size_t)n * 4,
                                   [&](const void *q, float *ms, bool self) {
-                                      return stan_spmv_probe(ctx, K, q, STAN_PREC_MIXED, ms, self);
+                                      return stan_spmv_probe(ctx, K, q, (size_t)n * 4, STAN_PREC_MIXED, ms, self);
                                   }));
     hipLaunchKernelGGL(k_to_fp32, dim3(vec_grid(n) * 4), dim3(VEC_T), 0, ctx->stream, K->d_vals,
                        K->d_vals32, n);
@@ -1261,7 +1250,7 @@ int stan_matrix_make_fx48(stan_ctx *ctx, stan_matrix *K) {
     uint32_t *out;
     STANCHK(stan_dmalloc_streamed(ctx, (void **)&out, (size_t)K->nslots * 14 * 64 * 4,
                                   [&](const void *q, float *ms, bool self) {
-                                      return stan_spmv_probe(ctx, K, q, STAN_PREC_FIXED48, ms, self);
+                                      return stan_spmv_probe(ctx, K, q, (size_t)K->nslots * 14 * 64 * 4, STAN_PREC_FIXED48, ms, self);
                                   }));
     unsigned long long *d_bad = (unsigned long long *)(ctx->d_status + SS_COUNTER);
     HIPCHK(ctx, hipMemsetAsync(d_bad, 0, 8, ctx->stream));
@@ -1341,6 +1330,17 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         ev0 = events.make(); ev1 = events.make();
         hipEventRecord(ev0, st_);
     }
+    const bool dist = ctx->comm != nullptr || ctx->nranks > 1;  // exchanges in the loop
+    // peer to peer (one-process group handle, STAN_OPT_COMM_P2P): no RCCL call below this line
+    const bool p2p = dist && ctx->comm_p2p && ctx->p2p != nullptr;
+    STANCHK(stan_cg_workspace(ctx, K));   // the context's vectors (the placement search probed with them)
+    if (p2p) {
+        // my neighbours write their boundary rows straight into these vectors: tell them where they are
+        const int64_t ns_ = 3 * ((int64_t)K->nslices * 64 + K->nhalo);
+        if (!K->d_scale) STANCHK(stan_dmalloc(ctx, &K->d_scale, (size_t)ns_));
+        double *const pub[5] = {ctx->ws.xb[0], ctx->ws.xb[1], ctx->ws.p, ctx->ws.r, K->d_scale};
+        STANCHK(stan_p2p_publish_vectors(ctx, K, pub));
+    }
     STANCHK(ensure_scaled(ctx, K));
     if (ctx->cols16) STANCHK(stan_matrix_make_cols16(ctx, K));
     if (precision_mode == STAN_PREC_MIXED) STANCHK(stan_matrix_make_fp32(ctx, K));
@@ -1348,7 +1348,6 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     // the stream the products really read (FIXED-48 falls back to fp64 when K is not SPD-scalable)
     const int vs = precision_mode == STAN_PREC_FIXED48 ? (K->d_vals48 ? STAN_PREC_FIXED48 : STAN_PREC_FP64)
                                                        : precision_mode;
-    const bool dist = ctx->comm != nullptr || ctx->nranks > 1;  // collectives in the loop
     const bool sr = ctx->cg_single_reduce;
     const bool foldr = ctx->cg_fold_reduce;
 
@@ -1360,7 +1359,6 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     double *xb[2], *p, *r, *v, *w, *bh, *partial, *sc, *sv = nullptr;
     int64_t *stt;
     unsigned long long *tick;
-    STANCHK(stan_cg_workspace(ctx, K));   // the context's vectors (the placement search probed with them)
     xb[0] = ctx->ws.xb[0]; xb[1] = ctx->ws.xb[1]; p = ctx->ws.p; r = ctx->ws.r;
     v = ctx->ws.v; w = ctx->ws.w; bh = ctx->ws.bh;
     if (sr) sv = ctx->ws.sv;
@@ -1380,25 +1378,60 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         HIPCHK(ctx, hipMemsetAsync(sv, 0, (size_t)n3 * 8, st_));
     }
     // folded reductions: counter A serves the products, counter B the vector kernels
-    auto fold_to = [&](int which, double *out) {
-        return fold_args{foldr ? tick + FOLD_WORDS * which : nullptr, 0, 0, out};
+    // Where the sums of a reduction go.  One rank, or RCCL: the local scalars (RCCL all-reduces them in
+    // place).  Peer to peer: every rank's mailbox slot `slot`, columns j0.. (+ arrival count when this is
+    // the producer that completes the exchange); the consumers then read through a red_src.
+    const stan_p2p_dev *p2p_tab = p2p ? stan_p2p_table(ctx) : nullptr;
+    auto p2p_to = [&](int j0, bool signal) {
+        return p2p ? p2p_out{p2p_tab, stan_p2p_reduce_slot(ctx), j0, signal ? 1 : 0} : NO_P2P;
     };
-    auto reduce_if_unfolded = [&](int np, int nv, double *out) {
+    auto fold_to = [&](int which, double *out, p2p_out po = NO_P2P) {
+        return fold_args{foldr ? tick + FOLD_WORDS * which : nullptr, 0, 0, out, po};
+    };
+    auto reduce_if_unfolded = [&](int np, int nv, double *out, p2p_out po = NO_P2P) {
         if (foldr || np <= 0) return;
-        if (nv == 2) hipLaunchKernelGGL(k_reduce<2>, dim3(1), dim3(256), 0, st_, partial, np, out);
-        else hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, np, out);
+        if (nv == 2) hipLaunchKernelGGL(k_reduce<2>, dim3(1), dim3(256), 0, st_, partial, np, out, po);
+        else hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, np, out, po);
+    };
+    // One exchange point of the sharded loop: RCCL all-reduce of `count` scalars in place, or the stream
+    // wait for every rank's arrival; returns where the consumers find the sums.
+    std::vector<hipEvent_t> red_ev, halo_ev;   // profiling: events around the exchanges
+    int64_t n_coll = 0, n_wait = 0;            // RCCL collectives / stream waits enqueued by the loop (profile)
+    auto exchange_sums = [&](double *scalars, int count, red_src *rs) -> int {
+        *rs = red_src{nullptr, 0};
+        if (!dist) return STAN_OK;
+        if (ctx->profiling) { red_ev.push_back(events.make()); hipEventRecord(red_ev.back(), st_); }
+        int rc_ = STAN_OK;
+        if (p2p) {
+            *rs = red_src{stan_p2p_mailbox(ctx, stan_p2p_reduce_slot(ctx)), ctx->nranks};
+            rc_ = stan_p2p_reduce_wait(ctx);
+            n_wait++;
+        } else {
+            rc_ = stan_comm_allreduce_sum_f64(ctx, scalars, (size_t)count);
+            n_coll++;
+        }
+        if (ctx->profiling) { red_ev.push_back(events.make()); hipEventRecord(red_ev.back(), st_); }
+        return rc_;
+    };
+    auto halo = [&](double *x) -> int {
+        if (ctx->profiling) { halo_ev.push_back(events.make()); hipEventRecord(halo_ev.back(), st_); }
+        const int rc_ = stan_comm_halo_exchange(ctx, K, x);
+        if (p2p && !K->nbr.empty()) n_wait++;
+        if (ctx->profiling) { halo_ev.push_back(events.make()); hipEventRecord(halo_ev.back(), st_); }
+        return rc_;
     };
 
     const unsigned vg = vec_grid(n3);
     {
-        fold_args f = fold_to(1, sc + S_VMV);
+        fold_args f = fold_to(1, sc + S_VMV, p2p_to(0, true));
         f.nblocks = vg; f.np = (int)vg;
         hipLaunchKernelGGL(k_init, dim3(vg), dim3(VEC_T), 0, st_, n3, dof0, K->d_red, d_F, K->d_scale,
                            bh, xb[0], r, p, partial, f);
-        reduce_if_unfolded((int)vg, 1, sc + S_VMV);
+        reduce_if_unfolded((int)vg, 1, sc + S_VMV, p2p_to(0, true));
     }
-    if (dist) STANCHK(stan_comm_allreduce_sum_f64(ctx, sc + S_VMV, 1));
-    hipLaunchKernelGGL(k_init_scalars, dim3(1), dim3(1), 0, st_, sc, stt, eps_f);
+    red_src rs_b;
+    STANCHK(exchange_sums(sc + S_VMV, 1, &rs_b));
+    hipLaunchKernelGGL(k_init_scalars, dim3(1), dim3(64), 0, st_, sc, stt, eps_f, rs_b);
     HIPCHK(ctx, hipGetLastError());
 
     // lincgcreate: ItsBeforeRestart = N (global reduced size)
@@ -1417,10 +1450,10 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     }
     std::vector<hipEvent_t> spmv_ev, spmv2_ev;
     std::vector<int64_t> spmv_k, spmv2_k;  // iteration of each timed launch (see the profile below)
-    int64_t n_launch = 0, n_coll = 0;      // kernels / collectives enqueued by the loop (profile)
+    int64_t n_launch = 0;                  // kernels enqueued by the loop (profile)
     // y = A^ x (x gets its halo filled first when sharded) with `dot` sums (k_spmv's DOT) reduced
     // into out[0..dot): folded into the last launch of the product, or by k_reduce.
-    auto spmv = [&](double *x, double *y, int dot, double *out, int64_t k) -> int {
+    auto spmv = [&](double *x, double *y, int dot, double *out, int64_t k, p2p_out po = NO_P2P) -> int {
         if (ctx->profiling) {
             hipEvent_t a = events.make(), b = events.make();
             hipEventRecord(a, st_);
@@ -1428,7 +1461,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             spmv_k.push_back(k);
         }
         auto go = [&](int which, hipStream_t s, bool last) -> unsigned {
-            const fold_args f = (dot && last) ? fold_to(0, out) : fold_args{nullptr, 0, 0, nullptr};
+            const fold_args f = (dot && last) ? fold_to(0, out, po) : NO_FOLD;
             n_launch++;
             return dot == 2 ? launch_spmv_any<2>(ctx, K, vs, x, y, partial, stt, k, which, s, f)
                  : dot == 1 ? launch_spmv_any<1>(ctx, K, vs, x, y, partial, stt, k, which, s, f)
@@ -1441,20 +1474,20 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             HIPCHK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_a, 0));
             parts = go(1, ctx->side, false);
             HIPCHK(ctx, hipEventRecord(ctx->ev_b, ctx->side));
-            STANCHK(stan_comm_halo_exchange(ctx, K, x));
+            STANCHK(halo(x));
             HIPCHK(ctx, hipStreamWaitEvent(st_, ctx->ev_b, 0));
             const unsigned pb = go(2, st_, true);   // adds up the interior launch's partials too
             if (pb == 0) folded = false;            // no boundary slices on this rank: nobody folded
             parts += pb;
         } else {
-            if (dist) STANCHK(stan_comm_halo_exchange(ctx, K, x));
+            if (dist) STANCHK(halo(x));
             parts = go(0, st_, true);
             if (parts == 0) folded = false;
         }
         if (dot && !folded) {
-            if (parts > 0) {
-                if (dot == 2) hipLaunchKernelGGL(k_reduce<2>, dim3(1), dim3(256), 0, st_, partial, (int)parts, out);
-                else hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, (int)parts, out);
+            if (parts > 0 || po.pp) {   // (peer to peer: a rank that owns no rows still sends its zeros)
+                if (dot == 2) hipLaunchKernelGGL(k_reduce<2>, dim3(1), dim3(256), 0, st_, partial, (int)parts, out, po);
+                else hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, (int)parts, out, po);
                 n_launch++;
             } else HIPCHK(ctx, hipMemsetAsync(out, 0, 8 * dot, st_));   // a rank that owns no rows
         }
@@ -1463,7 +1496,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     };
 
     // v = A^ x and w = A^ x2 in one matrix pass (fused residual refresh), x.v -> out
-    auto spmv2 = [&](double *x, double *x2, double *out, int64_t k) -> int {
+    auto spmv2 = [&](double *x, double *x2, double *out, int64_t k, p2p_out po = NO_P2P) -> int {
         if (ctx->profiling) {
             hipEvent_t a = events.make(), b = events.make();
             hipEventRecord(a, st_);
@@ -1471,7 +1504,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             spmv2_k.push_back(k);
         }
         auto go = [&](int which, hipStream_t s, bool last) -> unsigned {
-            const fold_args f = last ? fold_to(0, out) : fold_args{nullptr, 0, 0, nullptr};
+            const fold_args f = last ? fold_to(0, out, po) : NO_FOLD;
             n_launch++;
             if (vs == STAN_PREC_FIXED48) return launch_spmv2<uint32_t>(ctx, K, K->d_vals48, x, x2, v, w, partial, stt, k, which, s, f);
             return vs == STAN_PREC_MIXED ? launch_spmv2<float>(ctx, K, K->d_vals32, x, x2, v, w, partial, stt, k, which, s, f)
@@ -1484,26 +1517,26 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             HIPCHK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_a, 0));
             parts = go(1, ctx->side, false);
             HIPCHK(ctx, hipEventRecord(ctx->ev_b, ctx->side));
-            STANCHK(stan_comm_halo_exchange(ctx, K, x));
-            STANCHK(stan_comm_halo_exchange(ctx, K, x2));
+            STANCHK(halo(x));
+            STANCHK(halo(x2));
             HIPCHK(ctx, hipStreamWaitEvent(st_, ctx->ev_b, 0));
             const unsigned pb = go(2, st_, true);
             if (pb == 0) folded = false;
             parts += pb;
         } else {
-            if (dist) { STANCHK(stan_comm_halo_exchange(ctx, K, x)); STANCHK(stan_comm_halo_exchange(ctx, K, x2)); }
+            if (dist) { STANCHK(halo(x)); STANCHK(halo(x2)); }
             parts = go(0, st_, true);
             if (parts == 0) folded = false;
         }
         if (!folded) {
-            if (parts > 0) { hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, (int)parts, out); n_launch++; }
+            if (parts > 0 || po.pp) { hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, (int)parts, out, po); n_launch++; }
             else HIPCHK(ctx, hipMemsetAsync(out, 0, 8, st_));
         }
         if (ctx->profiling) hipEventRecord(spmv2_ev.back(), st_);
         return STAN_OK;
     };
-    auto vec_fold = [&](double *out) {
-        fold_args f = fold_to(1, out);
+    auto vec_fold = [&](double *out, p2p_out po = NO_P2P) {
+        fold_args f = fold_to(1, out, po);
         f.nblocks = vg; f.np = (int)vg;
         return f;
     };
@@ -1773,8 +1806,8 @@ int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode
 // self_pair: the gather vector and the product are carved out of the FRONT of the candidate block
 // itself instead of the context's vectors -- by construction the same-group (slow) pairing, i.e.
 // the reference the search compares the real pairing with (profiles/r02/placement_cross_self_n148.txt).
-int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, int32_t precision, float *ms_out,
-                    bool self_pair) {
+int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, size_t bytes, int32_t precision,
+                    float *ms_out, bool self_pair) {
     hipStream_t st_ = ctx->stream;
     *ms_out = 0;
     if (K->nslices <= 0) return STAN_OK;
@@ -1787,6 +1820,10 @@ int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, int32_t pre
     STANCHK(stan_cg_workspace(ctx, K));
     x = ctx->ws.p; y = ctx->ws.v;
     if (self_pair) {   // the block holds no values yet (only addresses matter to the timing)
+        // the gather vector and the product must fit into the candidate: a stream with few slots per
+        // slice (or a large halo) has no self-paired reference -- *ms_out stays 0, the search then
+        // keeps the fastest real pairing (placement.hip)
+        if ((size_t)(((ng + 511) & ~(int64_t)511) + 3 * K->nloc) * 8 > bytes) return STAN_OK;
         x = (double *)const_cast<void *>(vals);
         y = x + ((ng + 511) & ~(int64_t)511);
     }
@@ -1817,163 +1854,7 @@ int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, int32_t pre
 }
 
 #ifdef STAN_LAB
-// lab: time the fp64 SpMV over the slices [s0, s1) only, streaming the values from `vals`
-// (lab/placement_lab.hip: where inside a block does a slow block lose its time?)
-int stan_spmv_probe_range(stan_ctx *ctx, stan_matrix *K, const double *vals, int32_t s0, int32_t s1,
-                          int reps, float *ms_out, int variant, double *xy_region, double *y_region) {
-    hipStream_t st_ = ctx->stream;
-    *ms_out = 0;
-    if (s1 <= s0) return STAN_OK;
-    const int64_t npad = (int64_t)K->nslices * 64;
-    const int64_t ng = 3 * ((npad > K->nloc + K->nhalo ? npad : K->nloc + K->nhalo));
-    dev_bufs bufs;
-    double *x, *y, *partial; int64_t *stt; int32_t *list;
-    if (xy_region) {   // lab: gather vector and product live inside a block the caller chose
-        x = xy_region;
-        y = y_region ? y_region : xy_region + ((ng + 511) & ~(int64_t)511);
-    } else {
-        STANCHK(alloc(ctx, bufs, &x, (size_t)ng));
-        STANCHK(alloc(ctx, bufs, &y, (size_t)ng));
-    }
-    STANCHK(alloc(ctx, bufs, &partial, 2 * (size_t)K->nslices + 2));   // k_spmv_small leaves one partial per slice
-    STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
-    STANCHK(alloc(ctx, bufs, &list, (size_t)(s1 - s0)));
-    std::vector<int32_t> h((size_t)(s1 - s0));
-    for (int32_t i = s0; i < s1; i++) h[i - s0] = i;
-    int64_t init[T_NSTAT] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0, 0, 0, 0, 0, 0};
-    HIPCHK(ctx, hipMemcpyAsync(stt, init, sizeof(init), hipMemcpyHostToDevice, st_));
-    HIPCHK(ctx, hipMemcpyAsync(list, h.data(), h.size() * 4, hipMemcpyHostToDevice, st_));
-    hipLaunchKernelGGL(k_fill, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, x, ng, 1.0);
-    HIPCHK(ctx, hipStreamSynchronize(st_));
-    const unsigned grid = nblk(s1 - s0, 4);
-    event_bag ev;
-    hipEvent_t a = ev.make(), b = ev.make();
-    for (int r = 0; r < reps + 2; r++) {
-        if (r == 2) hipEventRecord(a, st_);
-#define LABV(V) case V: hipLaunchKernelGGL((k_spmv<double, 1, V>), dim3(grid), dim3(256), 0, st_, K->nslices, K->nloc, \
-                           K->d_slot_ptr, K->d_cols, vals, x, y, partial, stt, (int64_t)1, list, s1 - s0, 0,           \
-                           fold_args{nullptr, 0, 0, nullptr}, colstream{nullptr, nullptr, nullptr, nullptr}); break;
-        switch (variant) { LABV(0) LABV(13) LABV(14) LABV(15) LABV(16) LABV(12) default: LABV(9) }
-#undef LABV
-    }
-    hipEventRecord(b, st_);
-    HIPCHK(ctx, hipEventSynchronize(b));
-    hipEventElapsedTime(ms_out, a, b);
-    *ms_out /= reps;
-    HIPCHK(ctx, hipGetLastError());
-    return STAN_OK;
-}
-__global__ void k_fill_nt(double *p, int64_t n, double v) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) __builtin_nontemporal_store(v, p + i);
-}
-__global__ void k_fill_scope(double *p, int64_t n, double v, int scope) {   // 0: agent-scope (sc1), 1: system-scope stores
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        if (scope == 0) __hip_atomic_store(p + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else __hip_atomic_store(p + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-// the rewrite k_update really does: x = r + beta x (read-modify-write of the gather vector)
-template <bool LNT, bool SNT>
-__global__ void k_rmw(double *x, const double *r, int64_t n, double beta) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const double xo = LNT ? __builtin_nontemporal_load(x + i) : x[i];
-        const double ro = LNT ? __builtin_nontemporal_load(r + i) : r[i];
-        const double v = ro * 0.0 + 1.0 + beta * (xo - 1.0);   // stays 1.0
-        if (SNT) __builtin_nontemporal_store(v, x + i); else x[i] = v;
-    }
-}
-// ping-pong form of the same rewrite: xo = r + beta xi into ANOTHER buffer
-template <bool LNT, bool SNT>
-__global__ void k_pingpong(double *xo, const double *xi, const double *r, int64_t n, double beta) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const double xv = LNT ? __builtin_nontemporal_load(xi + i) : xi[i];
-        const double ro = LNT ? __builtin_nontemporal_load(r + i) : r[i];
-        const double v = ro * 0.0 + 1.0 + beta * (xv - 1.0);
-        if (SNT) __builtin_nontemporal_store(v, xo + i); else xo[i] = v;
-    }
-}
-__global__ void k_read_only(const double *p, int64_t n, double *sink) {
-    double a = 0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) a += p[i];
-    if (a == 0.123456789) sink[0] = a;
-}
-// lab: what makes the SpMV slower inside the CG than back to back?  mode 0: launches back to back;
-// 1: the gather vector is rewritten (k_fill, plain stores like k_update) before every launch;
-// 2: plus a k_step-like pass over four other vectors in between; 3: only that pass (x untouched).
-// Events bracket each product alone.  out_ms [4].
-int stan_spmv_incg_lab(stan_ctx *ctx, stan_matrix *K, int reps, double *out_ms) {
-    hipStream_t st_ = ctx->stream;
-    STANCHK(stan_cg_workspace(ctx, K));
-    const int64_t ng = ctx->ws.ng, n3 = 3 * K->nloc;
-    double *x = ctx->ws.p, *y = ctx->ws.v;
-    dev_bufs bufs;
-    double *partial; int64_t *stt;
-    STANCHK(alloc(ctx, bufs, &partial, 2 * (size_t)nblk(K->nslices, 4) + 16));
-    STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
-    int64_t init[T_NSTAT] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0, 0, 0, 0, 0, 0};
-    HIPCHK(ctx, hipMemcpyAsync(stt, init, sizeof(init), hipMemcpyHostToDevice, st_));
-    hipLaunchKernelGGL(k_fill, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, x, ng, 1.0);
-    for (double *q : {ctx->ws.xb[1], ctx->ws.r, ctx->ws.w})
-        hipLaunchKernelGGL(k_fill, dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, q, n3, 0.5);
-    hipLaunchKernelGGL(k_fill, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, ctx->ws.xb[0], ng, 1.0);
-    for (int mode = 0; mode < 15; mode++) {
-        event_bag ev;
-        std::vector<hipEvent_t> e;
-        for (int r = 0; r < reps + 2; r++) {
-            if (mode == 1 || mode == 2) hipLaunchKernelGGL(k_fill, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, x, ng, 1.0);
-            if (mode == 2 || mode == 3) {   // the traffic of k_step: x' = x + a p, r -= a v  (reads 4, writes 2)
-                step_args a;
-                a.n3 = n3; a.k = 1; a.sc = nullptr; a.st = stt; a.xcur = ctx->ws.xb[0]; a.xnext = ctx->ws.xb[1];
-                a.r = ctx->ws.r; a.p = ctx->ws.w; a.v = y; a.bh = ctx->ws.bh; a.partial = partial; a.w = ctx->ws.w;
-                a.merit = 0; a.refresh = 0; a.defer_x = 0; a.fold = fold_args{nullptr, 0, 0, nullptr};
-                double *scal; STANCHK(alloc(ctx, bufs, &scal, (size_t)S_NSCAL));
-                double hs[S_NSCAL] = {0}; hs[S_VMV] = 1.0; hs[S_RHO0] = hs[S_RHO1] = 1e-30;
-                HIPCHK(ctx, hipMemcpyAsync(scal, hs, sizeof(hs), hipMemcpyHostToDevice, st_));
-                a.sc = scal;
-                hipLaunchKernelGGL(k_step<false>, dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, a);
-            }
-            // 4: rewritten with non-temporal stores; 5: rewritten (plain), then read once front to back
-            // by a streaming kernel (does a read pull it into the memory-side cache?); 6: like 5 with nt stores
-            if (mode == 4 || mode == 6) hipLaunchKernelGGL(k_fill_nt, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, x, ng, 1.0);
-            if (mode == 5) hipLaunchKernelGGL(k_fill, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, x, ng, 1.0);
-            // 9-12: read-modify-write like k_update: plain/plain, plain load + nt store, nt load + nt store, nt load + plain store
-            if (mode == 9) hipLaunchKernelGGL((k_rmw<false, false>), dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, x, ctx->ws.r, n3, 0.5);
-            if (mode == 10) hipLaunchKernelGGL((k_rmw<false, true>), dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, x, ctx->ws.r, n3, 0.5);
-            if (mode == 11) hipLaunchKernelGGL((k_rmw<true, true>), dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, x, ctx->ws.r, n3, 0.5);
-            if (mode == 12) hipLaunchKernelGGL((k_rmw<true, false>), dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, x, ctx->ws.r, n3, 0.5);
-            // 7 / 8: rewritten with agent-scope (sc1, write-through) / system-scope stores
-            if (mode == 7 || mode == 8) hipLaunchKernelGGL(k_fill_scope, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, x, ng, 1.0, mode - 7);
-            if (mode == 5 || mode == 6) hipLaunchKernelGGL(k_read_only, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, (const double *)x, ng, partial);
-            // 13 / 14: the rewrite goes to the OTHER of two buffers (nt load + nt store / plain load + nt store)
-            double *xg = x;
-            if (mode == 13 || mode == 14) {
-                double *xa = (r & 1) ? x : ctx->ws.xb[0], *xi = (r & 1) ? ctx->ws.xb[0] : x;
-                if (mode == 13) hipLaunchKernelGGL((k_pingpong<true, true>), dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, xa, xi, ctx->ws.r, n3, 0.5);
-                else hipLaunchKernelGGL((k_pingpong<false, true>), dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, xa, xi, ctx->ws.r, n3, 0.5);
-                xg = xa;
-            }
-            hipEvent_t a0 = ev.make(), b0 = ev.make();
-            hipEventRecord(a0, st_);
-            hipLaunchKernelGGL((k_spmv<double, 1, 9>), dim3(nblk(K->nslices, 4)), dim3(256), 0, st_, K->nslices, K->nloc,
-                               K->d_slot_ptr, K->d_cols, K->d_vals, xg, y, partial, stt, (int64_t)1,
-                               (const int32_t *)nullptr, K->nslices, 0, fold_args{nullptr, 0, 0, nullptr},
-                               colstream{nullptr, nullptr, nullptr, nullptr});
-            hipEventRecord(b0, st_);
-            if (r >= 2) { e.push_back(a0); e.push_back(b0); }
-        }
-        HIPCHK(ctx, hipStreamSynchronize(st_));
-        double tot = 0;
-        for (size_t i = 0; i + 1 < e.size(); i += 2) { float f = 0; hipEventElapsedTime(&f, e[i], e[i + 1]); tot += f; }
-        out_ms[mode] = tot / reps;
-    }
-    HIPCHK(ctx, hipGetLastError());
-    return STAN_OK;
-}
+#include "lab/cg_lab.inc"   // lab-only host entry points
 #endif
 
 // un-scale on export
@@ -1981,7 +1862,7 @@ int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K) {
     if (!K->scaled) return STAN_OK;
     if (K->nslices > 0)
         hipLaunchKernelGGL(k_scale_matrix, dim3(nblk(K->nslices, 4)), dim3(256), 0, ctx->stream,
-                           K->nslices, K->d_slot_ptr, K->d_cols, K->d_vals, K->d_scale, 1);
+                           K->nslices, K->d_slot_ptr, K->d_rowof, K->d_cols, K->d_vals, K->d_scale, 1);
     HIPCHK(ctx, hipGetLastError());
     K->scaled = false;
     if (K->d_vals32) { stan_dfree(ctx, K->d_vals32); K->d_vals32 = nullptr; }

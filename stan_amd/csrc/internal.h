@@ -4,8 +4,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <string>
+#include <atomic>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
+#include <string>
 #include <unordered_map>
 #include <vector>
 
@@ -113,6 +116,63 @@ struct stan_cg_ws {
     double *v = nullptr, *w = nullptr, *bh = nullptr, *sv = nullptr;  // n3 each
 };
 
+// ---- peer-to-peer exchanges of the one-process multi-GPU handle (p2p.hip) ---------------------
+// All devices of a group handle live in ONE address space, so the sharded CG needs no RCCL launch
+// in its loop: the block that finishes a reduction stores its partial sums into EVERY rank's
+// mailbox and then counts itself into every rank's arrival counter; the consumer's stream waits
+// for the count (hipStreamWaitValue64: no spinning kernel) and the consuming kernel adds the
+// partials of all ranks in rank order (the result is the same on every rank, bit for bit, and
+// the same as a rank-ordered all-reduce gives).  Halo rows are written straight into the
+// neighbour's gather vector, followed by the same kind of count.
+constexpr int STAN_P2P_RING = 4;    // mailbox slots / counters in rotation (a rank is never two exchanges ahead)
+constexpr int STAN_P2P_MAXR = 16;   // ranks of a group that can exchange peer to peer
+struct stan_p2p_dev {               // device-resident, one copy per rank
+    int32_t n, me;
+    double *mbox[STAN_P2P_MAXR];    // rank q's mailbox [RING][n][4] doubles, fine-grained device memory of q
+    unsigned long long *sig_red[STAN_P2P_MAXR][STAN_P2P_RING];   // reduction arrivals at rank q
+    unsigned long long *sig_halo[STAN_P2P_MAXR][STAN_P2P_RING];  // halo arrivals at rank q
+};
+struct stan_p2p {                   // host side, shared by the ranks of a group (owned by multi.hip)
+    int n = 0;
+    int wait_mode = 0;              // 0: hipStreamWaitValue64 on signal memory; 1: a one-wave polling kernel on a device flag
+    struct rank_res {
+        int device = 0;
+        double *mbox = nullptr;
+        unsigned long long *sig_red[STAN_P2P_RING] = {}, *sig_halo[STAN_P2P_RING] = {};
+        stan_p2p_dev *d_dev = nullptr;       // this rank's device copy of the table
+        unsigned long long *d_tick = nullptr; // ticket counter of the halo-pack kernel (device)
+        int64_t red_calls = 0, halo_calls = 0;   // exchanges so far (identical on every rank)
+        unsigned long long red_expect[STAN_P2P_RING] = {}, halo_expect[STAN_P2P_RING] = {};   // arrivals each counter must have reached
+        // published at the start of a solve (host barrier behind it): where my neighbours write
+        double *vec[5] = {};                 // xb0, xb1, p, r, scale
+        int64_t nloc = 0;
+        std::vector<int> nbr;
+        std::vector<int64_t> recv_off;
+    };
+    std::vector<rank_res> rk;
+    // host barrier of the worker threads (abortable)
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    long generation = 0;
+    std::atomic<bool> broken{false};
+};
+int stan_p2p_create(stan_p2p **out, const std::vector<int> &devices, std::string *err);   // called with no worker running
+int stan_p2p_rank_setup(stan_p2p *pp, int rank, std::string *err);    // from rank's own thread (its device current)
+int stan_p2p_rank_finish(stan_p2p *pp, int rank, std::string *err);   // after every rank's setup: uploads the table
+void stan_p2p_rank_release(stan_p2p *pp, int rank);
+void stan_p2p_destroy(stan_p2p *pp);
+void stan_p2p_abort(stan_p2p *pp);                 // frees every stream wait and every host barrier
+int stan_p2p_barrier(stan_p2p *pp);                // STAN_E_COMM when aborted / timed out
+struct stan_ctx;
+struct stan_matrix;
+int stan_p2p_reduce_slot(stan_ctx *ctx);           // mailbox slot / counter of this rank's NEXT reduction
+int stan_p2p_reduce_wait(stan_ctx *ctx);           // stream-ordered wait for it (advances the slot)
+const stan_p2p_dev *stan_p2p_table(stan_ctx *ctx);
+const double *stan_p2p_mailbox(stan_ctx *ctx, int slot);
+int stan_p2p_publish_vectors(stan_ctx *ctx, const stan_matrix *K, double *const vec[5]);
+int stan_p2p_halo_exchange(stan_ctx *ctx, stan_matrix *K, double *d_vec);
+
 struct stan_matrix;
 struct stan_group;   // multi.hip: one process, several GPUs
 struct stan_ctx {
@@ -124,9 +184,13 @@ struct stan_ctx {
     int64_t bad_elem = -1;
     // communicator
     int rank = 0, nranks = 1;
-    void *comm = nullptr;
-    bool comm_broken = false;  // the communicator was aborted after a peer failed: no further collectives
+    void *comm = nullptr;      // guarded by comm_mu: the group's host thread may abort it (multi.hip)
+    std::mutex comm_mu;
+    std::atomic<bool> comm_broken{false};  // the communicator was aborted after a peer failed: no further collectives
     rccl_api nccl;
+    stan_p2p *p2p = nullptr;   // set on the rank contexts of a group whose devices can reach each other
+    bool comm_p2p = false;     // STAN_OPT_COMM_P2P: the CG's reductions and halo exchanges go peer to peer
+    bool result_segment = false;  // group rank: the solve leaves only this rank's own entries of U (no gather)
     // solver options (include/stan_hip.h STAN_OPT_*)
     bool cg_merit_stop = true;
     int cg_rupdate = 10;
@@ -141,7 +205,9 @@ struct stan_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     int assembly_mode = 0;     // 0 row-owner gather (default), 1 element-wave colour scatter
+    int sell_sigma = 32;       // SELL-C-sigma: rows sorted by length inside windows of this many slices (1 = off)
     int placement_tries = 16;  // > 1: allocate the value stream by search (placement.hip); blocks >= 256 MB only
+    int64_t placement_max_bytes = 0;  // bytes of candidates the search may hold at once; 0 = a quarter of the free memory
     float prof_placement_ms_best = 0, prof_placement_ms_worst = 0;
     int prof_placement_candidates = 0;
     int prof_placement_moved_vectors = 0;   // 1: the search ended by re-allocating the CG's vectors
@@ -164,6 +230,7 @@ struct stan_matrix {
     int64_t n_dof = 0, n_red = 0;
     int64_t nb_glob = 0;  // global block rows
     int64_t r0 = 0, r1 = 0;  // owned block rows
+    int64_t u0 = 0, u1 = 0;  // group shard: this rank's entries [u0, u1) of the reduced vectors
     int64_t nloc = 0, nhalo = 0;
     int32_t nslices = 0;
     int64_t nslots = 0;      // total k-slots (each = 64 rows x one block)
@@ -171,7 +238,10 @@ struct stan_matrix {
     int32_t max_row_blocks = 0;
     int64_t n_elem_scanned = 0;  // elements this rank holds on the device (sharded host entry: its subset)
     int32_t *d_slot_ptr = nullptr;  // [nslices+1]
-    int32_t *d_rowlen = nullptr;    // [nslices*64] blocks per row
+    int32_t *d_rowlen = nullptr;    // [nslices*64] blocks per row (by local row)
+    int32_t *d_rowof = nullptr;     // [nslices*64] SELL-C-sigma: position in the sliced layout -> local block row
+    int32_t *d_posof = nullptr;     // [nslices*64] local block row -> position (slice = pos / 64, lane = pos % 64)
+    int sigma = 1;                  // sorting window in slices the matrix was built with
     int32_t *d_cols = nullptr;      // [nslots][64] local block-column index
     uint32_t *d_cols16 = nullptr;   // packed column stream of the SpMV (cg.hip colstream): [pair][64]
     int32_t *d_colbase = nullptr;   //   [nslots] smallest column of each slot
@@ -252,6 +322,7 @@ int stan_recover_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz, con
 
 // ---- comm.cpp -------------------------------------------------------------------------------
 int stan_comm_allreduce_sum_f64(stan_ctx *ctx, double *d_buf, size_t count);
+int stan_comm_info(stan_ctx *ctx, int *version, int *count, int *rank);
 // exchange: pack rows listed in K->d_send_rows from d_vec (3 doubles per block row) and
 // receive into d_vec + 3*nloc (halo region).
 int stan_comm_halo_exchange(stan_ctx *ctx, stan_matrix *K, double *d_vec);
@@ -353,5 +424,5 @@ int stan_group_size(stan_ctx *lead);
 int stan_probe_block(stan_ctx *ctx, const void *p, size_t bytes, float *ms_out);
 int stan_dmalloc_streamed(stan_ctx *ctx, void **p, size_t bytes,
                           const std::function<int(const void *, float *, bool)> &probe);
-int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, int32_t precision, float *ms_out,
-                    bool self_pair = false);
+int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, size_t bytes, int32_t precision,
+                    float *ms_out, bool self_pair = false);

@@ -16,13 +16,13 @@ __global__ void k_csr_rowlen(int64_t nloc, const int32_t *rowlen, int32_t *len3)
     if (d < 3 * nloc) len3[d] = 3 * rowlen[d / 3];
 }
 
-__global__ void k_csr_fill(int64_t nloc, const int32_t *rowlen, const int32_t *slot_ptr,
+__global__ void k_csr_fill(int64_t nloc, const int32_t *rowlen, const int32_t *posof, const int32_t *slot_ptr,
                            const int32_t *cols, const double *vals, const int64_t *rp, int32_t *ci,
                            double *cv) {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= nloc) return;
-    const int64_t slice = row >> 6;
-    const int lane = (int)(row & 63);
+    const int64_t slice = posof[row] >> 6;
+    const int lane = (int)(posof[row] & 63);
     const int32_t k0 = slot_ptr[slice];
     for (int k = 0; k < rowlen[row]; k++) {
         const int32_t c = cols[((int64_t)k0 + k) * 64 + lane];
@@ -77,7 +77,7 @@ extern "C" int stan_hip_csr_spmv_bench(stan_ctx *ctx, stan_matrix *K, int32_t re
     STANCHK(A(&y2, (size_t)npad3)); STANCHK(A(&stt, 8));
     hipLaunchKernelGGL(k_csr_rowlen, dim3(nblk(n3, 256)), dim3(256), 0, st, nloc, K->d_rowlen, len3);
     STANCHK(stan_scan_exclusive(ctx, len3, rp, n3));
-    hipLaunchKernelGGL(k_csr_fill, dim3(nblk(nloc, 256)), dim3(256), 0, st, nloc, K->d_rowlen, K->d_slot_ptr,
+    hipLaunchKernelGGL(k_csr_fill, dim3(nblk(nloc, 256)), dim3(256), 0, st, nloc, K->d_rowlen, K->d_posof, K->d_slot_ptr,
                        K->d_cols, K->d_vals, rp, ci, cv);
     // x_i = 1 + (i mod 7): cheap, non-constant
     std::vector<double> hx((size_t)npad3);

@@ -298,7 +298,7 @@ extern "C" int stan_hip_lab_placement_vecalloc(stan_ctx *ctx, stan_matrix *K, do
     STANCHK(stan_cg_workspace(ctx, K));
     {   // the context's own vectors: region = ws.p .. (x) and ws.v (y) are separate blocks; use the probe
         float t = 0;
-        STANCHK(stan_spmv_probe(ctx, K, K->d_vals, STAN_PREC_FP64, &t, false)); out[4] = t;
+        STANCHK(stan_spmv_probe(ctx, K, K->d_vals, (size_t)K->nslots * 9 * 64 * 8, STAN_PREC_FP64, &t, false)); out[4] = t;
     }
     return STAN_OK;
 }

@@ -1,0 +1,295 @@
+// p2p.hip -- peer-to-peer exchanges of the one-process multi-GPU handle (stan_hip_init_multi):
+// the resources (mailboxes, arrival counters), the halo write, the stream waits and the host
+// barrier.  The reference is one process on one device (Solver.cs:18-69); the sharded CG is this
+// library's own design and SURVEY.md sections 5 / 8e ask for exchanges that cost no collective
+// launch: "avoid ring all-reduce for 16-byte payloads", "peer-mapped buffers".
+//
+// What an iteration of the sharded classic loop enqueues with STAN_OPT_COMM_P2P on (per rank):
+//   k_pack_p2p   boundary rows of p -> the neighbours' gather vectors + arrival count
+//   k_spmv       interior slices (side stream), then [wait: halo count] boundary slices; the block
+//                that finishes the p.Ap sum stores this rank's partial into EVERY rank's mailbox
+//   [wait: reduction count]  k_step   (adds the N partials in rank order; r.r and merit likewise)
+//   [wait: reduction count]  k_update
+// = 4 kernels, 3 stream waits, no RCCL launch (RCCL path: 4 kernels + 3 collective launches).
+// The waits are hipStreamWaitValue64 on signal memory where the device offers it (the command
+// processor waits, no wavefront spins), else a one-wave polling kernel on a device flag.
+#include <chrono>
+
+#include "internal.h"
+#include "p2p_device.h"
+
+namespace {
+
+constexpr unsigned long long RELEASE_ALL = 1ULL << 62;   // stan_p2p_abort: every wait is satisfied
+
+// boundary rows of `vec` into the halo regions of the neighbours' vectors, then one arrival count
+// per neighbour by the block that finishes last (every block has waited for its stores first)
+struct pack_args {
+    int64_t stot;                       // rows to send, grouped by neighbour
+    const int32_t *rows;
+    const double *vec;
+    int32_t n_nbr;
+    int64_t send_off[STAN_P2P_MAXR];    // [n_nbr + 1]
+    double *dst[STAN_P2P_MAXR];         // neighbour i's halo segment for this rank
+    unsigned long long *sig[STAN_P2P_MAXR];
+    unsigned long long *tick;
+};
+__global__ void __launch_bounds__(256) k_pack_p2p(pack_args a) {
+    __shared__ int sh_last;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < 3 * a.stot; t += stride) {
+        const int64_t i = t / 3;
+        int nb = 0;
+        while (nb + 1 < a.n_nbr && i >= a.send_off[nb + 1]) nb++;
+        const int c = (int)(t - 3 * i);
+        st_sys(a.dst[nb] + (t - 3 * a.send_off[nb]), a.vec[3 * (int64_t)a.rows[i] + c]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        const unsigned long long t = __hip_atomic_fetch_add(a.tick, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_last = t == (unsigned long long)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!sh_last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(a.tick, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)threadIdx.x < a.n_nbr && a.sig[threadIdx.x]) {
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        __hip_atomic_fetch_add(a.sig[threadIdx.x], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// wait_mode 1: one wavefront polls the counter (a device flag in fine-grained memory)
+__global__ void k_wait_flag(const unsigned long long *flag, unsigned long long want) {
+    if (threadIdx.x == 0) {
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) __builtin_amdgcn_s_sleep(4);
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+}
+
+int alloc_counter(stan_p2p *pp, unsigned long long **out) {
+    *out = nullptr;
+    if (pp->wait_mode == 0) {
+        if (hipExtMallocWithFlags((void **)out, 8, hipMallocSignalMemory) != hipSuccess) { (void)hipGetLastError(); return STAN_E_ALLOC; }
+        **out = 0;   // the value of an HSA signal lives in host-visible memory
+        return STAN_OK;
+    }
+    if (hipExtMallocWithFlags((void **)out, 128, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return STAN_E_ALLOC; }
+    return hipMemset(*out, 0, 128) == hipSuccess ? STAN_OK : STAN_E_HIP;
+}
+
+}  // namespace
+
+// Decides whether the devices can exchange peer to peer and how the streams will wait.
+int stan_p2p_create(stan_p2p **out, const std::vector<int> &devices, std::string *err) {
+    *out = nullptr;
+    const int n = (int)devices.size();
+    if (n < 2 || n > STAN_P2P_MAXR) { *err = "peer-to-peer exchanges need 2.." + std::to_string(STAN_P2P_MAXR) + " ranks"; return STAN_E_UNSUPPORTED; }
+    for (int a = 0; a < n; a++)
+        for (int b = 0; b < n; b++) {
+            if (devices[a] == devices[b]) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) != hipSuccess || !can) {
+                (void)hipGetLastError();
+                *err = "device " + std::to_string(devices[a]) + " cannot access device " + std::to_string(devices[b]);
+                return STAN_E_UNSUPPORTED;
+            }
+        }
+    stan_p2p *pp = new stan_p2p();
+    pp->n = n;
+    pp->rk.resize((size_t)n);
+    for (int r = 0; r < n; r++) pp->rk[(size_t)r].device = devices[r];
+    int can_wait = 0;
+    pp->wait_mode = 0;
+    for (int r = 0; r < n; r++) {
+        can_wait = 0;
+        if (hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, devices[r]) != hipSuccess || !can_wait) {
+            (void)hipGetLastError();
+            pp->wait_mode = 1;
+        }
+    }
+    if (const char *m = getenv("STAN_P2P_WAIT_MODE")) pp->wait_mode = atoi(m) ? 1 : 0;   // lab: force the polling kernel
+    *out = pp;
+    return STAN_OK;
+}
+
+// rank's own thread, its device current: peer access, mailbox, counters
+int stan_p2p_rank_setup(stan_p2p *pp, int rank, std::string *err) {
+    stan_p2p::rank_res &me = pp->rk[(size_t)rank];
+    for (int q = 0; q < pp->n; q++) {
+        if (pp->rk[(size_t)q].device == me.device) continue;
+        const hipError_t e = hipDeviceEnablePeerAccess(pp->rk[(size_t)q].device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { *err = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e); return STAN_E_HIP; }
+        (void)hipGetLastError();
+    }
+    const size_t mb = (size_t)STAN_P2P_RING * pp->n * 4 * sizeof(double);
+    if (hipExtMallocWithFlags((void **)&me.mbox, mb < 4096 ? 4096 : mb, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        *err = "peer-to-peer mailbox: no fine-grained device memory";
+        return STAN_E_ALLOC;
+    }
+    if (hipMemset(me.mbox, 0, mb < 4096 ? 4096 : mb) != hipSuccess) { *err = "peer-to-peer mailbox: hipMemset failed"; return STAN_E_HIP; }
+    for (int s = 0; s < STAN_P2P_RING; s++) {
+        int rc = alloc_counter(pp, &me.sig_red[s]);
+        if (rc == STAN_OK) rc = alloc_counter(pp, &me.sig_halo[s]);
+        if (rc != STAN_OK) { *err = "peer-to-peer arrival counters: allocation failed"; return rc; }
+    }
+    if (hipMalloc((void **)&me.d_dev, sizeof(stan_p2p_dev)) != hipSuccess || hipMalloc((void **)&me.d_tick, 128) != hipSuccess ||
+        hipMemset(me.d_tick, 0, 128) != hipSuccess) {
+        (void)hipGetLastError();
+        *err = "peer-to-peer tables: hipMalloc failed";
+        return STAN_E_ALLOC;
+    }
+    return STAN_OK;
+}
+
+// after EVERY rank's setup: the table of all ranks' mailboxes and counters goes to this rank's device
+int stan_p2p_rank_finish(stan_p2p *pp, int rank, std::string *err) {
+    stan_p2p_dev t{};
+    t.n = pp->n;
+    t.me = rank;
+    for (int q = 0; q < pp->n; q++) {
+        t.mbox[q] = pp->rk[(size_t)q].mbox;
+        for (int s = 0; s < STAN_P2P_RING; s++) {
+            t.sig_red[q][s] = pp->rk[(size_t)q].sig_red[s];
+            t.sig_halo[q][s] = pp->rk[(size_t)q].sig_halo[s];
+        }
+    }
+    if (hipMemcpy(pp->rk[(size_t)rank].d_dev, &t, sizeof(t), hipMemcpyHostToDevice) != hipSuccess) {
+        *err = "peer-to-peer tables: upload failed";
+        return STAN_E_HIP;
+    }
+    return STAN_OK;
+}
+
+void stan_p2p_rank_release(stan_p2p *pp, int rank) {
+    stan_p2p::rank_res &me = pp->rk[(size_t)rank];
+    if (me.mbox) hipFree(me.mbox);
+    for (int s = 0; s < STAN_P2P_RING; s++) {
+        if (me.sig_red[s]) hipFree(me.sig_red[s]);
+        if (me.sig_halo[s]) hipFree(me.sig_halo[s]);
+        me.sig_red[s] = me.sig_halo[s] = nullptr;
+    }
+    if (me.d_dev) hipFree(me.d_dev);
+    if (me.d_tick) hipFree(me.d_tick);
+    me.mbox = nullptr; me.d_dev = nullptr; me.d_tick = nullptr;
+}
+
+void stan_p2p_destroy(stan_p2p *pp) { delete pp; }
+
+// A rank failed: every stream wait of every rank is satisfied from now on (the counters jump past any
+// value a solve can ask for), host barriers return STAN_E_COMM, and the CG loops of the surviving
+// ranks see `broken` at their next status poll.
+void stan_p2p_abort(stan_p2p *pp) {
+    if (!pp) return;
+    pp->broken.store(true);
+    for (stan_p2p::rank_res &r : pp->rk)
+        for (int s = 0; s < STAN_P2P_RING; s++)
+            for (unsigned long long *c : {r.sig_red[s], r.sig_halo[s]}) {
+                if (!c) continue;
+                if (pp->wait_mode == 0) __atomic_store_n(c, RELEASE_ALL, __ATOMIC_RELEASE);   // host-visible signal value
+                else { const unsigned long long v = RELEASE_ALL; (void)hipMemcpy(c, &v, 8, hipMemcpyHostToDevice); }
+            }
+    std::lock_guard<std::mutex> lk(pp->m);
+    pp->cv.notify_all();
+}
+
+int stan_p2p_barrier(stan_p2p *pp) {
+    std::unique_lock<std::mutex> lk(pp->m);
+    if (pp->broken.load()) return STAN_E_COMM;
+    const long gen = pp->generation;
+    if (++pp->arrived == pp->n) {
+        pp->arrived = 0;
+        pp->generation++;
+        pp->cv.notify_all();
+        return STAN_OK;
+    }
+    // bounded: a peer that never arrives (it failed before the solve) must not hang this rank
+    const bool ok = pp->cv.wait_for(lk, std::chrono::seconds(120), [&] { return pp->generation != gen || pp->broken.load(); });
+    if (!ok || pp->broken.load()) { pp->broken.store(true); return STAN_E_COMM; }
+    return STAN_OK;
+}
+
+// ---- called from the CG (cg.hip) on a rank context --------------------------------------------------
+
+// stream-ordered wait until counter `c` has reached `want` arrivals (cumulative over its uses)
+static int p2p_wait(stan_ctx *ctx, unsigned long long *c, unsigned long long want) {
+    stan_p2p *pp = ctx->p2p;
+    if (pp->broken.load()) { ctx->err = "peer-to-peer exchange: a peer rank failed"; return STAN_E_COMM; }
+    if (pp->wait_mode == 0) HIPCHK(ctx, hipStreamWaitValue64(ctx->stream, c, want, hipStreamWaitValueGte, ~0ULL));
+    else hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(64), 0, ctx->stream, (const unsigned long long *)c, want);
+    return STAN_OK;
+}
+
+// the slot the NEXT reduction of this rank uses (cg.hip passes it to the producing kernel), and the wait
+// for it; every rank makes the same sequence of calls
+int stan_p2p_reduce_slot(stan_ctx *ctx) { return (int)(ctx->p2p->rk[(size_t)ctx->rank].red_calls % STAN_P2P_RING); }
+int stan_p2p_reduce_wait(stan_ctx *ctx) {
+    stan_p2p::rank_res &me = ctx->p2p->rk[(size_t)ctx->rank];
+    const int slot = (int)(me.red_calls++ % STAN_P2P_RING);
+    me.red_expect[slot] += (unsigned long long)ctx->p2p->n;   // every rank counts once per reduction
+    return p2p_wait(ctx, me.sig_red[slot], me.red_expect[slot]);
+}
+const stan_p2p_dev *stan_p2p_table(stan_ctx *ctx) { return ctx->p2p->rk[(size_t)ctx->rank].d_dev; }
+const double *stan_p2p_mailbox(stan_ctx *ctx, int slot) {
+    return ctx->p2p->rk[(size_t)ctx->rank].mbox + (size_t)slot * ctx->p2p->n * 4;
+}
+
+// what my neighbours need to know before they write into my vectors; host barrier behind it
+int stan_p2p_publish_vectors(stan_ctx *ctx, const stan_matrix *K, double *const vec[5]) {
+    stan_p2p *pp = ctx->p2p;
+    stan_p2p::rank_res &me = pp->rk[(size_t)ctx->rank];
+    if ((int)K->nbr.size() >= STAN_P2P_MAXR) { ctx->err = "peer-to-peer halo: too many neighbour ranks"; return STAN_E_UNSUPPORTED; }
+    for (int i = 0; i < 5; i++) me.vec[i] = vec[i];
+    me.nloc = K->nloc;
+    me.nbr = K->nbr;
+    me.recv_off = K->recv_off;
+    const int rc = stan_p2p_barrier(pp);
+    if (rc != STAN_OK) ctx->err = "peer-to-peer exchange: a peer rank failed or never arrived";
+    return rc;
+}
+
+// owned boundary rows of d_vec (one of the five published vectors) into the neighbours' halo regions,
+// then wait until my own halo has been filled by all of mine
+int stan_p2p_halo_exchange(stan_ctx *ctx, stan_matrix *K, double *d_vec) {
+    stan_p2p *pp = ctx->p2p;
+    stan_p2p::rank_res &me = pp->rk[(size_t)ctx->rank];
+    if (K->nbr.empty()) return STAN_OK;
+    int id = -1;
+    for (int i = 0; i < 5; i++) if (me.vec[i] == d_vec) id = i;
+    if (id < 0) { ctx->err = "peer-to-peer halo: vector was not published"; return STAN_E_ARG; }
+    const int64_t h = me.halo_calls++;
+    const int slot = (int)(h % STAN_P2P_RING);
+    pack_args a{};
+    a.stot = K->send_off.back();
+    a.rows = K->d_send_rows;
+    a.vec = d_vec;
+    a.n_nbr = (int)K->nbr.size();
+    a.tick = me.d_tick;
+    int n_in = 0;
+    for (size_t i = 0; i < K->nbr.size(); i++) {
+        const int q = K->nbr[i];
+        const stan_p2p::rank_res &pq = pp->rk[(size_t)q];
+        a.send_off[i] = K->send_off[i];
+        // my segment in q's halo region: q lists me as its j-th neighbour
+        int64_t off = -1;
+        for (size_t j = 0; j < pq.nbr.size(); j++) if (pq.nbr[j] == ctx->rank) off = pq.recv_off[j];
+        const int64_t ns = K->send_off[i + 1] - K->send_off[i];
+        if (ns > 0 && off < 0) { ctx->err = "peer-to-peer halo: neighbour lists are not symmetric"; return STAN_E_COMM; }
+        a.dst[i] = ns > 0 ? pq.vec[id] + 3 * (pq.nloc + off) : nullptr;
+        a.sig[i] = ns > 0 ? pq.sig_halo[slot] : nullptr;
+        if (K->recv_off[i + 1] - K->recv_off[i] > 0) n_in++;
+    }
+    a.send_off[K->nbr.size()] = K->send_off.back();
+    if (a.stot > 0) {
+        int64_t b = (3 * a.stot + 255) / 256;
+        if (b > 1024) b = 1024;
+        hipLaunchKernelGGL(k_pack_p2p, dim3((unsigned)b), dim3(256), 0, ctx->stream, a);
+    }
+    if (n_in > 0) {   // every neighbour that sends to me counts once per exchange
+        me.halo_expect[slot] += (unsigned long long)n_in;
+        STANCHK(p2p_wait(ctx, me.sig_halo[slot], me.halo_expect[slot]));
+    }
+    return STAN_OK;
+}

@@ -1,19 +1,26 @@
 // placement.hip -- where a big device block lands physically decides how fast it streams.
 //
-// Measured on MI355X (tools/placement_probe*.py): the SAME SpMV over the SAME 6.4 GB matrix takes
-// 1.02 ms from one hipMalloc'ed block and 1.15 ms from the next one, steadily, for the life of the
-// block; moving the data inside a block (offsets of 256 B ... 4 MB) changes nothing, and asking
-// for a physically contiguous block (hipExtMallocWithFlags, hipDeviceMallocContiguous) does not
-// remove the lottery either, nor does rounding the sizes to 2 MB (all tried with lab hooks that are
+// Measured on MI355X (tools/placement_probe*.py, profiles/r02/PLACEMENT.md): the SAME SpMV over the
+// SAME 6.4 GB matrix takes 1.02 ms from one hipMalloc'ed block and 1.15 ms from the next one, steadily,
+// for the life of the block; moving the data inside a block (offsets of 256 B ... 4 MB) changes nothing,
+// and asking for a physically contiguous block (hipExtMallocWithFlags, hipDeviceMallocContiguous) does
+// not remove the lottery either, nor does rounding the sizes to 2 MB (all tried with lab hooks that are
 // no longer in the tree).  For a given sequence of allocations the outcome repeats from process to
-// process: it is a property of the addresses the allocator hands out.  The column array's placement
-// does not matter (eight fresh copies of cols under one value array: 1.112-1.121 ms).
-// So the value stream of K may be allocated by trial: up to STAN_OPT_PLACEMENT_TRIES blocks are
-// allocated side by side, the SpMV itself is timed on each (the column indices exist by then; the
-// values are whatever the block holds, only the addresses matter), the fastest is kept and the
-// others are freed.  (A plain front-to-back read of the block, k_probe below, tells the bad blocks
-// from the rest but does not rank the rest: tools/placement_probe3.py.)  Off by default (1 try): the search costs `tries` allocations once per context
-// and size -- the block pool keeps the chosen block for the following assemblies.
+// process: it is a property of the addresses the allocator hands out -- more precisely (round 2) of the
+// PAIR (value block, vector blocks): the sweep is ~8 % slower exactly when the matrix stream and the
+// vectors it gathers from / writes to lie in the same group of device memory.  The column array's
+// placement does not matter (eight fresh copies of cols under one value array: 1.112-1.121 ms).
+// So the value stream of K is allocated by SEARCH (stan_dmalloc_streamed below; ON by default:
+// STAN_OPT_PLACEMENT_TRIES = 16 candidates at most, bench.py asks for 32, 1 = plain allocation): the
+// SpMV itself is timed on each candidate (the column indices exist by then; the values are whatever
+// the block holds, only the addresses matter) with the context's own vectors and with vectors carved
+// out of the candidate; the first candidate that is 3 % faster than its own reference is kept.
+// Candidates that are not clear stay allocated while the search goes on, within a BYTE BUDGET
+// (STAN_OPT_PLACEMENT_MAX_BYTES, default a quarter of the free device memory when the search starts)
+// and above a free-memory floor of four block sizes.  (A plain front-to-back read of the block,
+// k_probe below, tells the bad blocks from the rest but does not rank the rest:
+// tools/placement_probe3.py.)  Costs ~10 ms per candidate once per context and size -- the block pool
+// keeps the chosen block for the following assemblies.
 #include <cstdlib>
 #include <functional>
 
@@ -80,7 +87,9 @@ int stan_probe_block(stan_ctx *ctx, const void *p, size_t bytes, float *ms_out) 
 // A candidate whose real pairing is 3 % faster than its own reference is clear of the vectors'
 // group and is taken at once -- usually the first or second; otherwise it STAYS allocated, so that
 // the allocator has to move on to other memory, and the next one is tried, up to `tries`
-// candidates or a free-memory floor of four block sizes; then the fastest real pairing is kept.
+// candidates, the byte budget of held candidates (ctx->placement_max_bytes; 0 = a quarter of the free
+// memory at the start of the search) or a free-memory floor of four block sizes; then the fastest real
+// pairing is kept.
 // A hipMalloc of 6.4 GB takes 0.3 ms and a probe four launches: ~10 ms per candidate at 148^3,
 // once per context and size (the pool keeps the winner).
 int stan_dmalloc_streamed(stan_ctx *ctx, void **p, size_t bytes,
@@ -94,9 +103,17 @@ int stan_dmalloc_streamed(stan_ctx *ctx, void **p, size_t bytes,
     std::vector<float> ms;
     float worst = 0;
     bool clear = false;
+    // this library lives inside a foreign host process: the candidates held during the search never
+    // add up to more than the budget (the first candidate is always allowed: it is the allocation itself)
+    size_t budget = (size_t)ctx->placement_max_bytes;
+    {
+        size_t free0 = 0, total0 = 0;
+        if (budget == 0 && hipMemGetInfo(&free0, &total0) == hipSuccess) budget = free0 / 4;
+    }
     for (int i = 0; i < tries && !clear; i++) {
         size_t free_b = 0, total_b = 0;
         if (i > 0 && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 4 * bytes)) break;
+        if (i > 0 && budget > 0 && (cand.size() + 1) * bytes > budget) break;
         // (Groups come in runs of up to 150 GB of consecutive allocations: one box needed 24 candidates.
         // Longer strides -- spacers of 1, 2, 4 ... block sizes in front of the next candidate -- were
         // tried and dropped: a hipMalloc / hipFree of 50-200 GB takes seconds on this stack, 24 blocks
@@ -111,7 +128,7 @@ int stan_dmalloc_streamed(stan_ctx *ctx, void **p, size_t bytes,
         ms.push_back(t);
         if (t_self > worst) worst = t_self;
         if (t > worst) worst = t;
-        clear = t <= 0.97f * t_self;
+        clear = t_self > 0 && t <= 0.97f * t_self;   // t_self == 0: the candidate is too small to hold its own reference
 #ifdef STAN_LAB   // exercise the long-run path on any box: the first N candidates count as not clear
         if (const char *fm = getenv("STAN_LAB_PLACEMENT_FORCE_MISSES")) clear = clear && i >= atoi(fm);
 #endif
@@ -132,7 +149,7 @@ int stan_dmalloc_streamed(stan_ctx *ctx, void **p, size_t bytes,
         if (rc == STAN_OK && saved.p) {
             rc = probe(cand[ibest], &t_new, false);
             if (rc == STAN_OK) rc = probe(cand[ibest], &t_self, true);
-            const bool better = rc == STAN_OK && t_new <= 0.97f * t_self && t_new < ms[ibest];
+            const bool better = rc == STAN_OK && t_self > 0 && t_new <= 0.97f * t_self && t_new < ms[ibest];
             stan_cg_workspace_move(ctx, nullptr, better, &saved);
             if (better) { ms[ibest] = t_new; ctx->prof_placement_moved_vectors = 1; }
         }

@@ -28,6 +28,8 @@ OPT_VEC_STORE_NT = 12
 OPT_PACKED_COLUMNS = 13
 OPT_CG_DEFER_X = 14
 OPT_SPMV_SMALL = 15
+OPT_PLACEMENT_MAX_BYTES = 16
+OPT_SELL_SIGMA = 17
 E_HIP, E_ARG, E_ALLOC, E_DETJ, E_DOF_LAYOUT, E_VALENCE, E_COMM, E_UNSUPPORTED = (
     -1, -2, -3, -4, -5, -6, -7, -8)
 
@@ -49,7 +51,8 @@ class MatrixInfo(C.Structure):
     _fields_ = [("n_dof", C.c_int64), ("n_reduced", C.c_int64), ("n_block_rows", C.c_int64),
                 ("row_begin", C.c_int64), ("row_end", C.c_int64), ("n_halo", C.c_int64),
                 ("n_blocks", C.c_int64), ("n_slots", C.c_int64), ("bytes_matrix", C.c_int64),
-                ("scaled", C.c_int32), ("max_row_blocks", C.c_int32), ("n_elements_on_device", C.c_int64)]
+                ("scaled", C.c_int32), ("max_row_blocks", C.c_int32), ("n_elements_on_device", C.c_int64),
+                ("sell_sigma", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class Profile(C.Structure):
