@@ -78,6 +78,51 @@ def cpu_baseline(n, eps, return_u=False):
     return base, base_all
 
 
+METRIC = "DOF/s (assembly+CG to 1e-8) on 10M-DOF HEX8 cube; SpMV GB/s vs HBM peak"
+
+
+class Watchdog:
+    """A multi-GPU run that stops making progress (a rank that never joins, a collective that never
+    returns) must end by itself with a line that says where: a daemon thread checks the time since the
+    last `touch`; past the bound it prints ONE JSON error line and leaves with os._exit(3) -- the process is
+    never re-executed, a GPU process must not be.  Rank r waits 3 r seconds longer, so that rank 0 (whose
+    exit makes the launcher end the others) reports first when every rank is stuck."""
+
+    def __init__(self, bound_s, rank, world, args):
+        import threading
+        self.bound, self.rank, self.world, self.args = float(bound_s), rank, world, args
+        self.phase, self.t_last, self.steps_done = "start", time.time(), 0
+        self.enabled = bound_s > 0
+        if self.enabled:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def touch(self, phase, step_done=False):
+        self.phase, self.t_last = phase, time.time()
+        if step_done:
+            self.steps_done += 1
+
+    def stop(self):
+        self.enabled = False
+
+    def _run(self):
+        while self.enabled:
+            time.sleep(0.5)
+            idle = time.time() - self.t_last
+            if self.enabled and idle > self.bound + 3.0 * self.rank:
+                line = {"metric": METRIC, "value": None, "unit": "DOF/s", "n_gpus": self.world,
+                        "steps": self.args.steps, "warmup": self.args.warmup, "ms_per_step": None,
+                        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                        "error": "watchdog: rank %d made no progress for %.0f s in phase '%s' after %d completed "
+                                 "step(s); exiting (code 3)" % (self.rank, idle, self.phase, self.steps_done),
+                        "watchdog": {"rank": self.rank, "phase": self.phase, "idle_s": idle,
+                                     "bound_s": self.bound, "steps_done": self.steps_done}}
+                try:
+                    sys.stdout.write(json.dumps(line) + "\n")
+                    sys.stdout.flush()
+                finally:
+                    os._exit(3)
+
+
 def ensure_built():
     """The native libraries normally arrive prebuilt in the tree; from a bare checkout local rank 0
     compiles them (hipcc, ~2 min) while the other ranks wait for the files.  No fallback: without
@@ -115,21 +160,30 @@ def main():
                     help="LinSolverIterMax; a capped run reports per-iteration timings only (value null)")
     ap.add_argument("--single-reduce", action="store_true",
                     help="STAN_OPT_CG_SINGLE_REDUCE: Chronopoulos-Gear loop (not the oracle's recurrences)")
-    ap.add_argument("--cpu-n", type=int, default=56, help="cube edge of the CPU-baseline sample")
+    ap.add_argument("--cpu-n", type=int, default=56,
+                    help="cube edge of the CPU-baseline sample (56: ~20 s of CPU work; 100 = BASELINE config 2's size, "
+                         "~2 min; 148 = the bench workload itself, ~8 min and ~60 GB: profiles/r03/cpu_sizes_n148_*.jsonl)")
+    ap.add_argument("--sell-sigma", type=int, default=0,
+                    help="STAN_OPT_SELL_SIGMA: sorting window of the matrix layout in slices (0 = library default 32, 1 = off)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--placement-tries", type=int, default=32,
-                    help="STAN_OPT_PLACEMENT_TRIES: allocate the value array of K by trial in the first "
-                         "(warm-up) assembly; 1 = plain allocation (the library default)")
+                    help="STAN_OPT_PLACEMENT_TRIES: candidates the allocation-by-search of K's value array may time in "
+                         "the first (warm-up) assembly (library default 16; 1 = plain allocation)")
+    ap.add_argument("--watchdog", type=float, default=900.0,
+                    help="seconds without progress (set-up, a warm-up step, a timed step) after which the run prints a "
+                         "JSON error line and exits with code 3 (0 = off)")
     args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
 
     import numpy as np
     import torch
     import torch.distributed as dist
     from stan_amd import hip, problem
+    # armed after the imports: the first `import torch` on a fresh box pages the image in for a minute or two
+    dog = Watchdog(args.watchdog, rank, world, args)
 
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # STAN_BENCH_BACKEND / STAN_BENCH_DEVICE: test hooks (tests/test_gpu_sharded.py runs this
@@ -139,6 +193,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     ctl = dev if backend == "nccl" else torch.device("cpu")   # where control-plane tensors live
+    dog.touch("process group")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -147,7 +202,9 @@ def main():
             dist.init_process_group(backend)
 
     # ---- synthetic job (host: mesh, Database.AssignDOF, BC tables; outside the timed region)
+    dog.touch("host set-up (mesh, AssignDOF, BC tables)")
     job = problem.cube_job(args.n, etype=args.etype)
+    dog.touch("context + communicator")
     ctx = hip.Context(dev_index)
     if world > 1:
         uid = torch.zeros(128, dtype=torch.uint8, device=ctl)
@@ -159,7 +216,10 @@ def main():
     ctx.set_option(hip.OPT_PLACEMENT_TRIES, max(1, min(64, args.placement_tries)))
     if args.single_reduce:
         ctx.set_option(hip.OPT_CG_SINGLE_REDUCE, 1)
+    if args.sell_sigma > 0:
+        ctx.set_option(hip.OPT_SELL_SIGMA, args.sell_sigma)
     ctx.set_profiling(True)
+    comm = ctx.comm_info()   # which transport the sharded loop runs over (a SCALE line should say)
 
     # inputs resident in HBM before the timed region; a rank of a sharded run holds only the elements
     # that touch its rows (the node arrays stay whole: any node may be a halo column)
@@ -194,24 +254,49 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # STAN_BENCH_TEST_HANG_RANK: test hook (tests/test_gpu_sharded.py): that rank never starts its steps
+    if os.environ.get("STAN_BENCH_TEST_HANG_RANK", "") == str(rank):
+        dog.stop()
+        time.sleep(3600)
+    for i in range(args.warmup):
+        dog.touch("warm-up step %d" % (i + 1))
         step()
+    dog.touch("barrier before the timed steps")
     sync()
     t0 = time.perf_counter()
     spmv_ms = spmv_n = 0.0
+    spmv2_ms = spmv2_n = 0.0
     asm_ms = cg_ms = 0.0
-    for _ in range(args.steps):
+    red_ms = red_n = halo_ms = halo_n = 0.0
+    for i in range(args.steps):
+        dog.touch("timed step %d" % (i + 1))
         rep, prof, info = step()
+        dog.touch("timed step %d done" % (i + 1), step_done=True)
+        red_ms += prof["comm_reduce_ms_total"]; red_n += prof["comm_reduce_calls"]
+        halo_ms += prof["comm_halo_ms_total"]; halo_n += prof["comm_halo_calls"]
         spmv_ms += prof["spmv_ms_total"]
         spmv_n += prof["spmv_launches"]
+        spmv2_ms += prof["spmv2_ms_total"]
+        spmv2_n += prof["spmv2_launches"]
         asm_ms += prof["assemble_ms"]
         cg_ms += prof["cg_ms"]
+    dog.touch("barrier after the timed steps")
     sync()
     dt = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # what every rank measured on its own shard: SpMV rate against ITS bytes, exchange times per call
+        mine = torch.tensor([prof["spmv_bytes"] / (spmv_ms / max(spmv_n, 1) * 1e-3) / 1e9 if spmv_ms > 0 else 0.0,
+                             spmv_ms / max(spmv_n, 1), red_ms / max(red_n, 1) * 1e3, halo_ms / max(halo_n, 1) * 1e3,
+                             float(info["n_halo"]), float(info["row_end"] - info["row_begin"])],
+                            dtype=torch.float64, device=ctl)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[float(v) for v in a.cpu().tolist()] for a in allr]
+    dog.touch("report")
 
     # sanity of the timed work (rank 0): converged to eps, true residual through an
     # independent product is checked in tests; here the solver's own report
@@ -254,7 +339,7 @@ def main():
             # the same product priced as scalar CSR (fp64 values, int32 columns): 12 nnz + 20 N
             csr_equiv = (12 * 9 * blocks_red + 20 * job.n_red) / (avg_ms * 1e-3) / 1e9
         out = {
-            "metric": "DOF/s (assembly+CG to 1e-8) on 10M-DOF HEX8 cube; SpMV GB/s vs HBM peak",
+            "metric": METRIC,
             "value": job.n_dof * args.steps / dt,
             "unit": "DOF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -284,7 +369,14 @@ def main():
                                         "per-slot base in %.1f %% of the slots, int32 in the rest)" %
                                         ("fp32" if args.mixed else "48-bit fixed-point" if args.fixed48
                                          else "fp64", 100.0 * prof["col_slots_packed"] / max(info["n_slots"], 1)),
+                       # SELL-C-sigma: slots streamed per structural block - 1 (padded slots are streamed like real ones)
+                       "ell_padding": info["n_slots"] * 64.0 / max(info["n_blocks"], 1) - 1.0,
+                       "sell_sigma": info["sell_sigma"],
                        "parallelism": "rows sharded x%d" % world,
+                       "transport": ("one rank" if world == 1 else
+                                     "RCCL %s (ncclGetVersion %d), communicator of %d ranks, this = rank %d%s" %
+                                     ("" if comm["rccl_version"] else "stand-in", comm["rccl_version"],
+                                      comm["comm_ranks"], comm["comm_rank"], ", peer to peer" if comm["p2p"] else "")),
                        "elements_on_rank0": int(conn.shape[0]),
                        # the block pool keeps K's arrays between steps; with tries > 1 the first
                        # assembly picks the fastest-streaming of several hipMalloc blocks
@@ -313,11 +405,21 @@ def main():
                          "bytes_per_launch": prof["spmv_bytes"], "avg_launch_ms": avg_ms,
                          "launches": int(spmv_n),
                          # refresh iterations: A p and A x from one matrix pass (not in the average)
-                         "two_product_launches": int(prof["spmv2_launches"]),
-                         "two_product_avg_ms": (prof["spmv2_ms_total"] / prof["spmv2_launches"]
-                                                if prof["spmv2_launches"] else None)},
+                         "two_product_launches": int(spmv2_n),
+                         "two_product_avg_ms": (spmv2_ms / spmv2_n if spmv2_n else None)},
         }
+        if per_rank is not None:
+            fr = [p[0] / HBM_PEAK_GBS for p in per_rank]
+            out["roofline"]["per_rank"] = {"frac_min": min(fr), "frac_max": max(fr), "frac": fr,
+                                           "avg_launch_ms": [p[1] for p in per_rank]}
+            # stream time per exchange (events around each, profiling only): RCCL launch -> sums available
+            out["config"]["exchange"] = {"allreduce_us_per_call": [p[2] for p in per_rank],
+                                         "halo_us_per_call": [p[3] for p in per_rank],
+                                         "allreduces_per_step": red_n / args.steps, "halo_exchanges_per_step": halo_n / args.steps,
+                                         "halo_block_rows": [int(p[4]) for p in per_rank],
+                                         "owned_block_rows": [int(p[5]) for p in per_rank]}
         if not args.no_cpu and world == 1:
+            dog.stop()   # the CPU sample is bounded by its size, not by the watchdog
             base, base_all = cpu_baseline(args.cpu_n, args.eps)
             out["cpu_baseline"] = base
             out["cpu_baseline_all_cores"] = base_all
@@ -327,7 +429,9 @@ def main():
             out["value"] = None
             out["error"] = "CG ended with type %d at %.3e (> eps %.0e): no DOF/s reported" % (
                 rep["terminationtype"], rep["rel_residual"], args.eps)
+        dog.touch("cpu baseline done")
         print(json.dumps(out), flush=True)
+    dog.stop()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -155,6 +155,15 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
                            slices: <= 1.5 %.  The permutation is internal: vectors, CRS export, halo plan and the row
                            partition keep the reference (AssignDOF) order, every row sum keeps its bits (the order of
                            the dot-product partial sums changes with it).  1 = off; 1..32; applies to the next assembly. */
+#define STAN_OPT_COMM_P2P 18 /* one-process multi-device handle only (stan_hip_init_multi).  0 (default): the sharded CG
+                           exchanges over RCCL (2 all-reduce launches + 1 grouped send/recv per iteration).  1: peer to
+                           peer -- no collective launch in the loop: the block that finishes a reduction stores this
+                           rank's partial sums into every rank's mailbox and counts itself into every rank's arrival
+                           counter; the consumer's STREAM waits for the count (hipStreamWaitValue64) and the consuming
+                           kernel adds the partials in rank order (identical bits on every rank, and the bits of a
+                           rank-ordered all-reduce); boundary rows are written straight into the neighbours' gather
+                           vectors.  Needs peer access between all devices of the handle (STAN_E_UNSUPPORTED
+                           otherwise; also on a handle with more than 16 ranks). */
 #define STAN_OPT_POOL 7 /* 1 (default): device blocks >= 8 MB freed by the library stay with the
                            context and are reused by its next allocations (a hipMalloc of tens of GB
                            costs 0.4-1.8 s here); 0: release them now, plain hipMalloc/hipFree from then on */
@@ -177,6 +186,11 @@ int stan_hip_comm_unique_id(char id[128]);
  * work, anything that needs a collective returns STAN_E_COMM (used by the tests to check
  * every rank's shard on one GPU).  nranks == 1 with an id creates a real 1-rank communicator. */
 int stan_hip_comm_init(stan_ctx *ctx, int rank, int nranks, const char id[128]);
+
+/* What the sharded CG of this context exchanges over: RCCL's version code (ncclGetVersion; 0 without a
+ * communicator library), the communicator's own rank count and rank (ncclCommCount / ncclCommUserRank),
+ * p2p = 1 when STAN_OPT_COMM_P2P is in effect.  Any pointer may be NULL. */
+int stan_hip_comm_info(stan_ctx *ctx, int32_t *rccl_version, int32_t *comm_ranks, int32_t *comm_rank, int32_t *p2p);
 
 /* ---- assembly: replaces ParallelAssembly_K (SolverFunctions.cs:117-180) ----------------- */
 /* xyz            [n_nodes*3]  Node.X/Y/Z in NodeLib (wire) order           Node.cs:12-14
@@ -328,6 +342,12 @@ typedef struct stan_profile {
     float placement_ms_best, placement_ms_worst; /* SpMV probe time of the kept / the slowest candidate */
     int64_t col_slots_packed;         /* ELL slots whose columns the last solve read from the packed stream */
     int32_t placement_moved_vectors;  /* 1: no candidate was clear of the vectors' group and the search re-allocated the CG's vectors instead */
+    int32_t reserved0;
+    int64_t loop_stream_waits;        /* peer-to-peer exchanges (STAN_OPT_COMM_P2P): stream waits the loop enqueued instead of collectives */
+    double comm_reduce_ms_total;      /* sharded loop: stream time between "reduction issued" and "sums available", summed   */
+    int64_t comm_reduce_calls;        /*   over this many reduction points (RCCL all-reduce launches or peer-to-peer waits)   */
+    double comm_halo_ms_total;        /* the same for the halo exchanges (pack + send/recv, or pack + peer-to-peer wait)     */
+    int64_t comm_halo_calls;
 } stan_profile;
 int stan_hip_set_profiling(stan_ctx *ctx, int32_t enabled);
 int stan_hip_get_profile(stan_ctx *ctx, stan_profile *out);

@@ -58,7 +58,11 @@ void stan_hip_destroy(stan_ctx *ctx) {
     if (!ctx) return;
     if (ctx->group) { stan_group_destroy(ctx); return; }
     hipSetDevice(ctx->device);
-    if (ctx->comm && ctx->nccl.CommDestroy) ctx->nccl.CommDestroy(ctx->comm);
+    {
+        void *comm = nullptr;
+        { std::lock_guard<std::mutex> lk(ctx->comm_mu); comm = ctx->comm; ctx->comm = nullptr; }
+        if (comm && ctx->nccl.CommDestroy) ctx->nccl.CommDestroy(comm);
+    }
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     if (ctx->side) hipStreamDestroy(ctx->side);
     if (ctx->ev_a) hipEventDestroy(ctx->ev_a);
@@ -97,8 +101,13 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream) {
 
 int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
     if (!ctx) return STAN_E_ARG;
+    if (ctx->group && option == STAN_OPT_COMM_P2P) return stan_group_set_p2p(ctx, value != 0);
     if (ctx->group)
         return stan_group_ctx_call(ctx, [&](stan_ctx *c) { return stan_hip_set_option(c, option, value); });
+    if (option == STAN_OPT_COMM_P2P) {
+        if (value != 0) { ctx->err = "STAN_OPT_COMM_P2P: only on a handle of stan_hip_init_multi (one process, several devices)"; return STAN_E_UNSUPPORTED; }
+        return STAN_OK;
+    }
     if (option == STAN_OPT_CG_MERIT_STOP) ctx->cg_merit_stop = value != 0;
     else if (option == STAN_OPT_CG_RUPDATE && value >= 0 && value < (1 << 30)) ctx->cg_rupdate = (int)value;
     else if (option == STAN_OPT_ASSEMBLY_MODE && (value == 0 || value == 1)) ctx->assembly_mode = (int)value;
@@ -146,6 +155,19 @@ int stan_hip_pool_info(stan_ctx *ctx, int64_t *bytes_parked, int64_t *blocks_par
     if (ctx->group) ctx = stan_group_rank0(ctx);
     if (bytes_parked) *bytes_parked = (int64_t)ctx->pool.bytes_avail;
     if (blocks_parked) *blocks_parked = (int64_t)ctx->pool.avail.size();
+    return STAN_OK;
+}
+
+// which transport the sharded CG of this context will use (bench.py prints it next to a multi-GPU line)
+int stan_hip_comm_info(stan_ctx *ctx, int32_t *rccl_version, int32_t *comm_ranks, int32_t *comm_rank, int32_t *p2p) {
+    if (!ctx) return STAN_E_ARG;
+    stan_ctx *c = ctx->group ? stan_group_rank0(ctx) : ctx;
+    int v = 0, n = 0, r = 0;
+    stan_comm_info(c, &v, &n, &r);
+    if (rccl_version) *rccl_version = v;
+    if (comm_ranks) *comm_ranks = n;
+    if (comm_rank) *comm_rank = r;
+    if (p2p) *p2p = (c->p2p && c->comm_p2p) ? 1 : 0;
     return STAN_OK;
 }
 
@@ -298,6 +320,19 @@ int stan_hip_cg_solve(stan_ctx *ctx, stan_matrix *K, const double *F, double eps
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t N = (size_t)K->n_red;
     dbuf<double> dF, dU;
+    if (ctx->result_segment && ctx->nranks > 1) {
+        // a rank of a one-process group: only ITS entries [u0, u1) of F go up and of U come down -- the ranks
+        // share the caller's buffers (disjoint ranges), nothing is gathered on the devices (multi.hip)
+        const size_t u0 = (size_t)K->u0, nu = (size_t)(K->u1 - K->u0);
+        STANCHK(dF.alloc(ctx, N ? N : 1));
+        STANCHK(dU.alloc(ctx, N ? N : 1));
+        if (nu) HIPCHK(ctx, hipMemcpyAsync(dF.p + u0, F + u0, nu * 8, hipMemcpyHostToDevice, ctx->stream));
+        STANCHK(stan_cg_device(ctx, K, dF.p, eps_f, max_its, precision_mode, dU.p, termination_type,
+                               iterations, rel_residual));
+        if (nu) HIPCHK(ctx, hipMemcpyAsync(U + u0, dU.p + u0, nu * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return STAN_OK;
+    }
     STANCHK(dF.upload(ctx, F, N));
     STANCHK(dU.alloc(ctx, N));
     HIPCHK(ctx, hipMemsetAsync(dU.p, 0, (N ? N : 1) * 8, ctx->stream));
@@ -363,7 +398,11 @@ int stan_hip_nodal_forces_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz
     if (!ctx || !xyz || !disp || !node_dof || !mat_E_nu || n_nodes <= 0 || n_mat <= 0 || n_elem < 0 ||
         n_dof != n_nodes * 3 || (!elem_forces && !R) || (n_elem > 0 && (!conn || !elem_mat || !elem_type)))
         return STAN_E_ARG;
-    if (ctx->group) ctx = stan_group_rank0(ctx);   // R is an all-element sum: one device
+    if (ctx->group)   // R is an all-element sum: one device (rank 0); its error text follows the handle
+        return stan_group_rank0_call(ctx, [&](stan_ctx *c) {
+            return stan_hip_nodal_forces_hex8(c, n_nodes, xyz, disp, node_dof, n_elem, conn, elem_mat, elem_type, n_mat,
+                                              mat_E_nu, n_dof, elem_forces, R);
+        });
     HIPCHK(ctx, hipSetDevice(ctx->device));
     for (int64_t e = 0; e < n_elem; e++) {
         if (elem_mat[e] < 0 || elem_mat[e] >= n_mat) { ctx->err = "nodal_forces_hex8: elem_mat out of range"; return STAN_E_ARG; }
@@ -410,7 +449,8 @@ int stan_hip_matrix_info(stan_matrix *K, stan_matrix_info *o) {
 int stan_hip_ke_hex8_batch(stan_ctx *ctx, int64_t n, const double *xyz8, double E, double nu,
                            const uint8_t *type, double *out) {
     if (!ctx || n < 0 || (n > 0 && (!xyz8 || !type || !out))) return STAN_E_ARG;
-    if (ctx->group) ctx = stan_group_rank0(ctx);
+    if (ctx->group)
+        return stan_group_rank0_call(ctx, [&](stan_ctx *c) { return stan_hip_ke_hex8_batch(c, n, xyz8, E, nu, type, out); });
     HIPCHK(ctx, hipSetDevice(ctx->device));
     for (int64_t e = 0; e < n; e++)
         if (type[e] != STAN_HEX8_G1 && type[e] != STAN_HEX8_G2) {

@@ -51,6 +51,7 @@ namespace {
 constexpr int VEC_BLOCKS = 2048;  // grid of the streaming vector kernels (8 blocks per CU)
 constexpr int VEC_T = 256;
 constexpr int CHUNK = 32;         // iterations enqueued between two status polls
+constexpr int CHUNK_DIST = 8;     // ... of a sharded loop
 
 // device scalar slots (double)
 enum { S_BNORM = 0, S_VMV = 1, S_R2NEW = 2, S_MERIT = 3, S_RHO0 = 4, S_RHO1 = 5, S_PMF0 = 6,
@@ -177,6 +178,13 @@ __device__ __forceinline__ void fold_finish(const fold_args &f, const double *pa
     // every ticket of this launch has been drawn: clear the set for the next one
     if (threadIdx.x <= FOLD_SUB)
         __hip_atomic_store(f.counter + threadIdx.x * FOLD_LINE, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// A producing kernel that returns without doing its work (the solve has stopped; every rank takes the same
+// decision) still owes its peers the arrival count of its reduction: their streams wait for it.
+__device__ __forceinline__ void fold_skip(const fold_args &f) {
+    if (f.counter && f.po.pp && f.po.signal && blockIdx.x == 0 && (int)threadIdx.x < f.po.pp->n)
+        __hip_atomic_fetch_add(f.po.pp->sig_red[threadIdx.x][f.po.slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __device__ __forceinline__ bool stopped(const int64_t *st, int64_t k) {
@@ -446,7 +454,7 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, cons
        int32_t poff, fold_args fold, colstream cs) {
     __shared__ double sh[4];
     __shared__ int sh_last;
-    if (stopped(st, kiter)) return;
+    if (stopped(st, kiter)) { fold_skip(fold); return; }
     constexpr bool NT = ((VAR & 1) != 0 && VAR < 8) || (VAR >= 9 && VAR != 13);  // 13 = 9 without the hint; 14-16 lab
     constexpr bool XCD = (VAR & 2) != 0 && VAR < 8;
     constexpr int UNR = (((VAR & 4) != 0 && VAR < 8) || VAR == 12) ? 4 : 2;
@@ -554,7 +562,7 @@ k_spmv_small(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr
     __shared__ double sh[4];
     __shared__ int sh_last;
     __shared__ double acc[3][4][64];
-    if (stopped(st, kiter)) return;
+    if (stopped(st, kiter)) { fold_skip(fold); return; }
     constexpr bool NT = false;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int64_t slice = blockIdx.x;
@@ -617,7 +625,7 @@ k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, con
         const int32_t *__restrict__ slist, int32_t nlist, int32_t poff, fold_args fold, colstream cs) {
     __shared__ double sh[4];
     __shared__ int sh_last;
-    if (stopped(st, kiter)) return;
+    if (stopped(st, kiter)) { fold_skip(fold); return; }
     const int lane = threadIdx.x & 63;
     int64_t bid = blockIdx.x;
     {   // XCD-chunked workgroup mapping, as in k_spmv (variant 9)
@@ -725,7 +733,7 @@ template <bool RNT>
 __global__ void __launch_bounds__(VEC_T) k_step(step_args a) {
     __shared__ double sh[4];
     __shared__ int sh_last;
-    if (stopped(a.st, a.k)) return;
+    if (stopped(a.st, a.k)) { if (a.refresh != 1) fold_skip(a.fold); return; }
     double vmv_[1];
     red_get<1>(a.sc + S_VMV, a.rs_vmv, vmv_, sh);
     const double vmv = vmv_[0];
@@ -741,6 +749,7 @@ __global__ void __launch_bounds__(VEC_T) k_step(step_args a) {
             a.st[T_XSEL] = (a.k - 1) & 1;  // rx of the previous iteration
             a.st[T_ITER_B] = a.k;
         }
+        if (a.refresh != 1) fold_skip(a.fold);
         return;
     }
     double s_r2 = 0, s_mf = 0;
@@ -795,7 +804,7 @@ k_refresh(int64_t n3, int64_t k, const int64_t *st, const double *bh, const doub
           const double *cx, double *r, double *partial, fold_args fold) {
     __shared__ double sh[4];
     __shared__ int sh_last;
-    if (st[T_ITER_A] < k || st[T_ITER_B] <= k) return;
+    if (st[T_ITER_A] < k || st[T_ITER_B] <= k) { fold_skip(fold); return; }
     double s_r2 = 0, s_mf = 0;
     const int64_t stride = (int64_t)gridDim.x * VEC_T;
     for (int64_t i = (int64_t)blockIdx.x * VEC_T + threadIdx.x; i < n3; i += stride) {
@@ -1551,13 +1560,18 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     HIPCHK(ctx, hipMemcpyAsync(h_st, stt, T_NSTAT * 8, hipMemcpyDeviceToHost, st_));
     HIPCHK(ctx, hipStreamSynchronize(st_));
     if (h_st[T_ITER_A] == 0) done = true;
+    red_src rs_sr{nullptr, 0}, rs_vmv{nullptr, 0}, rs_r2{nullptr, 0};
     if (sr && !done) {   // w_0 = A r_0 with gamma_0, delta_0 (merit_0 = 0 sits in the zeroed scalars)
-        rc = spmv(r, w, 2, sc + S_SR_GAMMA, 0);
-        if (rc == STAN_OK && dist) { rc = stan_comm_allreduce_sum_f64(ctx, sc + S_SR_GAMMA, 3); n_coll++; }
+        if (p2p)         // ... or, peer to peer, is sent as this rank's zero into the slot of the first reduction
+            hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, 0, sc + S_SR_MERIT, p2p_to(2, false));
+        rc = spmv(r, w, 2, sc + S_SR_GAMMA, 0, p2p_to(0, true));
+        if (rc == STAN_OK) rc = exchange_sums(sc + S_SR_GAMMA, 3, &rs_sr);
     }
+    // a sharded loop polls more often: what runs ahead of the stop are exchanges nobody can cut short
+    const int chunk = dist ? CHUNK_DIST : CHUNK;
     while (!done && rc == STAN_OK) {
         // enqueue one chunk of iterations
-        for (int c = 0; c < CHUNK && k < hard_cap; c++, k++) {
+        for (int c = 0; c < chunk && k < hard_cap; c++, k++) {
             const bool refresh = ctx->cg_rupdate > 0 && (k % ctx->cg_rupdate) == 0;
             if (sr) {
                 sr_args a;
@@ -1566,28 +1580,35 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
                 a.refresh = refresh ? 1 : 0;
                 a.xcur = xb[(k - 1) & 1]; a.xnext = xb[k & 1];
                 a.r = r; a.p = p; a.s = sv; a.w = w; a.bh = bh; a.partial = partial;
-                a.fold = vec_fold(sc + S_SR_MERIT);
+                a.rs = rs_sr;
+                // the merit sum rides in the third column of the coming reduction's mailbox slot (no count of its own)
+                a.fold = vec_fold(sc + S_SR_MERIT, p2p_to(2, false));
                 hipLaunchKernelGGL(k_vec_sr, dim3(vg), dim3(VEC_T), 0, st_, a);
                 n_launch++;
-                if (!refresh) reduce_if_unfolded((int)vg, 1, sc + S_SR_MERIT);
+                if (!refresh) reduce_if_unfolded((int)vg, 1, sc + S_SR_MERIT, p2p_to(2, false));
                 else {   // r' = b^ - A^ x' (ALGLIB's periodic residual recomputation), then as usual
                     rc = spmv(xb[k & 1], v, 0, nullptr, k);
                     if (rc) break;
                     hipLaunchKernelGGL(k_refresh, dim3(vg), dim3(VEC_T), 0, st_, n3, k, (const int64_t *)stt,
-                                       bh, v, xb[k & 1], r, partial, vec_fold(sc + S_SR_DELTA));
+                                       bh, v, xb[k & 1], r, partial, vec_fold(sc + S_SR_DELTA, p2p_to(1, false)));
                     n_launch++;
-                    reduce_if_unfolded((int)vg, 2, sc + S_SR_DELTA);   // [r.r (rewritten below), merit]
+                    reduce_if_unfolded((int)vg, 2, sc + S_SR_DELTA, p2p_to(1, false));   // [r.r (rewritten below), merit]
                 }
-                rc = spmv(r, w, 2, sc + S_SR_GAMMA, k);
+                rc = spmv(r, w, 2, sc + S_SR_GAMMA, k, p2p_to(0, true));
                 if (rc) break;
-                if (dist) { rc = stan_comm_allreduce_sum_f64(ctx, sc + S_SR_GAMMA, 3); n_coll++; if (rc) break; }
+                rc = exchange_sums(sc + S_SR_GAMMA, 3, &rs_sr);
+                if (rc) break;
                 continue;
             }
             const bool fused = refresh && ctx->cg_fused_refresh;
-            rc = fused ? spmv2(p, xb[(k - 1) & 1], sc + S_VMV, k) : spmv(p, v, 1, sc + S_VMV, k);
+            rc = fused ? spmv2(p, xb[(k - 1) & 1], sc + S_VMV, k, p2p_to(0, true))
+                       : spmv(p, v, 1, sc + S_VMV, k, p2p_to(0, true));
             if (rc) break;
-            if (dist) { rc = stan_comm_allreduce_sum_f64(ctx, sc + S_VMV, 1); n_coll++; if (rc) break; }
+            rc = exchange_sums(sc + S_VMV, 1, &rs_vmv);
+            if (rc) break;
+            const p2p_out po_r = p2p_to(0, true);   // the slot of r.r / merit (the wait above moved on to it)
             step_args a;
+            a.rs_vmv = rs_vmv;
             a.n3 = n3; a.k = k; a.sc = sc; a.st = stt;
             a.xcur = xb[(k - 1) & 1]; a.xnext = xb[k & 1];
             a.r = r; a.p = p; a.v = v; a.w = w; a.bh = bh; a.partial = partial;
@@ -1596,7 +1617,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             // x' = x + a p moves into k_update (p is read once for both updates: -79 MB of 714 per
             // iteration at 148^3) unless the merit sum needs x' here or a literal refresh multiplies it
             a.defer_x = (ctx->cg_defer_x && !a.merit && a.refresh != 1) ? 1 : 0;
-            a.fold = vec_fold(sc + S_R2NEW);
+            a.fold = vec_fold(sc + S_R2NEW, a.refresh == 1 ? NO_P2P : po_r);   // refresh 1: k_refresh forms the sums
             if (ctx->vec_store_nt & 2) hipLaunchKernelGGL(k_step<true>, dim3(vg), dim3(VEC_T), 0, st_, a);
             else hipLaunchKernelGGL(k_step<false>, dim3(vg), dim3(VEC_T), 0, st_, a);
             n_launch++;
@@ -1605,19 +1626,20 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
                 rc = spmv(xb[k & 1], v, 0, nullptr, k);
                 if (rc) break;
                 hipLaunchKernelGGL(k_refresh, dim3(vg), dim3(VEC_T), 0, st_, n3, k,
-                                   (const int64_t *)stt, bh, v, xb[k & 1], r, partial, vec_fold(sc + S_R2NEW));
+                                   (const int64_t *)stt, bh, v, xb[k & 1], r, partial, vec_fold(sc + S_R2NEW, po_r));
                 n_launch++;
             }
-            if (!foldr) { reduce_if_unfolded((int)vg, 2, sc + S_R2NEW); n_launch++; }
-            if (dist) { rc = stan_comm_allreduce_sum_f64(ctx, sc + S_R2NEW, 2); n_coll++; if (rc) break; }
+            if (!foldr) { reduce_if_unfolded((int)vg, 2, sc + S_R2NEW, po_r); n_launch++; }
+            rc = exchange_sums(sc + S_R2NEW, 2, &rs_r2);
+            if (rc) break;
             const double *ux = a.defer_x ? a.xcur : nullptr;
             double *uxn = a.defer_x ? a.xnext : nullptr;
             if (ctx->vec_store_nt & 1)
                 hipLaunchKernelGGL(k_update<true>, dim3(vg), dim3(VEC_T), 0, st_, n3, k, sc, stt, eps_f,
-                                   (int64_t)max_its, its_before_restart, ctx->cg_merit_stop ? 1 : 0, r, p, ux, uxn);
+                                   (int64_t)max_its, its_before_restart, ctx->cg_merit_stop ? 1 : 0, r, p, ux, uxn, rs_r2, rs_vmv);
             else
                 hipLaunchKernelGGL(k_update<false>, dim3(vg), dim3(VEC_T), 0, st_, n3, k, sc, stt, eps_f,
-                                   (int64_t)max_its, its_before_restart, ctx->cg_merit_stop ? 1 : 0, r, p, ux, uxn);
+                                   (int64_t)max_its, its_before_restart, ctx->cg_merit_stop ? 1 : 0, r, p, ux, uxn, rs_r2, rs_vmv);
             n_launch++;
         }
         if (rc) break;
@@ -1631,6 +1653,10 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             if (prev[T_TYPE] != 0) done = true;
         }
         if (k >= hard_cap) done = true;
+        if (dist && (ctx->comm_broken.load() || (ctx->p2p && ctx->p2p->broken.load()))) {
+            ctx->err = "cg: a peer rank failed (the exchanges were aborted)";
+            rc = STAN_E_COMM;
+        }
         chunk_id++;
     }
     hipError_t e = hipStreamSynchronize(st_);
@@ -1645,8 +1671,9 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     if (type == 0) { type = 5; its = k - 1; h_st[T_XSEL] = (k - 1) & 1; }  // hard cap
     const double *xfin = xb[h_st[T_XSEL] & 1];
 
-    // U = S x^ on the free DOFs
-    if (!dist) {
+    // U = S x^ on the free DOFs (a rank of a one-process group leaves only ITS entries [u0, u1) of U: the
+    // group copies every rank's segment into the caller's buffer, nothing is gathered on the devices)
+    if (!dist || ctx->result_segment) {
         hipLaunchKernelGGL(k_result, dim3(vg), dim3(VEC_T), 0, st_, n3, dof0, K->d_red, K->d_scale,
                            xfin, d_U);
     } else {
@@ -1710,7 +1737,18 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         ctx->prof.cg_iteration_vector_bytes = 3 * K->nloc * 8 * ((ctx->cg_defer_x && !ctx->cg_merit_stop ? 8 : 9) + (ctx->cg_merit_stop ? 1 : 0));
         ctx->prof.loop_kernel_launches = n_launch;
         ctx->prof.loop_collectives = n_coll;
+        ctx->prof.loop_stream_waits = n_wait;
         ctx->prof.loop_iterations_enqueued = k - 1;
+        // what the stream spent in the exchanges (RCCL launches, or peer-to-peer waits): events around each
+        auto sum_pairs = [](const std::vector<hipEvent_t> &ev, double *tot, int64_t *cnt) {
+            *tot = 0; *cnt = 0;
+            for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+                float t = 0;
+                if (hipEventElapsedTime(&t, ev[i], ev[i + 1]) == hipSuccess) { *tot += t; (*cnt)++; }
+            }
+        };
+        sum_pairs(red_ev, &ctx->prof.comm_reduce_ms_total, &ctx->prof.comm_reduce_calls);
+        sum_pairs(halo_ev, &ctx->prof.comm_halo_ms_total, &ctx->prof.comm_halo_calls);
     }
     return STAN_OK;
 }

@@ -56,6 +56,9 @@ int load_rccl(stan_ctx *ctx) {
     SYM(GroupStart, "ncclGroupStart");
     SYM(GroupEnd, "ncclGroupEnd");
     SYM(GetErrorString, "ncclGetErrorString");
+    *(void **)(&n.GetVersion) = dlsym(n.handle, "ncclGetVersion");   // optional (bench.py prints it)
+    *(void **)(&n.CommCount) = dlsym(n.handle, "ncclCommCount");
+    *(void **)(&n.CommUserRank) = dlsym(n.handle, "ncclCommUserRank");
 #undef SYM
     return STAN_OK;
 }
@@ -79,9 +82,18 @@ __global__ void k_pack(int64_t n, const int32_t *rows, const double *vec, double
     }
 }
 
+// The communicator of this rank for one RCCL call.  The group's host thread may abort it while this
+// worker is between two calls (multi.hip: a peer rank failed): pointer and flag are read under the
+// context's mutex, the RCCL call itself runs outside it (an abort must be able to overtake a call that
+// blocks, as the test transport's do).
+void *comm_for_call(stan_ctx *ctx) {
+    std::lock_guard<std::mutex> lk(ctx->comm_mu);
+    return ctx->comm_broken.load() ? nullptr : ctx->comm;
+}
+
 // no communicator: fine for a single rank, an error for a detached rank of several
 int no_comm(stan_ctx *ctx) {
-    if (ctx->comm_broken) {
+    if (ctx->comm_broken.load()) {
         ctx->err = "the communicator was aborted after a peer rank failed";
         return STAN_E_COMM;
     }
@@ -102,7 +114,7 @@ extern "C" int stan_hip_comm_unique_id(char id[128]) {
 extern "C" int stan_hip_comm_init(stan_ctx *ctx, int rank, int nranks, const char id[128]) {
     if (!ctx || nranks < 1 || rank < 0 || rank >= nranks) return STAN_E_ARG;
     STAN_NO_GROUP(ctx, "comm_init (a multi-device handle builds its own communicator)");
-    if (ctx->comm) {
+    if (comm_for_call(ctx)) {
         ctx->err = "comm_init: communicator already initialised";
         return STAN_E_ARG;
     }
@@ -117,18 +129,35 @@ extern "C" int stan_hip_comm_init(stan_ctx *ctx, int rank, int nranks, const cha
     HIPCHK(ctx, hipSetDevice(ctx->device));
     nccl_uid uid;
     memcpy(uid.internal, id, 128);
-    NCCLCHK(ctx, ((fn_commInitRank)ctx->nccl.CommInitRank)(&ctx->comm, nranks, uid, rank));
+    void *comm = nullptr;
+    NCCLCHK(ctx, ((fn_commInitRank)ctx->nccl.CommInitRank)(&comm, nranks, uid, rank));
+    std::lock_guard<std::mutex> lk(ctx->comm_mu);
+    ctx->comm = comm;
     return STAN_OK;
 }
 
 int stan_comm_allreduce_sum_f64(stan_ctx *ctx, double *d_buf, size_t count) {
-    if (!ctx->comm) return no_comm(ctx);
-    NCCLCHK(ctx, ctx->nccl.AllReduce(d_buf, d_buf, count, NCCL_F64, NCCL_SUM, ctx->comm, ctx->stream));
+    void *comm = comm_for_call(ctx);
+    if (!comm) return no_comm(ctx);
+    NCCLCHK(ctx, ctx->nccl.AllReduce(d_buf, d_buf, count, NCCL_F64, NCCL_SUM, comm, ctx->stream));
+    return STAN_OK;
+}
+
+// RCCL's version code and what the communicator says about itself (bench.py prints them: a SCALE line
+// should say which transport it measured); zeros where there is no communicator / no such entry point
+int stan_comm_info(stan_ctx *ctx, int *version, int *count, int *rank) {
+    *version = *count = *rank = 0;
+    void *comm = comm_for_call(ctx);
+    if (ctx->nccl.GetVersion) ctx->nccl.GetVersion(version);
+    if (comm && ctx->nccl.CommCount) ctx->nccl.CommCount(comm, count);
+    if (comm && ctx->nccl.CommUserRank) ctx->nccl.CommUserRank(comm, rank);
     return STAN_OK;
 }
 
 int stan_comm_halo_exchange(stan_ctx *ctx, stan_matrix *K, double *d_vec) {
-    if (!ctx->comm) return no_comm(ctx);
+    if (ctx->comm_p2p && ctx->p2p) return stan_p2p_halo_exchange(ctx, K, d_vec);   // peer to peer: no RCCL call
+    void *comm = comm_for_call(ctx);
+    if (!comm) return no_comm(ctx);
     if (K->nbr.empty()) return STAN_OK;
     const int64_t stot = K->send_off.back();
     if (stot > 0) {
@@ -144,10 +173,10 @@ int stan_comm_halo_exchange(stan_ctx *ctx, stan_matrix *K, double *d_vec) {
         const int64_t nr = K->recv_off[i + 1] - K->recv_off[i];
         if (ns > 0)
             NCCLCHK(ctx, ctx->nccl.Send(K->d_sendbuf + 3 * K->send_off[i], (size_t)(3 * ns), NCCL_F64,
-                                        K->nbr[i], ctx->comm, ctx->stream));
+                                        K->nbr[i], comm, ctx->stream));
         if (nr > 0)
             NCCLCHK(ctx, ctx->nccl.Recv(halo + 3 * K->recv_off[i], (size_t)(3 * nr), NCCL_F64,
-                                        K->nbr[i], ctx->comm, ctx->stream));
+                                        K->nbr[i], comm, ctx->stream));
     }
     NCCLCHK(ctx, ctx->nccl.GroupEnd());
     return STAN_OK;
@@ -155,13 +184,14 @@ int stan_comm_halo_exchange(stan_ctx *ctx, stan_matrix *K, double *d_vec) {
 
 // every rank contributes its owned rows of a global block vector (3 doubles per block row)
 int stan_comm_allgather_rows(stan_ctx *ctx, stan_matrix *K, double *d_full) {
-    if (!ctx->comm) return no_comm(ctx);
+    void *comm = comm_for_call(ctx);
+    if (!comm) return no_comm(ctx);
     NCCLCHK(ctx, ctx->nccl.GroupStart());
     for (int r = 0; r < ctx->nranks; r++) {
         const int64_t a = K->row_starts[r], b = K->row_starts[r + 1];
         if (b > a)
             NCCLCHK(ctx, ctx->nccl.Broadcast(d_full + 3 * a, d_full + 3 * a, (size_t)(3 * (b - a)),
-                                             NCCL_F64, r, ctx->comm, ctx->stream));
+                                             NCCL_F64, r, comm, ctx->stream));
     }
     NCCLCHK(ctx, ctx->nccl.GroupEnd());
     return STAN_OK;
@@ -169,9 +199,16 @@ int stan_comm_allgather_rows(stan_ctx *ctx, stan_matrix *K, double *d_full) {
 
 // A peer rank failed while this one may be blocked in a collective: abort the communicator so that
 // its queued work returns (ncclCommAbort), and refuse every later collective on this context.
+// Called from the group's HOST thread while the rank's worker may be inside the solve: the pointer is
+// taken away under the mutex (the worker's next call sees comm_broken and returns STAN_E_COMM), the
+// abort itself runs outside it -- ncclCommAbort is the one RCCL call that may overtake a blocked one.
 void stan_comm_abort(stan_ctx *ctx) {
-    if (!ctx->comm) return;
-    if (ctx->nccl.CommAbort) ctx->nccl.CommAbort(ctx->comm);
-    ctx->comm = nullptr;
-    ctx->comm_broken = true;
+    void *comm = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(ctx->comm_mu);
+        comm = ctx->comm;
+        ctx->comm = nullptr;
+        ctx->comm_broken.store(true);
+    }
+    if (comm && ctx->nccl.CommAbort) ctx->nccl.CommAbort(comm);
 }

@@ -49,6 +49,9 @@ struct rccl_api {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int *) = nullptr;          // optional
+    int (*CommCount)(void *, int *) = nullptr;   // optional
+    int (*CommUserRank)(void *, int *) = nullptr;
 };
 
 // Device blocks of 8 MB and more are kept by the context when they are freed and handed out again
@@ -409,6 +412,8 @@ int stan_group_cg_solve(stan_ctx *lead, stan_matrix *K, const double *F, double 
 int stan_group_recover(stan_ctx *lead, int64_t n_nodes, const double *xyz, const double *disp, int64_t n_elem,
                        const int32_t *conn, const int32_t *elem_mat, const uint8_t *elem_type, int32_t n_mat,
                        const double *mat_E_nu, double *strain, double *stress);
+int stan_group_set_p2p(stan_ctx *lead, bool on);
+int stan_group_rank0_call(stan_ctx *lead, const std::function<int(stan_ctx *)> &fn);
 stan_ctx *stan_group_rank0(stan_ctx *lead);
 int stan_group_size(stan_ctx *lead);
 // entry points that have no meaning for a group handle (device pointers, single-rank helpers)

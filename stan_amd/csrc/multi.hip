@@ -6,9 +6,15 @@
 // thread (HIP's current device and RCCL's group state are per thread), joined into one RCCL
 // communicator.  Every entry point of include/stan_hip.h that takes the group handle fans the
 // same call out to the workers -- exactly the calls a process-per-GPU launcher (bench.py under
-// torch.distributed.run) makes on its ranks -- and hands back rank 0's results: the sharding,
-// the halo exchange, the all-reduces and the result gather are the code of comm.hip / cg.hip,
-// unchanged.  The host sees the single-GPU API: init_multi, assemble, cg_solve, matrix_free.
+// torch.distributed.run) makes on its ranks: the sharding, the halo exchange and the reductions
+// are the code of comm.hip / p2p.hip / cg.hip.  The host sees the single-GPU API: init_multi,
+// assemble, cg_solve, matrix_free.
+//
+// Two things only this form can do, because all ranks share one address space:
+//   * the exchanges of the CG loop can go PEER TO PEER (STAN_OPT_COMM_P2P, p2p.hip): no collective
+//     launch per iteration;
+//   * the result needs no gather: every rank copies ITS entries of U straight into the caller's
+//     buffer (stan_matrix::u0/u1), and uploads only its entries of F.
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -24,13 +30,17 @@ struct stan_group {
         std::mutex m;
         std::condition_variable cv;
         std::function<int()> job;
-        bool has_job = false, done = false, quit = false;
+        bool has_job = false, done = true, quit = false;
         int rc = 0;
     };
     std::vector<stan_ctx *> ctx;         // one ordinary context per device, rank = index
     std::vector<worker *> w;
+    std::vector<int> devices;
     std::string err;
-    bool broken = false;                 // a rank failed inside a sharded call: the communicators were aborted
+    bool broken = false;                 // a rank failed inside a sharded call: the exchanges were aborted
+    bool wedged = false;                 // a worker never came back after the abort: its thread is abandoned
+    stan_p2p *p2p = nullptr;             // peer-to-peer resources (nullptr: not available, see p2p_why)
+    std::string p2p_why;
 };
 
 namespace {
@@ -51,9 +61,23 @@ void worker_main(stan_group::worker *w) {
     }
 }
 
-// run fn(rank) on every worker, wait for all; first non-zero code wins (its text goes to g->err)
-int run_all(stan_group *g, const std::function<int(int)> &fn) {
+// RUN_JOIN: calls without any exchange between the ranks (assembly, stress recovery, options,
+// destroy): every worker is simply joined and the first error (by rank) is returned -- a shard that
+// fails fast (det J == 0, out of memory) while a peer is still inside a long assembly must not
+// cost the handle its communicators.
+// RUN_EXCHANGE: calls that can block in an exchange with the other ranks (the solve, the
+// communicator's rendezvous): a rank that fails returns while its peers wait for it.  Once one
+// worker has come back with an error the others get a grace period; then every communicator is
+// aborted (ncclCommAbort from this thread: the one RCCL call that may overtake a blocked one; the
+// pointer hand-off is guarded, comm.hip) and the peer-to-peer waits are released; a worker that
+// STILL does not return within the final bound is abandoned and the handle reports STAN_E_COMM
+// for good -- the host is never left waiting forever.
+enum run_mode { RUN_JOIN, RUN_EXCHANGE };
+constexpr int GRACE_S = 5, FINAL_S = 60;
+
+int run_all(stan_group *g, const std::function<int(int)> &fn, run_mode mode) {
     const int n = (int)g->w.size();
+    if (g->wedged) { g->err = "a worker thread never returned from an aborted call: destroy this handle"; return STAN_E_COMM; }
     for (int r = 0; r < n; r++) {
         stan_group::worker *w = g->w[r];
         std::lock_guard<std::mutex> lk(w->m);
@@ -62,52 +86,103 @@ int run_all(stan_group *g, const std::function<int(int)> &fn) {
         w->done = false;
         w->cv.notify_all();
     }
-    int rc = STAN_OK;
-    // A rank that fails inside a sharded call returns while its peers wait for it in a collective
-    // (ADVICE r01): once one worker has come back with an error, the others get a grace period and
-    // then their communicators are aborted, which makes their queued RCCL work return.
-    bool failed = false, aborted = false;
-    for (int r = 0; r < n; r++) {
-        stan_group::worker *w = g->w[r];
-        std::unique_lock<std::mutex> lk(w->m);
-        while (!w->done) {
-            if (!failed) {
-                w->cv.wait_for(lk, std::chrono::milliseconds(200), [&] { return w->done; });
-                if (w->done) break;
-                lk.unlock();   // has some other rank already failed?
-                for (int q = 0; q < n && !failed; q++) {
-                    std::lock_guard<std::mutex> lq(g->w[q]->m);
-                    failed = g->w[q]->done && g->w[q]->rc != STAN_OK;
-                }
-                lk.lock();
-            } else if (!aborted) {
-                if (w->cv.wait_for(lk, std::chrono::seconds(5), [&] { return w->done; })) break;
-                lk.unlock();
+    int first_failed = -1;   // the rank that failed FIRST in time is the one worth reporting
+    if (mode == RUN_JOIN) {
+        for (int r = 0; r < n; r++) {
+            stan_group::worker *w = g->w[r];
+            std::unique_lock<std::mutex> lk(w->m);
+            w->cv.wait(lk, [&] { return w->done; });
+            if (w->rc != STAN_OK && first_failed < 0) first_failed = r;
+        }
+    } else {
+        using clock = std::chrono::steady_clock;
+        bool aborted = false;
+        clock::time_point t_fail, t_abort;
+        for (;;) {
+            int running = 0;
+            for (int r = 0; r < n; r++) {
+                stan_group::worker *w = g->w[r];
+                std::lock_guard<std::mutex> lk(w->m);
+                if (!w->done) running++;
+                else if (w->rc != STAN_OK && first_failed < 0) { first_failed = r; t_fail = clock::now(); }
+            }
+            if (running == 0) break;
+            if (first_failed >= 0 && !aborted && clock::now() - t_fail > std::chrono::seconds(GRACE_S)) {
                 for (int q = 0; q < n; q++)
                     if (g->ctx[q]) stan_comm_abort(g->ctx[q]);
+                stan_p2p_abort(g->p2p);
                 g->broken = aborted = true;
-                lk.lock();
-            } else
-                w->cv.wait(lk, [&] { return w->done; });
-        }
-        if (w->rc != STAN_OK) failed = true;
-        // the code that is reported: the first rank's, except that a communicator error gives way to
-        // any other one (after an abort every surviving rank reports STAN_E_COMM: a consequence)
-        if (w->rc != STAN_OK && (rc == STAN_OK || (rc == STAN_E_COMM && w->rc != STAN_E_COMM))) {
-            rc = w->rc;
-            g->err = "rank " + std::to_string(r) + ": " + (g->ctx[r] ? g->ctx[r]->err : std::string("no context"));
+                t_abort = clock::now();
+            }
+            if (aborted && clock::now() - t_abort > std::chrono::seconds(FINAL_S)) {
+                g->wedged = true;   // (the abandoned jobs hold copies of their arguments, not references to this frame)
+                break;
+            }
+            // sleep until some worker finishes (or 100 ms)
+            stan_group::worker *w = nullptr;
+            for (int r = 0; r < n && !w; r++) { std::lock_guard<std::mutex> lk(g->w[r]->m); if (!g->w[r]->done) w = g->w[r]; }
+            if (w) { std::unique_lock<std::mutex> lk(w->m); w->cv.wait_for(lk, std::chrono::milliseconds(100), [&] { return w->done; }); }
         }
     }
+    if (g->wedged) {
+        g->err = "rank " + std::to_string(first_failed) + " failed and a peer did not return after the exchanges were aborted";
+        return STAN_E_COMM;
+    }
+    // the code that is reported: the rank that failed first, except that a communicator error gives way to
+    // any other one (after an abort every surviving rank reports STAN_E_COMM: a consequence, not the cause)
+    int rc = STAN_OK, who = -1;
+    if (first_failed >= 0) { rc = g->w[first_failed]->rc; who = first_failed; }
+    for (int r = 0; r < n; r++) {
+        const int e = g->w[r]->rc;
+        if (e != STAN_OK && (rc == STAN_OK || (rc == STAN_E_COMM && e != STAN_E_COMM))) { rc = e; who = r; }
+    }
+    if (rc != STAN_OK)
+        g->err = "rank " + std::to_string(who) + ": " + (g->ctx[who] ? g->ctx[who]->err : std::string("no context"));
     return rc;
 }
 
 void stop_workers(stan_group *g) {
     for (stan_group::worker *w : g->w) {
-        { std::lock_guard<std::mutex> lk(w->m); w->quit = true; w->cv.notify_all(); }
-        if (w->th.joinable()) w->th.join();
-        delete w;
+        bool idle;
+        { std::lock_guard<std::mutex> lk(w->m); idle = w->done && !w->has_job; w->quit = true; w->cv.notify_all(); }
+        if (idle && w->th.joinable()) { w->th.join(); delete w; }
+        else if (w->th.joinable()) w->th.detach();   // abandoned inside a call that never returned: leaked on purpose
     }
     g->w.clear();
+}
+
+// peer-to-peer resources of the group; failure only means the option is unavailable
+void setup_p2p(stan_group *g) {
+    const int n = (int)g->devices.size();
+    bool shared = false;
+    for (int a = 0; a < n; a++)
+        for (int b = a + 1; b < n; b++) shared |= g->devices[a] == g->devices[b];
+    if (shared) {
+        // Ranks that share a device (a test topology) share its hardware queues: the runtime multiplexes
+        // streams onto GPU_MAX_HW_QUEUES (default 4) queues, and a stream wait blocks the queue it sits in --
+        // with a producer of another rank queued behind it that is a deadlock (measured:
+        // profiles/r03/waitvalue_probe_default_hw_queues.txt).  Every stream needs a queue of its own.
+        const char *q = getenv("GPU_MAX_HW_QUEUES");
+        if (!q || atoi(q) < 2 * n + 2) {
+            g->p2p_why = "ranks share a device: peer-to-peer stream waits need GPU_MAX_HW_QUEUES >= " +
+                         std::to_string(2 * n + 2) + " in the environment (one hardware queue per stream)";
+            return;
+        }
+    }
+    stan_p2p *pp = nullptr;
+    if (stan_p2p_create(&pp, g->devices, &g->p2p_why) != STAN_OK) return;
+    std::vector<std::string> why((size_t)n);
+    int rc = run_all(g, [&](int r) { hipSetDevice(g->devices[r]); return stan_p2p_rank_setup(pp, r, &why[(size_t)r]); }, RUN_JOIN);
+    if (rc == STAN_OK)
+        rc = run_all(g, [&](int r) { hipSetDevice(g->devices[r]); return stan_p2p_rank_finish(pp, r, &why[(size_t)r]); }, RUN_JOIN);
+    if (rc != STAN_OK) {
+        for (const std::string &s : why) if (!s.empty()) { g->p2p_why = s; break; }
+        run_all(g, [&](int r) { hipSetDevice(g->devices[r]); stan_p2p_rank_release(pp, r); return STAN_OK; }, RUN_JOIN);
+        stan_p2p_destroy(pp);
+        return;
+    }
+    g->p2p = pp;
+    for (stan_ctx *c : g->ctx) c->p2p = pp;
 }
 
 }  // namespace
@@ -118,6 +193,7 @@ extern "C" int stan_hip_init_multi(int n_devices, const int *devices, stan_ctx *
     stan_group *g = new stan_group();
     g->ctx.assign((size_t)n_devices, nullptr);
     for (int r = 0; r < n_devices; r++) {
+        g->devices.push_back(devices ? devices[r] : r);
         stan_group::worker *w = new stan_group::worker();
         g->w.push_back(w);
         w->th = std::thread(worker_main, w);
@@ -128,26 +204,33 @@ extern "C" int stan_hip_init_multi(int n_devices, const int *devices, stan_ctx *
     // phase 1: a context per device (a rank that cannot come up must not leave the others
     // blocked in the communicator's rendezvous); phase 2: every rank joins from its own thread
     std::vector<std::string> init_err((size_t)n_devices);
-    int rc = run_all(g, [&](int r) {
-        const int e = stan_hip_init(devices ? devices[r] : r, &g->ctx[r]);
+    int rc = run_all(g, [g, &init_err](int r) {
+        const int e = stan_hip_init(g->devices[(size_t)r], &g->ctx[(size_t)r]);
         if (e) init_err[(size_t)r] = stan_hip_last_error(nullptr);   // thread-local text of THIS worker
         return e;
-    });
-    char id[128];
-    if (rc == STAN_OK && n_devices > 1) rc = stan_hip_comm_unique_id(id);
+    }, RUN_JOIN);
+    // (the rendezvous job captures by value: should a rank hang in it for good, run_all gives up and the
+    // abandoned worker must not look at this frame again)
+    std::string id(128, '\0');
+    if (rc == STAN_OK && n_devices > 1) rc = stan_hip_comm_unique_id(&id[0]);
     if (rc == STAN_OK && n_devices > 1)
-        rc = run_all(g, [&](int r) { return stan_hip_comm_init(g->ctx[r], r, n_devices, id); });
+        rc = run_all(g, [g, id, n_devices](int r) { return stan_hip_comm_init(g->ctx[(size_t)r], r, n_devices, id.data()); }, RUN_EXCHANGE);
     if (rc != STAN_OK) {
         std::string msg = g->err;
         for (size_t r = 0; r < g->ctx.size(); r++)
             if (!init_err[r].empty()) { msg = "rank " + std::to_string(r) + ": " + init_err[r]; break; }
         // contexts that did come up are destroyed by their own threads
-        run_all(g, [&](int r) { if (g->ctx[r]) { stan_hip_destroy(g->ctx[r]); g->ctx[r] = nullptr; } return STAN_OK; });
+        if (!g->wedged)
+            run_all(g, [g](int r) { if (g->ctx[(size_t)r]) { stan_hip_destroy(g->ctx[(size_t)r]); g->ctx[(size_t)r] = nullptr; } return STAN_OK; }, RUN_JOIN);
         stop_workers(g);
-        delete g;
+        if (!g->wedged) delete g;   // an abandoned worker may still touch the group: leaked with it
         delete lead;
         stan_set_global_error("stan_hip_init_multi: " + msg);
         return rc;
+    }
+    if (n_devices > 1) {
+        for (stan_ctx *c : g->ctx) c->result_segment = true;
+        setup_p2p(g);
     }
     *out = lead;
     return STAN_OK;
@@ -158,9 +241,18 @@ extern "C" int stan_hip_init_multi(int n_devices, const int *devices, stan_ctx *
 void stan_group_destroy(stan_ctx *lead) {
     stan_group *g = lead->group;
     for (stan_matrix *K : lead->matrices) K->ctx = nullptr;   // group matrices may be freed afterwards
-    run_all(g, [&](int r) { stan_hip_destroy(g->ctx[r]); g->ctx[r] = nullptr; return STAN_OK; });
-    stop_workers(g);
-    delete g;
+    if (!g->wedged) {
+        run_all(g, [g](int r) {
+            if (g->p2p) { hipSetDevice(g->devices[(size_t)r]); stan_p2p_rank_release(g->p2p, r); }
+            stan_hip_destroy(g->ctx[(size_t)r]);
+            g->ctx[(size_t)r] = nullptr;
+            return STAN_OK;
+        }, RUN_JOIN);
+        stop_workers(g);
+        if (g->p2p) stan_p2p_destroy(g->p2p);
+        delete g;
+    } else
+        stop_workers(g);   // what an abandoned worker still holds is leaked with the group
     delete lead;
 }
 
@@ -171,7 +263,20 @@ const char *stan_group_last_error(stan_ctx *lead) {
 int stan_group_ctx_call(stan_ctx *lead, const std::function<int(stan_ctx *)> &fn) {
     stan_group *g = lead->group;
     lead->err.clear();
-    return run_all(g, [&](int r) { return fn(g->ctx[r]); });
+    return run_all(g, [&](int r) { return fn(g->ctx[(size_t)r]); }, RUN_JOIN);
+}
+
+// STAN_OPT_COMM_P2P on a group handle
+int stan_group_set_p2p(stan_ctx *lead, bool on) {
+    stan_group *g = lead->group;
+    lead->err.clear();
+    if (on && !g->p2p) {
+        lead->err = "peer-to-peer exchanges are not available on this handle: " +
+                    (g->p2p_why.empty() ? std::string("a single device") : g->p2p_why);
+        return STAN_E_UNSUPPORTED;
+    }
+    for (stan_ctx *c : g->ctx) c->comm_p2p = on;
+    return STAN_OK;
 }
 
 int stan_group_assemble(stan_ctx *lead, int64_t n_nodes, const double *xyz, const int32_t *node_dof,
@@ -180,18 +285,18 @@ int stan_group_assemble(stan_ctx *lead, int64_t n_nodes, const double *xyz, cons
                         const int32_t *red, stan_matrix **outK) {
     stan_group *g = lead->group;
     lead->err.clear();
-    if (g->broken) { lead->err = "a rank failed earlier and the communicators were aborted: destroy this handle"; return STAN_E_COMM; }
+    if (g->broken) { lead->err = "a rank failed earlier and the exchanges were aborted: destroy this handle"; return STAN_E_COMM; }
     stan_matrix *K = new stan_matrix();
     K->ctx = lead;
     K->parts.assign(g->ctx.size(), nullptr);
     const int rc = run_all(g, [&](int r) {
-        const int e = stan_hip_assemble_hex8(g->ctx[r], n_nodes, xyz, node_dof, n_elem, conn, elem_mat, elem_type,
-                                             n_mat, mat_E_nu, n_dof, red, &K->parts[r]);
-        if (e == STAN_E_DETJ) lead->bad_elem = g->ctx[r]->bad_elem;
+        const int e = stan_hip_assemble_hex8(g->ctx[(size_t)r], n_nodes, xyz, node_dof, n_elem, conn, elem_mat, elem_type,
+                                             n_mat, mat_E_nu, n_dof, red, &K->parts[(size_t)r]);
+        if (e == STAN_E_DETJ) lead->bad_elem = g->ctx[(size_t)r]->bad_elem;
         return e;
-    });
+    }, RUN_JOIN);
     if (rc != STAN_OK) {
-        run_all(g, [&](int r) { if (K->parts[r]) stan_hip_matrix_free(K->parts[r]); return STAN_OK; });
+        run_all(g, [&](int r) { if (K->parts[(size_t)r]) stan_hip_matrix_free(K->parts[(size_t)r]); return STAN_OK; }, RUN_JOIN);
         delete K;
         return rc;
     }
@@ -203,6 +308,18 @@ int stan_group_assemble(stan_ctx *lead, int64_t n_nodes, const double *xyz, cons
         K->n_elem_scanned += p->n_elem_scanned;
         if (p->max_row_blocks > K->max_row_blocks) K->max_row_blocks = p->max_row_blocks;
     }
+    // a rank's entries of the reduced vectors are contiguous: [#free DOFs below its first row, ... its last)
+    {
+        size_t r = 0;
+        int64_t nfree = 0;
+        for (int64_t d = 0; d <= n_dof; d++) {
+            while (r < K->parts.size() && d == 3 * K->parts[r]->r0) { K->parts[r]->u0 = nfree; r++; }
+            if (d < n_dof && red[d] != -1) nfree++;
+        }
+        for (size_t q = 0; q < K->parts.size(); q++)
+            K->parts[q]->u1 = q + 1 < K->parts.size() ? K->parts[q + 1]->u0 : nfree;
+        K->u0 = 0; K->u1 = nfree;
+    }
     lead->matrices.push_back(K);
     *outK = K;
     return STAN_OK;
@@ -210,12 +327,12 @@ int stan_group_assemble(stan_ctx *lead, int64_t n_nodes, const double *xyz, cons
 
 void stan_group_matrix_free(stan_matrix *K) {
     stan_ctx *lead = K->ctx;
-    if (lead && lead->group) {
+    if (lead && lead->group && !lead->group->wedged) {
         auto &v = lead->matrices;
         for (size_t i = 0; i < v.size(); i++)
             if (v[i] == K) { v.erase(v.begin() + i); break; }
-        run_all(lead->group, [&](int r) { stan_hip_matrix_free(K->parts[r]); return STAN_OK; });
-    } else   // the group is gone: its contexts detached the parts when they were destroyed
+        run_all(lead->group, [&](int r) { stan_hip_matrix_free(K->parts[(size_t)r]); return STAN_OK; }, RUN_JOIN);
+    } else if (!lead)   // the group is gone: its contexts detached the parts when they were destroyed
         for (stan_matrix *p : K->parts) stan_hip_matrix_free(p);
     delete K;
 }
@@ -225,25 +342,25 @@ int stan_group_cg_solve(stan_ctx *lead, stan_matrix *K, const double *F, double 
                         double *rel_residual) {
     stan_group *g = lead->group;
     lead->err.clear();
-    if (g->broken) { lead->err = "a rank failed earlier and the communicators were aborted: destroy this handle"; return STAN_E_COMM; }
-    const size_t N = (size_t)K->n_red;
-    // every rank ends with the whole U (the result gather of the sharded CG); rank 0 writes the
-    // caller's buffer, the others a scratch copy
-    std::vector<std::vector<double>> scratch(g->ctx.size());
-    // STAN_TEST_FAIL_RANK: test hook only (tests/test_gpu_multi.py: a rank that fails while its peers
-    // are inside the solve must not hang the host), like STAN_RCCL_LIB
-    const char *inject = getenv("STAN_TEST_FAIL_RANK");
-    return run_all(g, [&](int r) {
-        if (inject && *inject && atoi(inject) == r) {
-            g->ctx[r]->err = "injected failure (STAN_TEST_FAIL_RANK)";
+    if (g->broken) { lead->err = "a rank failed earlier and the exchanges were aborted: destroy this handle"; return STAN_E_COMM; }
+    // Every rank uploads its entries of F and leaves its entries of U in the caller's buffer (disjoint
+    // ranges: stan_hip_cg_solve on a rank whose context has result_segment set).
+    // STAN_TEST_FAIL_RANK: honoured only together with the test transport (STAN_RCCL_LIB, tests/fake_rccl):
+    // tests/test_gpu_multi.py checks that a rank that fails while its peers are inside the solve does not
+    // hang the host.  Without the test transport in the environment the variable is ignored.
+    int inject = -1;
+    if (const char *t = getenv("STAN_RCCL_LIB"))
+        if (*t) if (const char *f = getenv("STAN_TEST_FAIL_RANK")) if (*f) inject = atoi(f);
+    // by value: an abandoned worker (see run_all) must not read this frame
+    return run_all(g, [=](int r) {
+        if (inject == r) {
+            g->ctx[(size_t)r]->err = "injected failure (STAN_TEST_FAIL_RANK)";
             return (int)STAN_E_HIP;
         }
-        double *u = U;
-        if (r != 0) { scratch[(size_t)r].resize(N ? N : 1); u = scratch[(size_t)r].data(); }
-        return stan_hip_cg_solve(g->ctx[r], K->parts[r], F, eps_f, max_its, precision_mode, u,
+        return stan_hip_cg_solve(g->ctx[(size_t)r], K->parts[(size_t)r], F, eps_f, max_its, precision_mode, U,
                                  r == 0 ? termination_type : nullptr, r == 0 ? iterations : nullptr,
                                  r == 0 ? rel_residual : nullptr);
-    });
+    }, RUN_EXCHANGE);
 }
 
 // Stress recovery is per element: the elements are cut into one contiguous chunk per device.
@@ -256,16 +373,27 @@ int stan_group_recover(stan_ctx *lead, int64_t n_nodes, const double *xyz, const
     return run_all(g, [&](int r) {
         const int64_t e0 = n_elem * r / n, e1 = n_elem * (r + 1) / n;
         if (e1 <= e0) return (int)STAN_OK;
-        const int rc = stan_hip_recover_hex8(g->ctx[r], n_nodes, xyz, disp, e1 - e0, conn + 8 * e0, elem_mat + e0,
+        stan_ctx *c = g->ctx[(size_t)r];
+        const int rc = stan_hip_recover_hex8(c, n_nodes, xyz, disp, e1 - e0, conn + 8 * e0, elem_mat + e0,
                                              elem_type + e0, n_mat, mat_E_nu, strain + 48 * e0, stress + 48 * e0);
         if (rc == STAN_E_UNSUPPORTED || rc == STAN_E_DETJ) {   // element numbers of the whole model
-            lead->bad_elem = g->ctx[r]->bad_elem + e0;
-            g->ctx[r]->err = (rc == STAN_E_DETJ ? "det J == 0 in element " : "stress recovery: HEX8_G1 element ") +
-                             std::to_string(lead->bad_elem) +
-                             (rc == STAN_E_DETJ ? "" : " (the reference throws: N has one row, Element.cs:242)");
+            lead->bad_elem = c->bad_elem + e0;
+            c->err = (rc == STAN_E_DETJ ? "det J == 0 in element " : "stress recovery: HEX8_G1 element ") +
+                     std::to_string(lead->bad_elem) +
+                     (rc == STAN_E_DETJ ? "" : " (the reference throws: N has one row, Element.cs:242)");
         }
         return rc;
-    });
+    }, RUN_JOIN);
+}
+
+// single-rank helpers that a group handle redirects to rank 0 (K_e, nodal forces, pool info): run on rank
+// 0's worker thread... they are synchronous host calls on its context; the error text follows the handle
+int stan_group_rank0_call(stan_ctx *lead, const std::function<int(stan_ctx *)> &fn) {
+    stan_group *g = lead->group;
+    lead->err.clear();
+    const int rc = fn(g->ctx[0]);
+    if (rc != STAN_OK) lead->err = "rank 0: " + g->ctx[0]->err;
+    return rc;
 }
 
 stan_ctx *stan_group_rank0(stan_ctx *lead) { return lead->group->ctx[0]; }

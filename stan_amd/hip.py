@@ -30,6 +30,7 @@ OPT_CG_DEFER_X = 14
 OPT_SPMV_SMALL = 15
 OPT_PLACEMENT_MAX_BYTES = 16
 OPT_SELL_SIGMA = 17
+OPT_COMM_P2P = 18
 E_HIP, E_ARG, E_ALLOC, E_DETJ, E_DOF_LAYOUT, E_VALENCE, E_COMM, E_UNSUPPORTED = (
     -1, -2, -3, -4, -5, -6, -7, -8)
 
@@ -41,7 +42,7 @@ EXPORTS = [
     "stan_hip_ke_hex8_batch", "stan_hip_matrix_to_csr", "stan_hip_spmv", "stan_hip_spmv_bench",
     "stan_hip_set_profiling", "stan_hip_get_profile", "stan_hip_set_option", "stan_hip_recover_hex8", "stan_hip_recover_hex8_dev",
     "stan_hip_nodal_forces_hex8", "stan_hip_pool_info",
-    "stan_hip_matrix_plan", "stan_hip_spmv_local",
+    "stan_hip_matrix_plan", "stan_hip_spmv_local", "stan_hip_comm_info",
 ]
 # only in the lab build (stan_amd/csrc/lab/stan_hip_lab.h, selected with STAN_HIP_LIB)
 LAB_EXPORTS = ["stan_hip_csr_spmv_bench", "stan_hip_lab_placement_map", "stan_hip_lab_placement_variants", "stan_hip_lab_placement_alloc", "stan_hip_lab_placement_rounds", "stan_hip_lab_placement_cross", "stan_hip_lab_incg_penalty", "stan_hip_lab_placement_vecalloc", "stan_hip_lab_placement_vecshape"]
@@ -65,7 +66,9 @@ class Profile(C.Structure):
                 ("loop_kernel_launches", C.c_int64), ("loop_collectives", C.c_int64),
                 ("loop_iterations_enqueued", C.c_int64), ("placement_candidates", C.c_int32),
                 ("placement_ms_best", C.c_float), ("placement_ms_worst", C.c_float),
-                ("col_slots_packed", C.c_int64), ("placement_moved_vectors", C.c_int32)]
+                ("col_slots_packed", C.c_int64), ("placement_moved_vectors", C.c_int32), ("reserved0", C.c_int32),
+                ("loop_stream_waits", C.c_int64), ("comm_reduce_ms_total", C.c_double),
+                ("comm_reduce_calls", C.c_int64), ("comm_halo_ms_total", C.c_double), ("comm_halo_calls", C.c_int64)]
 
 
 class StanHipError(RuntimeError):
@@ -185,6 +188,12 @@ class Context:
             return
         buf = C.create_string_buffer(bytes(uid), 128)
         self._chk(self.lib.stan_hip_comm_init(self.h, C.c_int(rank), C.c_int(nranks), buf))
+
+    def comm_info(self):
+        """What the sharded CG exchanges over: RCCL version code, the communicator's rank count / rank, p2p flag."""
+        v, n, r, p = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._chk(self.lib.stan_hip_comm_info(self.h, C.byref(v), C.byref(n), C.byref(r), C.byref(p)))
+        return dict(rccl_version=v.value, comm_ranks=n.value, comm_rank=r.value, p2p=bool(p.value))
 
     # -- K_e (debug / parity) ---------------------------------------------------------
     def ke_hex8(self, xyz8, E, nu, etype):

@@ -252,6 +252,9 @@ int ncclBroadcast(const void *send, void *recv, size_t count, int dt, int root, 
     g_ops.push_back(Op{2, send, recv, count * tsize(dt), root, st});
     return g_depth ? 0 : flush_group(g_comm);
 }
+int ncclGetVersion(int *v) { *v = 0; return 0; }   // 0 = "not RCCL": bench.py prints it
+int ncclCommCount(void *comm, int *n) { *n = ((Comm *)comm)->nranks; return 0; }
+int ncclCommUserRank(void *comm, int *r) { *r = ((Comm *)comm)->rank; return 0; }
 const char *ncclGetErrorString(int r) {
     return r == 0 ? "success" : r == 4 ? "fake_rccl: invalid argument" : r == 5 ? "fake_rccl: protocol error" : "fake_rccl: system error";
 }

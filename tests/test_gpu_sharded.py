@@ -94,3 +94,31 @@ def test_bench_multi_rank_code_path(built_libs):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["converged"] and d["value"] > 0
     assert d["config"]["parallelism"] == "rows sharded x2" and d["roofline"]["launches"] > 0
+    # round 3: a multi-GPU line explains itself -- transport, per-rank SpMV rates, exchange times per call
+    assert "stand-in" in d["config"]["transport"] and "communicator of 2 ranks" in d["config"]["transport"]
+    pr = d["roofline"]["per_rank"]
+    assert len(pr["frac"]) == 2 and 0 < pr["frac_min"] <= pr["frac_max"]
+    ex = d["config"]["exchange"]
+    assert len(ex["allreduce_us_per_call"]) == 2 and min(ex["allreduce_us_per_call"]) > 0
+    assert min(ex["halo_us_per_call"]) > 0 and ex["allreduces_per_step"] > 2 * d["config"]["cg_iterations"] * 0.9
+    assert sum(ex["owned_block_rows"]) == 17 ** 3 and min(ex["halo_block_rows"]) > 0
+    assert d["roofline"]["two_product_launches"] >= d["config"]["cg_iterations"] // 10
+
+
+def test_bench_watchdog_ends_a_stuck_multi_rank_run(built_libs):
+    """First contact with an 8-GPU node must not hang the driver: rank 1 never starts its steps (test hook),
+    rank 0 blocks in the first exchange; the watchdog prints one JSON error line and the job exits non-zero
+    well inside a minute -- by os._exit from a thread, never by re-executing a GPU process."""
+    import time
+    t0 = time.time()
+    out = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--size", "10", "--no-cpu", "--watchdog", "12"],
+                    {"STAN_BENCH_BACKEND": "gloo", "STAN_BENCH_DEVICE": "0", "STAN_BENCH_TEST_HANG_RANK": "1"})
+    took = time.time() - t0
+    assert out.returncode != 0, out.stdout[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) >= 1, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["value"] is None and "watchdog" in d["error"] and d["watchdog"]["rank"] == 0
+    assert "warm-up" in d["watchdog"]["phase"] and d["n_gpus"] == 2
+    assert took < 100, took     # launcher start + torch import + 12 s bound + teardown
