@@ -198,23 +198,58 @@ k_symbolic(int64_t nloc, int64_t r0, int64_t r1, const int64_t *ptr, int32_t *li
 // The permutation stays INSIDE the matrix: rowof[position] = local block row, posof = inverse;
 // vectors, halo plan, CRS export and the row partition keep the reference (AssignDOF) order, and
 // a row's blocks keep their ascending column order, so every row sum keeps its bits.
-// One workgroup per window; rank = #{longer rows} + #{equally long rows in front}.
-__global__ void __launch_bounds__(256)
+// One WAVEFRONT per window, a stable counting sort: histogram of the lengths (<= STAN_MAX_ROW_BLOCKS),
+// start of every length class (longest first), then the window's rows in order, 64 at a time -- a row's
+// place in its class = rows of that length seen so far + equal-length lanes in front of it in the wave.
+__global__ void __launch_bounds__(64)
 k_window_sort(int64_t npad, int sigma, const int32_t *rowlen, int32_t *rowof, int32_t *posof) {
-    __shared__ int32_t len[64 * 32];
+    constexpr int NL = 128;            // length classes (row lengths are clipped into them: only the order suffers)
+    __shared__ int32_t start[NL];      // histogram, then the running start of every class
+    const int lane = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * sigma * 64;
     const int W = (int)((npad - base) < (int64_t)sigma * 64 ? (npad - base) : (int64_t)sigma * 64);
-    for (int i = threadIdx.x; i < W; i += 256) len[i] = rowlen[base + i];
+    for (int i = lane; i < NL; i += 64) start[i] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < W; i += 256) {
-        const int32_t li = len[i];
-        int rank = 0;
-        for (int j = 0; j < W; j++) {
-            const int32_t lj = len[j];
-            rank += (lj > li || (lj == li && j < i)) ? 1 : 0;
+    for (int i = lane; i < W; i += 64) {
+        int l = rowlen[base + i];
+        l = l < NL ? l : NL - 1;
+        atomicAdd(&start[l], 1);
+    }
+    __syncthreads();
+    {   // exclusive prefix over the classes, longest first (two classes per lane, serial: NL is tiny)
+        int32_t h0 = start[NL - 1 - 2 * lane], h1 = start[NL - 2 - 2 * lane];
+        int32_t incl = h0 + h1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int32_t t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
         }
-        rowof[base + rank] = (int32_t)(base + i);
-        posof[base + i] = (int32_t)(base + rank);
+        const int32_t excl = incl - (h0 + h1);
+        __syncthreads();
+        start[NL - 1 - 2 * lane] = excl;
+        start[NL - 2 - 2 * lane] = excl + h0;
+    }
+    __syncthreads();
+    for (int c = 0; c < W; c += 64) {
+        const int i = c + lane;
+        int l = i < W ? rowlen[base + i] : -1;
+        if (l >= NL) l = NL - 1;
+        int32_t pos = 0;
+        unsigned long long todo = __ballot(l >= 0);
+        while (todo) {   // one round per distinct length among the 64 rows (1-4 in practice)
+            const int leader = __ffsll((long long)todo) - 1;
+            const int lv = __shfl(l, leader, 64);
+            const unsigned long long same = __ballot(l == lv);
+            if (l == lv) pos = start[lv] + __popcll(same & ((1ull << lane) - 1ull));
+            __syncthreads();
+            if (lane == leader) start[lv] += __popcll(same);
+            __syncthreads();
+            todo &= ~same;
+        }
+        if (i < W) {
+            rowof[base + pos] = (int32_t)(base + i);
+            posof[base + i] = (int32_t)(base + pos);
+        }
     }
 }
 
@@ -791,7 +826,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     STANCHK(stan_dmalloc(ctx, &K->d_rowof, (size_t)(nrows_pad > 0 ? nrows_pad : 1)));
     STANCHK(stan_dmalloc(ctx, &K->d_posof, (size_t)(nrows_pad > 0 ? nrows_pad : 1)));
     if (nrows_pad > 0)
-        hipLaunchKernelGGL(k_window_sort, dim3(nblk(K->nslices, K->sigma)), dim3(256), 0, st, nrows_pad, K->sigma,
+        hipLaunchKernelGGL(k_window_sort, dim3(nblk(K->nslices, K->sigma)), dim3(64), 0, st, nrows_pad, K->sigma,
                            K->d_rowlen, K->d_rowof, K->d_posof);
     // halo numbering
     K->nhalo = 0;

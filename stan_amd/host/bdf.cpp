@@ -129,6 +129,7 @@ bool Database::ReadNastranMesh(const std::string &path, std::string *err) {
     bool ok;
     std::vector<std::string> data = read_all_lines(path, &ok);
     if (!ok) { if (err) *err = "cannot open " + path; return false; }
+    conn_index.clear();   // (cache of AssignDOF: the mesh changes)
     for (size_t i = 0; i < data.size(); i++) {
         if (data[i].rfind("$", 0) == 0) continue;  // commented line
         if (contains(data[i], "CHEXA")) {           // Elem_types_allowed = { "CHEXA" }

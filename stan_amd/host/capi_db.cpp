@@ -63,6 +63,7 @@ int stan_host_db_set_mesh(stan_db *d, int64_t n_nodes, const int32_t *node_ids, 
         return STAN_HOST_E_ARG;
     d->db.NodeLib.Clear();
     d->db.ElemLib.Clear();
+    d->db.conn_index.clear();
     for (int64_t i = 0; i < n_nodes; i++) {
         Node n;
         n.ID = node_ids[i];

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/stan_hip.h"
@@ -26,6 +27,16 @@
 using namespace stan;
 using clk = std::chrono::steady_clock;
 static double secs(clk::time_point a) { return std::chrono::duration<double>(clk::now() - a).count(); }
+
+// fn(i0, i1) over [0, n) on the host threads of libstan_host (STAN_HOST_THREADS)
+template <typename F>
+static void parallel_ranges(size_t n, F fn) {
+    const size_t nt = (size_t)HostThreads();
+    if (nt <= 1 || n < 4096) { fn((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; t++) th.emplace_back([=] { fn(n * t / nt, n * (t + 1) / nt); });
+    for (std::thread &x : th) x.join();
+}
 
 static int fail(const char *what, const std::string &msg) {
     fprintf(stderr, "\n  ERROR in %s: %s\n", what, msg.c_str());
@@ -68,15 +79,25 @@ int main(int argc, char **argv) {
     SolverFunctions Functions(opt);  // Solver.cs:16
     Functions.Welcome_Messsage();
 
+    // host phase times of this run (--json): the path around the GPU hot path is host work, and at scale most
+    // of the wall clock
+    double t_read = 0, t_dof = 0, t_bc = 0, t_disp = 0, t_recover = 0, t_store = 0, t_write = 0, t_hot = 0;
+    const auto t_wall = clk::now();
     printf("   Reading input file: ");  // Solver.cs:23-41
+    fflush(stdout);
     Database DB;
     std::string err;
+    auto t0 = clk::now();
     if (!Functions.ProtoDeserialize(path, &DB, &err)) return fail("ProtoDeserialize", err);
+    t_read = secs(t0);
     printf("     Done\n");
 
     printf("   DoF ordering: ");  // Solver.cs:44-47
+    fflush(stdout);
+    t0 = clk::now();
     if (int rc = DB.AssignDOF()) return fail("AssignDOF", "code " + std::to_string(rc) +
                                              " (disconnected mesh or unknown node ID)");
+    t_dof = secs(t0);
     printf("           Done\n");
     fputs(DB.Database_Summary().c_str(), stdout);  // Solver.cs:50
 
@@ -89,9 +110,12 @@ int main(int argc, char **argv) {
         std::vector<int32_t> nDOF_reduction;
         std::vector<double> F;
         int64_t n_fixed = 0;
+        t0 = clk::now();
         if (BuildReductionAndLoads(DB, &nDOF_reduction, &n_fixed, &F, &err)) return fail("boundary conditions", err);
+        t_bc = secs(t0);
         const int64_t n_nodes = (int64_t)DB.NodeLib.Count();
 
+        t0 = clk::now();
         SparseMatrixHandle K;
         Functions.ParallelAssembly_K(DB, nDOF_reduction, 1, "Initial", &K);  // Solver.cs:157
         stan_matrix_info minfo;
@@ -110,51 +134,70 @@ int main(int argc, char **argv) {
             if (devices.size() > 1) return fail("solver selection", "the direct solvers run on one device's export of K: drop --gpus/--devices");
             U = Functions.LinearSolver_LU(K, F);
         }  // any other string: the reference leaves U = 0 (Solver.cs:160-164)
+        t_hot = secs(t0);   // flatten + context + upload + assembly + solve + download
 
         // U = Include_BC_DOF(U, nDOF_reduction); node.dU_buffer[d] = U[DOF[d]] (Solver.cs:168-178)
+        t0 = clk::now();
         const std::vector<double> Ufull = Functions.Include_BC_DOF(U, nDOF_reduction);
         std::vector<double> disp((size_t)n_nodes * 3);
         for (size_t k = 0; k < disp.size(); k++) disp[k] = Ufull[(size_t)K.flat.node_dof[k]];
+        t_disp = secs(t0);
 
         printf("   Stress recovery: ");  // Solver.cs:183
         fflush(stdout);
+        t0 = clk::now();
         std::vector<double> strain, stress;
         Functions.Recovery_Stress(K, disp, &strain, &stress);
+        t_recover = secs(t0);
         printf("            Done\n");
-        if (json) {  // one machine-readable line per run (metrics/logging)
-            stan_profile pr;
-            stan_hip_get_profile(K.ctx, &pr);
+        stan_profile pr{};
+        if (json) stan_hip_get_profile(K.ctx, &pr);
+        // Solver.cs:81-90 (initialise step 0/1), :203-210 (update), Main :56
+        t0 = clk::now();
+        auto &nodes = DB.NodeLib.Items();
+        parallel_ranges(nodes.size(), [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; i++) {
+                Node &n = nodes[i].second;
+                n.Initialize_StepZero();
+                n.Initialize_NewDisp(1);
+                for (int d = 0; d < 3; d++) n.dU_buffer[d] = disp[3 * i + (size_t)d];
+                n.Update_Displacement(1);
+            }
+        });
+        auto &elems = DB.ElemLib.Items();
+        parallel_ranges(elems.size(), [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; i++) {
+                Element &e = elems[i].second;
+                e.Initialize_StepZero();
+                e.Initialize_Increment(1);
+                memcpy(e.Strain[1].M.data(), &strain[48 * i], 48 * sizeof(double));
+                memcpy(e.Stress[1].M.data(), &stress[48 * i], 48 * sizeof(double));
+            }
+        });
+        t_store = secs(t0);
+        printf("\n%s\n  Total CPU time: %.2f s\n%s\n", separator, secs(t_total), separator);
+        DB.AnalysisLib.Result_StepNo = 1;
+        // ExportOutput: overwrite the input path (Solver.cs:454-462)
+        t0 = clk::now();
+        if (!Functions.ProtoSerialize(DB, path, packed, &err)) return fail("ExportOutput", err);
+        t_write = secs(t0);
+        if (json) {  // one machine-readable line per run (metrics/logging), after the export
             const double spmv_ms = pr.spmv_launches ? pr.spmv_ms_total / (double)pr.spmv_launches : 0;
+            const double wall = secs(t_wall), dev = (pr.assemble_ms + pr.cg_ms) * 1e-3;
             printf("{\"n_gpus\": %d, \"n_dof\": %d, \"n_reduced\": %lld, \"blocks_3x3\": %lld, \"cg_iterations\": %d, "
                    "\"termination_type\": %d, \"rel_residual\": %.3e, \"t_assembly_s\": %.4f, \"t_cg_s\": %.4f, "
-                   "\"spmv_ms\": %.4f, \"spmv_GBs\": %.1f, \"hbm_frac\": %.3f}\n",
+                   "\"spmv_ms\": %.4f, \"spmv_GBs\": %.1f, \"hbm_frac\": %.3f, "
+                   "\"host_threads\": %d, \"t_wall_s\": %.3f, \"t_device_assembly_plus_cg_s\": %.4f, "
+                   "\"phases_s\": {\"read_parse\": %.3f, \"assign_dof\": %.3f, \"bc_tables\": %.3f, "
+                   "\"flatten_upload_assemble_solve\": %.3f, \"displacements\": %.3f, \"stress_recovery\": %.3f, "
+                   "\"store_results\": %.3f, \"serialize_write\": %.3f}}\n",
                    devices.size() > 1 ? (int)devices.size() : 1, DB.nDOF, (long long)minfo.n_reduced, (long long)minfo.n_blocks, Functions.last_iterations,
                    Functions.last_termination_type, Functions.last_rel_residual, Functions.last_assembly_s,
                    Functions.last_cg_s, spmv_ms, spmv_ms > 0 ? pr.spmv_bytes / spmv_ms / 1e6 : 0.0,
-                   spmv_ms > 0 ? pr.spmv_bytes / spmv_ms / 1e6 / 8000.0 : 0.0);
+                   spmv_ms > 0 ? pr.spmv_bytes / spmv_ms / 1e6 / 8000.0 : 0.0,
+                   HostThreads(), wall, dev, t_read, t_dof, t_bc, t_hot, t_disp, t_recover, t_store, t_write);
         }
-
-        // Solver.cs:81-90 (initialise step 0/1), :203-210 (update), Main :56
-        size_t i = 0;
-        for (auto &kv : DB.NodeLib.Items()) {
-            Node &n = kv.second;
-            n.Initialize_StepZero();
-            n.Initialize_NewDisp(1);
-            for (int d = 0; d < 3; d++) n.dU_buffer[d] = disp[3 * i + (size_t)d];
-            n.Update_Displacement(1);
-            i++;
-        }
-        i = 0;
-        for (auto &kv : DB.ElemLib.Items()) {
-            Element &e = kv.second;
-            e.Initialize_StepZero();
-            e.Initialize_Increment(1);
-            memcpy(e.Strain[1].M.data(), &strain[48 * i], 48 * sizeof(double));
-            memcpy(e.Stress[1].M.data(), &stress[48 * i], 48 * sizeof(double));
-            i++;
-        }
-        printf("\n%s\n  Total CPU time: %.2f s\n%s\n", separator, secs(t_total), separator);
-        DB.AnalysisLib.Result_StepNo = 1;
+        return 0;
     } catch (const std::exception &e) {  // the C# lets these escape Main as unhandled exceptions
         return fail("SolverLinearStatics", e.what());
     } else if (DB.AnalysisLib.Type == "Nonlinear_Statics") {
@@ -162,7 +205,8 @@ int main(int argc, char **argv) {
                                      "(MainWindow.xaml.cs:444) and outside the hot path");
     }
 
-    // ExportOutput: overwrite the input path (Solver.cs:454-462)
+    // ExportOutput: overwrite the input path (Solver.cs:454-462) -- also when the analysis type is not one
+    // this driver solves (Main writes the file back regardless)
     if (!Functions.ProtoSerialize(DB, path, packed, &err)) return fail("ExportOutput", err);
     return 0;
 }

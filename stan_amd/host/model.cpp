@@ -68,6 +68,7 @@ int Database::AssignDOF() {
     std::vector<int32_t> index((size_t)nn);
     const int rc = stan_host_assign_dof(nn, ne, conn.data(), index.data(), nullptr);
     if (rc != STAN_HOST_OK) return rc;
+    conn_index = std::move(conn);   // Flatten needs the same 8 lookups per element again
     int64_t i = 0;
     for (auto &kv : NodeLib.Items()) kv.second.SetDOF(index[(size_t)i++]);
     return STAN_HOST_OK;
@@ -99,11 +100,13 @@ int Flatten(const Database &db, FlatModel *out, std::string *err) {
     out->conn.resize(ne * 8);
     out->elem_mat.resize(ne);
     out->elem_type.resize(ne);
+    const bool have_conn = db.conn_index.size() == ne * 8;   // AssignDOF resolved the node IDs already
+    if (have_conn) out->conn = db.conn_index;
     i = 0;
     for (const auto &kv : db.ElemLib.Items()) {
         const Element &e = kv.second;
         if (e.NList.size() != 8) { if (err) *err = "element " + std::to_string(e.ID) + " does not have 8 nodes"; return STAN_HOST_E_ARG; }
-        for (int a = 0; a < 8; a++) {
+        for (int a = 0; a < 8 && !have_conn; a++) {
             const int64_t idx = db.NodeLib.IndexOf(e.NList[(size_t)a]);
             if (idx < 0) { if (err) *err = "element " + std::to_string(e.ID) + " references unknown node " + std::to_string(e.NList[(size_t)a]); return STAN_HOST_E_ARG; }
             out->conn[8 * i + a] = (int32_t)idx;

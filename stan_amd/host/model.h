@@ -25,36 +25,97 @@
 
 namespace stan {
 
+// key -> position index of OrderedDict: open addressing over a power-of-two table (6.5 M keys at 148^3:
+// std::unordered_map cost seconds to build and a cache miss per node lookup of every element)
+class FlatIndex {
+  public:
+    void Reserve(size_t n) {
+        size_t cap = 16;
+        while (cap < 2 * n + 2) cap <<= 1;
+        if (cap <= slots_.size()) return;
+        std::vector<Slot> old;
+        old.swap(slots_);
+        slots_.assign(cap, Slot{0, EMPTY});
+        shift_ = 64;
+        for (size_t c = cap; c > 1; c >>= 1) shift_--;
+        for (const Slot &s : old)
+            if (s.pos != EMPTY) Put(s.key, s.pos);
+    }
+    // position of key, or -1
+    int64_t Get(int key) const {
+        if (slots_.empty()) return -1;
+        const size_t mask = slots_.size() - 1;
+        for (size_t i = Hash(key);; i = (i + 1) & mask) {
+            const Slot &s = slots_[i];
+            if (s.pos == EMPTY) return -1;
+            if (s.key == key) return (int64_t)s.pos;
+        }
+    }
+    // false when the key exists
+    bool Insert(int key, size_t pos) {
+        if (2 * (count_ + 1) + 2 > slots_.size()) Reserve(count_ < 8 ? 16 : 2 * count_);
+        if (Get(key) >= 0) return false;
+        Put(key, (uint32_t)pos);
+        count_++;
+        return true;
+    }
+    void Clear() { slots_.clear(); count_ = 0; }
+
+  private:
+    static constexpr uint32_t EMPTY = 0xffffffffu;
+    struct Slot { int key; uint32_t pos; };
+    size_t Hash(int key) const { return (size_t)(((uint64_t)(uint32_t)key * 0x9E3779B97F4A7C15ull) >> shift_); }
+    void Put(int key, uint32_t pos) {
+        const size_t mask = slots_.size() - 1;
+        size_t i = Hash(key);
+        while (slots_[i].pos != EMPTY) i = (i + 1) & mask;
+        slots_[i] = Slot{key, pos};
+    }
+    std::vector<Slot> slots_;
+    size_t count_ = 0;
+    int shift_ = 60;
+};
+
 template <typename T>
 class OrderedDict {  // Dictionary<int, T> with insertion-order enumeration
   public:
     bool Add(int key, T value) {  // false when the key exists (Dictionary.Add would throw)
-        if (index_.count(key)) return false;
-        index_[key] = items_.size();
+        if (!index_.Insert(key, items_.size())) return false;
         items_.emplace_back(key, std::move(value));
         return true;
     }
-    bool ContainsKey(int key) const { return index_.count(key) != 0; }
+    // A whole library at once (the parallel STdb reader decodes the entries first): wire order is kept, a
+    // repeated key keeps its first entry, like Add.
+    void Adopt(std::vector<std::pair<int, T>> &&items) {
+        items_ = std::move(items);
+        index_.Clear();
+        index_.Reserve(items_.size());
+        size_t w = 0;
+        for (size_t i = 0; i < items_.size(); i++) {
+            if (!index_.Insert(items_[i].first, w)) continue;   // duplicate key: dropped
+            if (w != i) items_[w] = std::move(items_[i]);
+            w++;
+        }
+        items_.resize(w);
+    }
+    bool ContainsKey(int key) const { return index_.Get(key) >= 0; }
     T *Find(int key) {
-        auto it = index_.find(key);
-        return it == index_.end() ? nullptr : &items_[it->second].second;
+        const int64_t i = index_.Get(key);
+        return i < 0 ? nullptr : &items_[(size_t)i].second;
     }
     const T *Find(int key) const {
-        auto it = index_.find(key);
-        return it == index_.end() ? nullptr : &items_[it->second].second;
+        const int64_t i = index_.Get(key);
+        return i < 0 ? nullptr : &items_[(size_t)i].second;
     }
-    int64_t IndexOf(int key) const {
-        auto it = index_.find(key);
-        return it == index_.end() ? -1 : (int64_t)it->second;
-    }
+    int64_t IndexOf(int key) const { return index_.Get(key); }
     size_t Count() const { return items_.size(); }
     std::vector<std::pair<int, T>> &Items() { return items_; }
     const std::vector<std::pair<int, T>> &Items() const { return items_; }
-    void Clear() { items_.clear(); index_.clear(); }
+    void Clear() { items_.clear(); index_.Clear(); }
 
   private:
     std::vector<std::pair<int, T>> items_;
-    std::unordered_map<int, size_t> index_;
+    FlatIndex index_;
 };
 
 struct MatrixST {  // MatrixST.cs:15-26
@@ -143,6 +204,7 @@ struct Database {  // Database.cs:10-37
     Information Info;
     bool has_info = true;
     std::vector<std::string> Import_Error;  // not serialized (Database.cs:18)
+    std::vector<int32_t> conn_index;        // not serialized: NList as NodeLib positions, left by AssignDOF for Flatten
 
     // Database.cs:39-111 (mesh only: Part objects are GUI-side and not serialized)
     bool ReadNastranMesh(const std::string &path, std::string *err);
@@ -157,6 +219,9 @@ struct Database {  // Database.cs:10-37
 bool ReadStdb(const std::string &path, Database *db, std::string *err);
 bool ParseStdb(const uint8_t *data, size_t size, Database *db, std::string *err);
 bool WriteStdb(const Database &db, const std::string &path, bool packed, std::string *err);
+// worker threads of the STdb reader / writer and of the result write-back (STAN_HOST_THREADS, default: the
+// machine's cores, at most 16)
+int HostThreads();
 void SerializeStdb(const Database &db, bool packed, std::string *out);
 
 // ---- flat views for the C-ABI of libstan_hip.so ----------------------------------------------

@@ -10,14 +10,45 @@
 // Writer rules: fields in ascending number; scalar members equal to 0 / 0.0 / null are
 // omitted (implicit zero default); list elements are always written, zeros included;
 // empty lists are omitted; repeated scalars unpacked unless `packed`.
+//
+// Round 3: both directions run on HostThreads() threads.  The libraries are sequences of
+// length-delimited map entries, so the reader first walks the top level (tags and lengths only),
+// then decodes the entries of a library in parallel and adopts them in wire order; the writer
+// encodes chunks of entries in parallel and writes the chunks in order -- the bytes are those of
+// the serial writer (tests/test_stdb_pin.py, tests/test_stdb.py).
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <mutex>
+#include <thread>
 
 #include "model.h"
 
 namespace stan {
+
+int HostThreads() {
+    if (const char *e = getenv("STAN_HOST_THREADS")) {
+        const int n = atoi(e);
+        if (n >= 1) return n > 64 ? 64 : n;
+    }
+    const unsigned hc = std::thread::hardware_concurrency();
+    return hc == 0 ? 1 : hc > 16 ? 16 : (int)hc;
+}
+
 namespace {
+
+// fn(t) on `threads` threads (t = 0 .. threads-1); the caller is thread 0
+template <typename F>
+void run_threads(int threads, F fn) {
+    std::vector<std::thread> th;
+    for (int t = 1; t < threads; t++) th.emplace_back([&fn, t] { fn(t); });
+    fn(0);
+    for (std::thread &x : th) x.join();
+}
 
 // ---------------------------------------------------------------- writer
 struct W {
@@ -91,8 +122,9 @@ void enc(const Element &e, bool packed, std::string &o) {
     W w{o, packed};
     w.i32(1, e.ID); w.str(2, e.Type, e.has_type); w.i32(3, e.PID); w.i32(4, e.MatID);
     w.rep_i32(5, e.NList);
-    for (const MatrixST &m : e.Strain) { std::string t; enc(m, packed, t); w.bytes(6, t); }
-    for (const MatrixST &m : e.Stress) { std::string t; enc(m, packed, t); w.bytes(7, t); }
+    thread_local std::string t;   // (one buffer per thread: 4 matrices per element, millions of elements)
+    for (const MatrixST &m : e.Strain) { t.clear(); enc(m, packed, t); w.bytes(6, t); }
+    for (const MatrixST &m : e.Stress) { t.clear(); enc(m, packed, t); w.bytes(7, t); }
 }
 void enc(const Material &m, bool packed, std::string &o) {
     W w{o, packed};
@@ -108,6 +140,21 @@ void enc_entry(int key, const T &v, bool packed, std::string &o) {  // map entry
     std::string t;
     enc(v, packed, t);
     w.bytes(2, t);
+}
+// field `field` of the root message for entries [i0, i1) of a library, appended to o
+template <typename T>
+void enc_lib_range(int field, const std::vector<std::pair<int, T>> &items, size_t i0, size_t i1, bool packed,
+                   std::string &o) {
+    W w{o, packed};
+    std::string entry, val;
+    for (size_t i = i0; i < i1; i++) {
+        entry.clear(); val.clear();
+        W we{entry, packed};
+        we.i32(1, items[i].first);
+        enc(items[i].second, packed, val);
+        we.bytes(2, val);
+        w.bytes(field, entry);
+    }
 }
 void enc(const BoundaryCondition &b, bool packed, std::string &o) {
     W w{o, packed};
@@ -315,14 +362,6 @@ bool dec(R r, Information &i) {
     return r.ok;
 }
 
-template <typename T>
-bool dec_lib(R &r, OrderedDict<T> &lib) {
-    int k; T v;
-    if (!dec_entry(r.sub(), k, v)) return false;
-    lib.Add(k, std::move(v));  // a repeated key keeps the first entry
-    return true;
-}
-
 }  // namespace
 
 void SerializeStdb(const Database &db, bool packed, std::string *out) {
@@ -337,51 +376,157 @@ void SerializeStdb(const Database &db, bool packed, std::string *out) {
     if (db.has_info) { std::string t; enc(db.Info, packed, t); w.bytes(7, t); }
 }
 
-bool WriteStdb(const Database &db, const std::string &path, bool packed, std::string *err) {
-    // Solver.cs:454-462 ExportOutput: FileMode.Create, overwrite.  Entries are streamed one
-    // at a time, so the writer is not bound by protobuf-net's 2 GB MemoryStream.
-    FILE *fp = fopen(path.c_str(), "wb");
-    if (!fp) { if (err) *err = "cannot open " + path + " for writing"; return false; }
+namespace {
+// One library to the file: chunks of entries are encoded by `threads` workers and written by the calling
+// thread in order; at most `window` encoded chunks wait for the writer (bounded memory whatever the model size).
+template <typename T>
+bool write_lib(FILE *fp, int field, const std::vector<std::pair<int, T>> &items, bool packed, int threads) {
+    const size_t n = items.size();
+    if (n == 0) return true;
+    constexpr size_t CHUNK = 4096;
+    const size_t nchunks = (n + CHUNK - 1) / CHUNK;
+    if (threads <= 1 || nchunks < 4) {
+        std::string buf;
+        bool ok = true;
+        for (size_t c = 0; c < nchunks && ok; c++) {
+            buf.clear();
+            enc_lib_range(field, items, c * CHUNK, std::min(n, (c + 1) * CHUNK), packed, buf);
+            ok = fwrite(buf.data(), 1, buf.size(), fp) == buf.size();
+        }
+        return ok;
+    }
+    const size_t window = (size_t)threads * 4;
+    std::vector<std::string> ring(window);
+    std::vector<char> ready(window, 0);
+    std::mutex m;
+    std::condition_variable cv;
+    std::atomic<size_t> next{0};
+    size_t written = 0;      // chunks the writer has consumed (guarded by m)
     bool ok = true;
-    auto flush = [&](std::string &b) { ok &= fwrite(b.data(), 1, b.size(), fp) == b.size(); b.clear(); };
-    std::string buf;
-    W w{buf, packed};
-    auto lib = [&](int field, const auto &dict) {
-        for (const auto &kv : dict.Items()) {
-            std::string t;
-            enc_entry(kv.first, kv.second, packed, t);
-            w.bytes(field, t);
-            if (buf.size() > (1u << 20)) flush(buf);
+    auto worker = [&] {
+        for (;;) {
+            const size_t c = next.fetch_add(1);
+            if (c >= nchunks) return;
+            {   // wait for the ring slot of chunk c to be free
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return c < written + window || !ok; });
+                if (!ok) return;
+            }
+            std::string &buf = ring[c % window];
+            buf.clear();
+            enc_lib_range(field, items, c * CHUNK, std::min(n, (c + 1) * CHUNK), packed, buf);
+            std::lock_guard<std::mutex> lk(m);
+            ready[c % window] = 1;
+            cv.notify_all();
         }
     };
-    lib(1, db.NodeLib); lib(2, db.ElemLib); lib(3, db.MatLib); lib(4, db.BCLib);
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) th.emplace_back(worker);
+    for (size_t c = 0; c < nchunks; c++) {
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return ready[c % window] != 0; });
+        }
+        const std::string &buf = ring[c % window];
+        const bool w_ok = fwrite(buf.data(), 1, buf.size(), fp) == buf.size();
+        std::lock_guard<std::mutex> lk(m);
+        ready[c % window] = 0;
+        written = c + 1;
+        if (!w_ok) ok = false;
+        cv.notify_all();
+        if (!ok) break;
+    }
+    { std::lock_guard<std::mutex> lk(m); if (!ok) next.store(nchunks); cv.notify_all(); }
+    for (std::thread &x : th) x.join();
+    return ok;
+}
+}  // namespace
+
+bool WriteStdb(const Database &db, const std::string &path, bool packed, std::string *err) {
+    // Solver.cs:454-462 ExportOutput: FileMode.Create, overwrite.  Entries are streamed in chunks, so
+    // the writer is not bound by protobuf-net's 2 GB MemoryStream; the chunks of a library are encoded
+    // in parallel and written in order (write_lib): the bytes are SerializeStdb's.
+    FILE *fp = fopen(path.c_str(), "wb");
+    if (!fp) { if (err) *err = "cannot open " + path + " for writing"; return false; }
+    static thread_local std::vector<char> iobuf;
+    iobuf.resize(8u << 20);
+    setvbuf(fp, iobuf.data(), _IOFBF, iobuf.size());
+    const int threads = HostThreads();
+    bool ok = write_lib(fp, 1, db.NodeLib.Items(), packed, threads);
+    ok = ok && write_lib(fp, 2, db.ElemLib.Items(), packed, threads);
+    ok = ok && write_lib(fp, 3, db.MatLib.Items(), packed, 1);
+    ok = ok && write_lib(fp, 4, db.BCLib.Items(), packed, 1);
+    std::string buf;
+    W w{buf, packed};
     w.i32(5, db.nDOF);
     if (db.has_analysis) { std::string t; enc(db.AnalysisLib, packed, t); w.bytes(6, t); }
     if (db.has_info) { std::string t; enc(db.Info, packed, t); w.bytes(7, t); }
-    flush(buf);
-    ok &= fclose(fp) == 0;
+    ok = ok && fwrite(buf.data(), 1, buf.size(), fp) == buf.size();
+    ok = (fclose(fp) == 0) && ok;
     if (!ok && err) *err = "short write to " + path;
     return ok;
 }
+
+namespace {
+struct Span { const uint8_t *p, *end; };
+// entries of one library, decoded on `threads` threads into wire order
+template <typename T>
+bool dec_lib_parallel(const std::vector<Span> &spans, OrderedDict<T> &lib, int threads, size_t *bad) {
+    std::vector<std::pair<int, T>> items(spans.size());
+    std::atomic<size_t> next{0};
+    std::atomic<size_t> first_bad{(size_t)-1};
+    constexpr size_t CHUNK = 2048;
+    auto work = [&](int) {
+        for (;;) {
+            const size_t c = next.fetch_add(CHUNK);
+            if (c >= spans.size()) return;
+            const size_t e = std::min(spans.size(), c + CHUNK);
+            for (size_t i = c; i < e; i++) {
+                R r{spans[i].p, spans[i].end, true};
+                if (!dec_entry(r, items[i].first, items[i].second)) {
+                    size_t cur = first_bad.load();
+                    while (i < cur && !first_bad.compare_exchange_weak(cur, i)) {}
+                }
+            }
+        }
+    };
+    if (threads <= 1 || spans.size() < 4 * CHUNK) work(0);
+    else run_threads(threads, work);
+    if (first_bad.load() != (size_t)-1) { *bad = first_bad.load(); return false; }
+    lib.Adopt(std::move(items));
+    return true;
+}
+}  // namespace
 
 bool ParseStdb(const uint8_t *data, size_t size, Database *db, std::string *err) {
     *db = Database();
     db->has_analysis = false;  // SkipConstructor: members absent from the wire stay null
     db->has_info = false;
+    // pass 1: the top level only (tags and lengths); the payloads of the four libraries are remembered
+    std::vector<Span> lib[4];
     R r{data, data + size, true};
     FIELDS(r)
-        if (f == 1 && wt == 2) { if (!dec_lib(r, db->NodeLib)) r.ok = false; }
-        else if (f == 2 && wt == 2) { if (!dec_lib(r, db->ElemLib)) r.ok = false; }
-        else if (f == 3 && wt == 2) { if (!dec_lib(r, db->MatLib)) r.ok = false; }
-        else if (f == 4 && wt == 2) { if (!dec_lib(r, db->BCLib)) r.ok = false; }
+        if (f >= 1 && f <= 4 && wt == 2) {
+            R sub = r.sub();
+            if (r.ok) lib[f - 1].push_back(Span{sub.p, sub.end});
+        }
         else if (f == 5 && wt == 0) db->nDOF = (int)r.varint();
         else if (f == 6 && wt == 2) { db->has_analysis = true; if (!dec(r.sub(), db->AnalysisLib)) r.ok = false; }
         else if (f == 7 && wt == 2) { db->has_info = true; if (!dec(r.sub(), db->Info)) r.ok = false; }
         else r.skip(wt);
     END_FIELDS(r)
-    if (!r.ok && err) *err = "malformed STdb (protobuf wire error near byte " +
-                             std::to_string((size_t)(r.p - data)) + ")";
-    return r.ok;
+    const uint8_t *where = r.p;
+    bool ok = r.ok;
+    // pass 2: the entries, in parallel (a repeated key keeps its first entry: OrderedDict::Adopt)
+    const int threads = HostThreads();
+    size_t bad = 0;
+    if (ok && !dec_lib_parallel(lib[0], db->NodeLib, threads, &bad)) { ok = false; where = lib[0][bad].p; }
+    if (ok && !dec_lib_parallel(lib[1], db->ElemLib, threads, &bad)) { ok = false; where = lib[1][bad].p; }
+    if (ok && !dec_lib_parallel(lib[2], db->MatLib, 1, &bad)) { ok = false; where = lib[2][bad].p; }
+    if (ok && !dec_lib_parallel(lib[3], db->BCLib, 1, &bad)) { ok = false; where = lib[3][bad].p; }
+    if (!ok && err) *err = "malformed STdb (protobuf wire error near byte " +
+                           std::to_string((size_t)(where - data)) + ")";
+    return ok;
 }
 
 bool ReadStdb(const std::string &path, Database *db, std::string *err) {

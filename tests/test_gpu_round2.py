@@ -390,5 +390,6 @@ def test_small_system_spmv_kernel(gpu_ctx, oracle, n, prec):
     for small in (1, 0):
         assert out[small][2]["terminationtype"] == repo["terminationtype"] or prec == "mixed"
         assert np.abs(out[small][1] - Uo).max() <= tol * np.abs(Uo).max()
-    assert abs(out[1][2]["iterations"] - out[0][2]["iterations"]) <= max(3, out[0][2]["iterations"] // 20)
+    # (the fp32 matrix with eps 1e-10 ends on the merit-function floor, type 7: where exactly is rounding's choice)
+    assert abs(out[1][2]["iterations"] - out[0][2]["iterations"]) <= max(3, out[0][2]["iterations"] // (10 if prec == "mixed" else 20))
     K.free()
