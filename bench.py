@@ -169,6 +169,12 @@ def main():
     ap.add_argument("--placement-tries", type=int, default=32,
                     help="STAN_OPT_PLACEMENT_TRIES: candidates the allocation-by-search of K's value array may time in "
                          "the first (warm-up) assembly (library default 16; 1 = plain allocation)")
+    ap.add_argument("--p2p", action="store_true",
+                    help="STAN_OPT_COMM_P2P (N > 1): the CG's reductions and halo exchanges go peer to peer between the "
+                         "rank processes (HIP IPC mappings; no RCCL launch in the loop) instead of over RCCL")
+    ap.add_argument("--knockout", type=float, default=0.0,
+                    help="not the headline workload: the cube with this fraction of its elements knocked out at random "
+                         "(an irregular mesh: row lengths vary; SELL-C-sigma evidence, profiles/r03)")
     ap.add_argument("--watchdog", type=float, default=900.0,
                     help="seconds without progress (set-up, a warm-up step, a timed step) after which the run prints a "
                          "JSON error line and exits with code 3 (0 = off)")
@@ -203,7 +209,8 @@ def main():
 
     # ---- synthetic job (host: mesh, Database.AssignDOF, BC tables; outside the timed region)
     dog.touch("host set-up (mesh, AssignDOF, BC tables)")
-    job = problem.cube_job(args.n, etype=args.etype)
+    job = (problem.perforated_job(args.n, args.knockout, etype=args.etype) if args.knockout > 0
+           else problem.cube_job(args.n, etype=args.etype))
     dog.touch("context + communicator")
     ctx = hip.Context(dev_index)
     if world > 1:
@@ -218,6 +225,8 @@ def main():
         ctx.set_option(hip.OPT_CG_SINGLE_REDUCE, 1)
     if args.sell_sigma > 0:
         ctx.set_option(hip.OPT_SELL_SIGMA, args.sell_sigma)
+    if args.p2p and world > 1:
+        ctx.set_option(hip.OPT_COMM_P2P, 1)
     ctx.set_profiling(True)
     comm = ctx.comm_info()   # which transport the sharded loop runs over (a SCALE line should say)
 
@@ -331,7 +340,7 @@ def main():
         # them as identity rows, so a launch moves slightly more.  Both
         # fractions are reported; the x-clamped cube's reduced block count is (3n-2)(3n+1)^2.
         frac_reduced = csr_equiv = None
-        if args.etype == 2 and world == 1 and avg_ms > 0:
+        if args.etype == 2 and world == 1 and avg_ms > 0 and args.knockout == 0:
             blocks_red = (3 * args.n - 2) * (3 * args.n + 1) ** 2
             blk_bytes = 40 if args.mixed else 60 if args.fixed48 else 76
             bytes_red = blocks_red * blk_bytes + job.n_red * 16 + (job.n_red // 3) * 4
@@ -352,9 +361,11 @@ def main():
             "dtype": ("f32 matrix / f64 vectors" if args.mixed else
                       "f64 (matrix streamed as 48-bit fixed point)" if args.fixed48 else "f64"),
             "data": "synthetic",
-            "config": {"workload": "%d^3 HEX8_G%d cube, %d DOF, clamp %s, PointLoad (0,0,50) on "
+            "config": {"workload": "%d^3 HEX8_G%d cube%s, %d DOF, clamp %s, PointLoad (0,0,50) on "
                                    "x=n; fp64 Jacobi-scaled CG to %.0e" %
-                                   (args.n, args.etype, job.n_dof,
+                                   (args.n, args.etype,
+                                    " with %.0f %% of its elements knocked out (irregular mesh)" % (100 * args.knockout)
+                                    if args.knockout > 0 else "", job.n_dof,
                                     "x=0" if args.etype == 2 else "x=0, y=0, z=0", args.eps),
                        "cg_loop": "single-reduction (Chronopoulos-Gear)" if args.single_reduce
                                   else "classic (alglib lincg recurrences)",

@@ -99,6 +99,13 @@ const char *stan_host_db_last_error(stan_db *db);
 int stan_host_db_read_stdb(stan_db *db, const char *path);
 int stan_host_db_parse_stdb(stan_db *db, const uint8_t *data, int64_t size);
 int stan_host_db_write_stdb(stan_db *db, const char *path, int32_t packed);
+/* ExportOutput after a solve (Solver.cs:454-462) WITHOUT storing the results in the objects first: the file
+ * is byte for byte what stan_host_db_set_results + stan_host_db_write_stdb write (node i: DispX/Y/Z = {0,
+ * disp[3i+d]}; element e: Strain / Stress = {zeros(8x6), strain[48e..] / stress[48e..]}; Result_StepNo = 1),
+ * encoded straight from the flat arrays (disp [n_nodes*3] NodeLib order, strain / stress [n_elem*48]).  The
+ * database itself is left unchanged. */
+int stan_host_db_write_stdb_with_results(stan_db *db, const char *path, int32_t packed, const double *disp,
+                                         const double *strain, const double *stress);
 /* two-call: buf == NULL returns the size */
 int stan_host_db_serialize(stan_db *db, int32_t packed, uint8_t *buf, int64_t cap, int64_t *size);
 

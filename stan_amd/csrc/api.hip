@@ -58,6 +58,7 @@ void stan_hip_destroy(stan_ctx *ctx) {
     if (!ctx) return;
     if (ctx->group) { stan_group_destroy(ctx); return; }
     hipSetDevice(ctx->device);
+    if (ctx->p2p && ctx->p2p->ipc) stan_p2p_ipc_release(ctx);   // (a group's resources belong to the group)
     {
         void *comm = nullptr;
         { std::lock_guard<std::mutex> lk(ctx->comm_mu); comm = ctx->comm; ctx->comm = nullptr; }
@@ -105,7 +106,14 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
     if (ctx->group)
         return stan_group_ctx_call(ctx, [&](stan_ctx *c) { return stan_hip_set_option(c, option, value); });
     if (option == STAN_OPT_COMM_P2P) {
-        if (value != 0) { ctx->err = "STAN_OPT_COMM_P2P: only on a handle of stan_hip_init_multi (one process, several devices)"; return STAN_E_UNSUPPORTED; }
+        // one process per GPU: the ranks map each other's mailboxes, counters and vectors through HIP IPC; the
+        // handles travel over the communicator, so EVERY rank must make this call (it is a collective)
+        if (value != 0) {
+            if (ctx->nranks < 2 || !ctx->comm) { ctx->err = "STAN_OPT_COMM_P2P: needs a communicator of several ranks (stan_hip_comm_init) or a handle of stan_hip_init_multi"; return STAN_E_UNSUPPORTED; }
+            HIPCHK(ctx, hipSetDevice(ctx->device));
+            STANCHK(stan_p2p_ipc_setup(ctx));
+        }
+        ctx->comm_p2p = value != 0 && ctx->p2p != nullptr;
         return STAN_OK;
     }
     if (option == STAN_OPT_CG_MERIT_STOP) ctx->cg_merit_stop = value != 0;
@@ -291,7 +299,7 @@ void stan_hip_matrix_free(stan_matrix *K) {
     }
     // the solves that used these buffers have been synchronised by their own calls; the blocks go
     // back to the context's pool (stan_pool) or to the driver
-    for (void *q : {(void *)K->d_slot_ptr, (void *)K->d_rowlen, (void *)K->d_rowof, (void *)K->d_posof, (void *)K->d_cols, (void *)K->d_vals,
+    for (void *q : {(void *)K->d_slot_ptr, (void *)K->d_rowlen, (void *)K->d_rowof, (void *)K->d_posof, (void *)K->d_poslen, (void *)K->d_cols, (void *)K->d_vals,
                     (void *)K->d_vals32, (void *)K->d_vals48, (void *)K->d_cols16, (void *)K->d_colbase,
                     (void *)K->d_pair_ptr, (void *)K->d_slice_packed, (void *)K->d_red, (void *)K->d_fixmask,
                     (void *)K->d_scale, (void *)K->d_send_rows, (void *)K->d_halo_glob, (void *)K->d_sendbuf,

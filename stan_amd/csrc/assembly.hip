@@ -34,8 +34,11 @@ namespace {
 constexpr int ERR_DOF_LAYOUT = 1, ERR_CONN_RANGE = 2, ERR_VALENCE = 4, ERR_ROWLEN = 8;
 
 // ---- step 0: node permutation + fixed-DOF masks ------------------------------------------
+// (+ the coordinates in BLOCK-ROW order: the numeric phase gathers the nodes of a row's elements, which are
+// neighbours in row order but strided all over the wire order)
 __global__ void k_perm(int64_t n_nodes, int64_t nb_glob, const int32_t *node_dof,
-                       const int32_t *red, int32_t *perm, uint8_t *fixmask, int64_t *status) {
+                       const int32_t *red, const double *xyz, int32_t *perm, uint8_t *fixmask, double *xrow,
+                       int64_t *status) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
     const int32_t d0 = node_dof[3 * i], d1 = node_dof[3 * i + 1], d2 = node_dof[3 * i + 2];
@@ -47,6 +50,7 @@ __global__ void k_perm(int64_t n_nodes, int64_t nb_glob, const int32_t *node_dof
     }
     const int32_t r = d0 / 3;
     perm[i] = r;
+    xrow[3 * (int64_t)r] = xyz[3 * i]; xrow[3 * (int64_t)r + 1] = xyz[3 * i + 1]; xrow[3 * (int64_t)r + 2] = xyz[3 * i + 2];
     uint8_t m = 0;
     if (red[d0] == -1) m |= 1;
     if (red[d1] == -1) m |= 2;
@@ -55,28 +59,29 @@ __global__ void k_perm(int64_t n_nodes, int64_t nb_glob, const int32_t *node_dof
 }
 
 // ---- step 1: node -> (element, local node) incidence lists for owned rows -----------------
+// (+ the connectivity as GLOBAL BLOCK ROWS, crow = perm[conn]: every later phase wants the row, and the
+// numeric phase saves one dependent gather per incidence)
 __global__ void k_count_incident(int64_t n_elem, int64_t n_nodes, const int32_t *conn,
                                  const int32_t *perm, int64_t r0, int64_t r1, int32_t *cnt,
-                                 int64_t *status) {
+                                 int32_t *crow, int64_t *status) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_elem * 8) return;
     const int32_t nd = conn[t];
     if (nd < 0 || nd >= n_nodes) {
         atomicOr((unsigned long long *)&status[SS_ERRBITS], (unsigned long long)ERR_CONN_RANGE);
+        crow[t] = 0;
         return;
     }
     const int64_t row = perm[nd];
+    crow[t] = (int32_t)row;
     if (row >= r0 && row < r1) atomicAdd(&cnt[row - r0], 1);
 }
 
-__global__ void k_fill_incident(int64_t n_elem, int64_t n_nodes, const int32_t *conn,
-                                const int32_t *perm, int64_t r0, int64_t r1,
+__global__ void k_fill_incident(int64_t n_elem, const int32_t *crow, int64_t r0, int64_t r1,
                                 const int64_t *ptr, int32_t *cursor, int32_t *list) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_elem * 8) return;
-    const int32_t nd = conn[t];
-    if (nd < 0 || nd >= n_nodes) return;
-    const int64_t row = perm[nd];
+    const int64_t row = crow[t];   // (a connectivity entry out of range has ended the call before this launch)
     if (row >= r0 && row < r1) {
         const int32_t pos = atomicAdd(&cursor[row - r0], 1);
         list[ptr[row - r0] + pos] = (int32_t)t;  // t = e*8 + a
@@ -127,7 +132,7 @@ __device__ inline int32_t wave_bitonic_sort(int32_t v) {
 // kernel twice, count and fill, and sorted every row both times.)
 __global__ void __launch_bounds__(64)
 k_symbolic(int64_t nloc, int64_t r0, int64_t r1, const int64_t *ptr, int32_t *list,
-           const int32_t *conn, const int32_t *perm, int32_t *rowlen, int32_t *refflag,
+           const int32_t *crow, int32_t *rowlen, int32_t *refflag,
            int32_t *ucols, int64_t *status) {
     __shared__ int32_t ent[64];
     __shared__ int32_t cand[8 * STAN_MAX_INCIDENT];
@@ -158,7 +163,7 @@ k_symbolic(int64_t nloc, int64_t r0, int64_t r1, const int64_t *ptr, int32_t *li
         int32_t c = 0x7fffffff;
         if (i < ncand) {
             const int32_t e = ent[i >> 3] >> 3;
-            c = perm[conn[(int64_t)e * 8 + (i & 7)]];
+            c = crow[(int64_t)e * 8 + (i & 7)];
         }
         cand[i] = c;
     }
@@ -253,39 +258,52 @@ k_window_sort(int64_t npad, int sigma, const int32_t *rowlen, int32_t *rowof, in
     }
 }
 
-// ---- step 2c: columns into the ELL slots.  One wavefront per slice, lane = position: every store
-// is a full 256-B line; a lane walks the contiguous distinct-column run k_symbolic left for its row.
+// ---- step 2c: columns into the ELL slots.  One wavefront per slice.  The distinct columns of a row
+// are a contiguous run in ucols; the slots want them transposed (slot-major, 64 rows side by side).
+// The wave reads its 64 rows one after the other, each as ONE coalesced access, into an LDS tile, then
+// writes slot by slot, every store a full 256-B line.  (The first version let every lane walk its own
+// run: 64 lines touched per load, 8.4 GB fetched for 0.36 GB of columns, 1.2 ms at 148^3.)
 __global__ void __launch_bounds__(256)
 k_fill_cols(int32_t nslices, int64_t nloc, int64_t r0, int64_t r1, const int32_t *slot_ptr,
             const int32_t *rowof, const int32_t *rowlen, const int64_t *ptr, const int32_t *ucols,
-            const int64_t *halo_rank, int32_t *cols) {
-    const int lane = threadIdx.x & 63;
-    const int64_t slice = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (slice >= nslices) return;
+            const int64_t *halo_rank, int32_t *cols, int32_t wmax) {
+    extern __shared__ int32_t tile_all[];   // [4 waves][64 rows][wmax | 1] (odd stride: conflict-free column reads)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t slice = (int64_t)blockIdx.x * 4 + w;
+    if (slice >= nslices) return;   // (no workgroup barrier below: the waves are independent)
+    const int stride = wmax | 1;
+    int32_t *tile = tile_all + (size_t)w * 64 * stride;
     const int64_t row = rowof[slice * 64 + lane];
     const bool live = row < nloc;   // rows >= nloc: padding of the last slice (zero values, column 0)
     const int rl = live ? rowlen[row] : 0;
-    const int32_t *uc = ucols + (live ? 8 * ptr[row] : 0);
-    const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
-    for (int32_t k = k0; k < k1; k++) {
-        int32_t lc = live ? (int32_t)row : 0;   // a row shorter than its slice is padded with its own column
-        if (k - k0 < rl) {
-            const int64_t g = uc[k - k0];
-            lc = (g >= r0 && g < r1) ? (int32_t)(g - r0) : (int32_t)(nloc + halo_rank[g]);
+    const int64_t p8 = live ? 8 * ptr[row] : 0;
+    for (int r = 0; r < 64; r++) {
+        const int rlr = __shfl(rl, r, 64);
+        const int64_t pr = __shfl(p8, r, 64);
+        for (int k = lane; k < rlr; k += 64) {
+            const int64_t g = ucols[pr + k];
+            tile[r * stride + k] = (g >= r0 && g < r1) ? (int32_t)(g - r0) : (int32_t)(nloc + halo_rank[g]);
         }
-        cols[(int64_t)k * 64 + lane] = lc;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
+    const int32_t own = live ? (int32_t)row : 0;   // a row shorter than its slice is padded with its own column
+    for (int32_t k = k0; k < k1; k++)
+        cols[(int64_t)k * 64 + lane] = (k - k0 < rl) ? tile[lane * stride + (k - k0)] : own;
 }
 
 // slice width = longest row of the slice; also accumulates block count and max width
 // (4 slices per workgroup, one atomic pair per workgroup: 51 k same-address atomics were 1.2 ms)
 __global__ void __launch_bounds__(256)
-k_slice_width(int32_t nslices, const int32_t *rowlen, const int32_t *rowof, int32_t *width,
+k_slice_width(int32_t nslices, const int32_t *rowlen, const int32_t *rowof, int32_t *poslen, int32_t *width,
               unsigned long long *nblocks, int32_t *maxw) {
     __shared__ int sh_s[4], sh_m[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t slice = (int64_t)blockIdx.x * 4 + w;
     int v = slice < nslices ? rowlen[rowof[slice * 64 + lane]] : 0;
+    if (slice < nslices) poslen[slice * 64 + lane] = v;   // row length by POSITION: the SpMV's per-lane loop bound
     int s = v;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
@@ -331,9 +349,8 @@ struct numeric_args {
     int64_t nloc, r0, r1, nhalo;
     const int64_t *ptr;
     const int32_t *list;
-    const int32_t *conn;
-    const int32_t *perm;
-    const double *xyz;
+    const int32_t *crow;     // [n_elem*8] global block row of each element node (perm[conn])
+    const double *xrow;      // [nb_glob*3] coordinates by global block row
     const int32_t *elem_mat;
     const uint8_t *elem_type;
     const double *mat_lamG;  // [n_mat*2] lambda, G
@@ -396,7 +413,7 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
     // being paid row by row (first 8 incidences of each row; longer rows load inline).
     int64_t P0[4];
     int DEG[4], RL[4];
-    int32_t EN[4], NB[4], COLG[4], TY[4], MI[4];
+    int32_t EN[4], COLG[4], TY[4], MI[4];
     double X0[4], X1[4], X2[4];
     int64_t ROW[4];
 #pragma unroll
@@ -414,21 +431,20 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int32_t e = EN[i] >> 3;
-        NB[i] = 0; TY[i] = STAN_HEX8_G2; MI[i] = 0;
+        COLG[i] = 0; TY[i] = STAN_HEX8_G2; MI[i] = 0;
         if (s < DEG[i]) {
-            NB[i] = A.conn[(int64_t)e * 8 + b];
+            COLG[i] = A.crow[(int64_t)e * 8 + b];
             TY[i] = A.elem_type[e];
             MI[i] = A.elem_mat[e];
         }
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        COLG[i] = 0; X0[i] = X1[i] = X2[i] = 0.0;
+        X0[i] = X1[i] = X2[i] = 0.0;
         if (s < DEG[i]) {
-            COLG[i] = A.perm[NB[i]];
-            X0[i] = A.xyz[3 * (int64_t)NB[i] + 0];
-            X1[i] = A.xyz[3 * (int64_t)NB[i] + 1];
-            X2[i] = A.xyz[3 * (int64_t)NB[i] + 2];
+            X0[i] = A.xrow[3 * (int64_t)COLG[i] + 0];
+            X1[i] = A.xrow[3 * (int64_t)COLG[i] + 1];
+            X2[i] = A.xrow[3 * (int64_t)COLG[i] + 2];
         }
     }
 
@@ -445,20 +461,19 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
             int32_t e = 0, a = 0, type = STAN_HEX8_G2, colg = 0;
             double lam = 0, G = 0;
             if (valid) {
-                int32_t en, nb, m;
+                int32_t en, m;
                 double x0, x1, x2;
                 if (c0 == 0) {
-                    en = EN[i]; nb = NB[i]; colg = COLG[i]; type = TY[i]; m = MI[i];
+                    en = EN[i]; colg = COLG[i]; type = TY[i]; m = MI[i];
                     x0 = X0[i]; x1 = X1[i]; x2 = X2[i];
                 } else {
                     en = A.list[p0 + c0 + s];
-                    nb = A.conn[(int64_t)(en >> 3) * 8 + b];
-                    colg = A.perm[nb];
+                    colg = A.crow[(int64_t)(en >> 3) * 8 + b];
                     type = A.elem_type[en >> 3];
                     m = A.elem_mat[en >> 3];
-                    x0 = A.xyz[3 * (int64_t)nb + 0];
-                    x1 = A.xyz[3 * (int64_t)nb + 1];
-                    x2 = A.xyz[3 * (int64_t)nb + 2];
+                    x0 = A.xrow[3 * (int64_t)colg + 0];
+                    x1 = A.xrow[3 * (int64_t)colg + 1];
+                    x2 = A.xrow[3 * (int64_t)colg + 2];
                 }
                 e = en >> 3;
                 a = en & 7;
@@ -779,8 +794,10 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     STANCHK(stan_dmalloc(ctx, &K->d_red, (size_t)n_dof));
     HIPCHK(ctx, hipMemsetAsync(K->d_fixmask, 0, (size_t)nb, st));
     HIPCHK(ctx, hipMemcpyAsync(K->d_red, d_red, (size_t)n_dof * 4, hipMemcpyDeviceToDevice, st));
+    double *d_xrow; STANCHK(stan_dmalloc(ctx, &d_xrow, (size_t)nb * 3)); tmp.own(d_xrow);
+    int32_t *d_crow; STANCHK(stan_dmalloc(ctx, &d_crow, (size_t)(n_elem > 0 ? n_elem * 8 : 1))); tmp.own(d_crow);
     hipLaunchKernelGGL(k_perm, dim3(nblk(n_nodes, 256)), dim3(256), 0, st, n_nodes, nb, d_node_dof,
-                       d_red, d_perm, K->d_fixmask, d_status);
+                       d_red, d_xyz, d_perm, K->d_fixmask, d_xrow, d_status);
 
     // incidence lists of owned rows
     int32_t *d_cnt; STANCHK(stan_dmalloc(ctx, &d_cnt, (size_t)nrows_pad + 1)); tmp.own(d_cnt);
@@ -788,7 +805,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, ((size_t)nrows_pad + 1) * 4, st));
     if (n_elem > 0)
         hipLaunchKernelGGL(k_count_incident, dim3(nblk(n_elem * 8, 256)), dim3(256), 0, st, n_elem,
-                           n_nodes, d_conn, d_perm, r0, r1, d_cnt, d_status);
+                           n_nodes, d_conn, d_perm, r0, r1, d_cnt, d_crow, d_status);
     STANCHK(stan_scan_exclusive(ctx, d_cnt, d_ptr, nrows_pad));
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_ERRBITS, d_status + SS_ERRBITS, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_H_NINC, d_ptr + nrows_pad, 8, hipMemcpyDeviceToHost, st));
@@ -806,7 +823,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, ((size_t)nrows_pad + 1) * 4, st));
     if (n_elem > 0)
         hipLaunchKernelGGL(k_fill_incident, dim3(nblk(n_elem * 8, 256)), dim3(256), 0, st, n_elem,
-                           n_nodes, d_conn, d_perm, r0, r1, d_ptr, d_cnt, d_list);
+                           d_crow, r0, r1, d_ptr, d_cnt, d_list);
 
     // symbolic count
     STANCHK(stan_dmalloc(ctx, &K->d_rowlen, (size_t)nrows_pad));
@@ -820,11 +837,12 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     int32_t *d_ucols; STANCHK(stan_dmalloc(ctx, &d_ucols, (size_t)(n_inc > 0 ? 8 * n_inc : 1))); tmp.own(d_ucols);
     if (nrows_pad > 0)
         hipLaunchKernelGGL(k_symbolic, dim3((unsigned)nrows_pad), dim3(64), 0, st, nloc, r0, r1, d_ptr,
-                           d_list, d_conn, d_perm, K->d_rowlen, d_refflag, d_ucols, d_status);
+                           d_list, d_crow, K->d_rowlen, d_refflag, d_ucols, d_status);
     // SELL-C-sigma: positions of the rows inside the sliced layout
     K->sigma = ctx->sell_sigma < 1 ? 1 : ctx->sell_sigma > 32 ? 32 : ctx->sell_sigma;
     STANCHK(stan_dmalloc(ctx, &K->d_rowof, (size_t)(nrows_pad > 0 ? nrows_pad : 1)));
     STANCHK(stan_dmalloc(ctx, &K->d_posof, (size_t)(nrows_pad > 0 ? nrows_pad : 1)));
+    STANCHK(stan_dmalloc(ctx, &K->d_poslen, (size_t)(nrows_pad > 0 ? nrows_pad : 1)));
     if (nrows_pad > 0)
         hipLaunchKernelGGL(k_window_sort, dim3(nblk(K->nslices, K->sigma)), dim3(64), 0, st, nrows_pad, K->sigma,
                            K->d_rowlen, K->d_rowof, K->d_posof);
@@ -845,7 +863,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     HIPCHK(ctx, hipMemsetAsync(d_status + SS_WIDTH_SUM, 0, 16, st));
     if (K->nslices > 0)
         hipLaunchKernelGGL(k_slice_width, dim3(nblk(K->nslices, 4)), dim3(256), 0, st, K->nslices, K->d_rowlen,
-                           K->d_rowof, d_width, (unsigned long long *)(d_status + SS_WIDTH_SUM), (int32_t *)(d_status + SS_WIDTH_MAX));
+                           K->d_rowof, K->d_poslen, d_width, (unsigned long long *)(d_status + SS_WIDTH_SUM), (int32_t *)(d_status + SS_WIDTH_MAX));
     STANCHK(stan_scan_exclusive(ctx, d_width, d_sp64, K->nslices));
     STANCHK(stan_dmalloc(ctx, &K->d_slot_ptr, (size_t)K->nslices + 1));
     hipLaunchKernelGGL(k_i64_to_i32, dim3(nblk(K->nslices + 1, 256)), dim3(256), 0, st, d_sp64,
@@ -868,10 +886,15 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         return STAN_E_ARG;
     }
     STANCHK(stan_dmalloc(ctx, &K->d_cols, (size_t)K->nslots * 64));
-    if (K->nslices > 0)
-        hipLaunchKernelGGL(k_fill_cols, dim3(nblk(K->nslices, 4)), dim3(256), 0, st, K->nslices, nloc, r0, r1,
+    if (K->nslices > 0) {
+        const int32_t wmax = K->max_row_blocks > 0 ? K->max_row_blocks : 1;
+        const size_t lds = (size_t)4 * 64 * (wmax | 1) * sizeof(int32_t);   // <= 4 * 64 * 97 * 4 = 99 KB
+        if (lds > 64 * 1024)
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)k_fill_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_fill_cols, dim3(nblk(K->nslices, 4)), dim3(256), lds, st, K->nslices, nloc, r0, r1,
                            K->d_slot_ptr, K->d_rowof, K->d_rowlen, d_ptr, d_ucols, (const int64_t *)d_halo_rank,
-                           K->d_cols);
+                           K->d_cols, wmax);
+    }
     // (after the columns are in place: an allocation by trial times the SpMV itself, which needs the columns)
     STANCHK(stan_dmalloc_streamed(ctx, (void **)&K->d_vals, (size_t)K->nslots * 9 * 64 * 8,
                                   [&](const void *q, float *ms, bool self) {
@@ -888,7 +911,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         ctx->prof_colours = 0;
         numeric_args A;
         A.nloc = nloc; A.r0 = r0; A.r1 = r1; A.nhalo = K->nhalo;
-        A.ptr = d_ptr; A.list = d_list; A.conn = d_conn; A.perm = d_perm; A.xyz = d_xyz;
+        A.ptr = d_ptr; A.list = d_list; A.crow = d_crow; A.xrow = d_xrow;
         A.elem_mat = d_elem_mat; A.elem_type = d_elem_type; A.mat_lamG = d_lamG;
         A.fixmask = K->d_fixmask; A.halo_glob = K->d_halo_glob; A.halo_rank = d_halo_rank;
         A.rowlen = K->d_rowlen; A.rowof = K->d_rowof; A.slot_ptr = K->d_slot_ptr; A.cols = K->d_cols; A.vals = K->d_vals;

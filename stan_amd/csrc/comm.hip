@@ -197,6 +197,25 @@ int stan_comm_allgather_rows(stan_ctx *ctx, stan_matrix *K, double *d_full) {
     return STAN_OK;
 }
 
+// small host-side all-gather over the communicator (control plane of the peer-to-peer set-up: IPC handles):
+// every rank contributes `bytes` bytes, all [nranks * bytes] come back; synchronises the ranks
+int stan_comm_allgather_bytes(stan_ctx *ctx, const void *mine, size_t bytes, void *all) {
+    void *comm = comm_for_call(ctx);
+    if (!comm) return no_comm(ctx);
+    unsigned char *d = nullptr;
+    const size_t tot = bytes * (size_t)ctx->nranks;
+    HIPCHK(ctx, hipMalloc((void **)&d, tot));
+    struct F { void *p; ~F() { hipFree(p); } } fr{d};
+    HIPCHK(ctx, hipMemcpyAsync(d + bytes * (size_t)ctx->rank, mine, bytes, hipMemcpyHostToDevice, ctx->stream));
+    NCCLCHK(ctx, ctx->nccl.GroupStart());
+    for (int r = 0; r < ctx->nranks; r++)
+        NCCLCHK(ctx, ctx->nccl.Broadcast(d + bytes * (size_t)r, d + bytes * (size_t)r, bytes, 1 /* ncclUint8 */, r, comm, ctx->stream));
+    NCCLCHK(ctx, ctx->nccl.GroupEnd());
+    HIPCHK(ctx, hipMemcpyAsync(all, d, tot, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return STAN_OK;
+}
+
 // A peer rank failed while this one may be blocked in a collective: abort the communicator so that
 // its queued work returns (ncclCommAbort), and refuse every later collective on this context.
 // Called from the group's HOST thread while the rank's worker may be inside the solve: the pointer is

@@ -153,6 +153,14 @@ struct stan_p2p {                   // host side, shared by the ranks of a group
         std::vector<int64_t> recv_off;
     };
     std::vector<rank_res> rk;
+    // process-per-GPU form (stan_p2p_ipc_setup): this process owns ONE rank; the other ranks' mailboxes,
+    // counters and vectors are device memory of other processes mapped through HIP IPC handles, which the
+    // ranks exchange over the RCCL communicator they already have (no change to the host application)
+    bool ipc = false;
+    int ipc_me = -1;
+    void *ipc_block = nullptr;                     // own mailbox + counters: one fine-grained allocation, one handle
+    std::vector<void *> ipc_peer_block;            // mapped blocks of the peers
+    std::unordered_map<std::string, void *> ipc_open;   // vectors of peers mapped so far, by handle bytes
     // host barrier of the worker threads (abortable)
     std::mutex m;
     std::condition_variable cv;
@@ -168,6 +176,8 @@ void stan_p2p_destroy(stan_p2p *pp);
 void stan_p2p_abort(stan_p2p *pp);                 // frees every stream wait and every host barrier
 int stan_p2p_barrier(stan_p2p *pp);                // STAN_E_COMM when aborted / timed out
 struct stan_ctx;
+int stan_p2p_ipc_setup(stan_ctx *ctx);             // collective over the context's RCCL communicator
+void stan_p2p_ipc_release(stan_ctx *ctx);
 struct stan_matrix;
 int stan_p2p_reduce_slot(stan_ctx *ctx);           // mailbox slot / counter of this rank's NEXT reduction
 int stan_p2p_reduce_wait(stan_ctx *ctx);           // stream-ordered wait for it (advances the slot)
@@ -244,6 +254,7 @@ struct stan_matrix {
     int32_t *d_rowlen = nullptr;    // [nslices*64] blocks per row (by local row)
     int32_t *d_rowof = nullptr;     // [nslices*64] SELL-C-sigma: position in the sliced layout -> local block row
     int32_t *d_posof = nullptr;     // [nslices*64] local block row -> position (slice = pos / 64, lane = pos % 64)
+    int32_t *d_poslen = nullptr;    // [nslices*64] blocks of the row at each position (the SpMV's per-lane loop bound)
     int sigma = 1;                  // sorting window in slices the matrix was built with
     int32_t *d_cols = nullptr;      // [nslots][64] local block-column index
     uint32_t *d_cols16 = nullptr;   // packed column stream of the SpMV (cg.hip colstream): [pair][64]
@@ -326,6 +337,7 @@ int stan_recover_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz, con
 // ---- comm.cpp -------------------------------------------------------------------------------
 int stan_comm_allreduce_sum_f64(stan_ctx *ctx, double *d_buf, size_t count);
 int stan_comm_info(stan_ctx *ctx, int *version, int *count, int *rank);
+int stan_comm_allgather_bytes(stan_ctx *ctx, const void *mine, size_t bytes, void *all);   // host buffers, [nranks*bytes] out
 // exchange: pack rows listed in K->d_send_rows from d_vec (3 doubles per block row) and
 // receive into d_vec + 3*nloc (halo region).
 int stan_comm_halo_exchange(stan_ctx *ctx, stan_matrix *K, double *d_vec);

@@ -13,6 +13,8 @@
 // = 4 kernels, 3 stream waits, no RCCL launch (RCCL path: 4 kernels + 3 collective launches).
 // The waits are hipStreamWaitValue64 on signal memory where the device offers it (the command
 // processor waits, no wavefront spins), else a one-wave polling kernel on a device flag.
+#include <unistd.h>
+
 #include <chrono>
 
 #include "internal.h"
@@ -236,11 +238,164 @@ const double *stan_p2p_mailbox(stan_ctx *ctx, int slot) {
     return ctx->p2p->rk[(size_t)ctx->rank].mbox + (size_t)slot * ctx->p2p->n * 4;
 }
 
+// ---- process-per-GPU form: the same exchanges between PROCESSES, peers mapped through HIP IPC -----------
+namespace {
+constexpr size_t CTR_STRIDE = 128;   // one counter per 128-B line
+size_t ipc_mbox_bytes(int n) { return ((size_t)STAN_P2P_RING * n * 4 * sizeof(double) + 255) & ~(size_t)255; }
+size_t ipc_block_bytes(int n) { return ipc_mbox_bytes(n) + 2 * STAN_P2P_RING * CTR_STRIDE; }
+void ipc_carve(stan_p2p::rank_res &r, void *block, int n) {
+    r.mbox = (double *)block;
+    unsigned char *c = (unsigned char *)block + ipc_mbox_bytes(n);
+    for (int s = 0; s < STAN_P2P_RING; s++) {
+        r.sig_red[s] = (unsigned long long *)(c + (size_t)s * CTR_STRIDE);
+        r.sig_halo[s] = (unsigned long long *)(c + (size_t)(STAN_P2P_RING + s) * CTR_STRIDE);
+    }
+}
+struct ipc_hello { hipIpcMemHandle_t h; int32_t device, pid; };
+struct ipc_vectors {   // what a rank publishes at the start of a solve
+    hipIpcMemHandle_t h[5];
+    int64_t nloc;
+    int32_t n_nbr, pad;
+    int32_t nbr[STAN_P2P_MAXR];
+    int64_t recv_off[STAN_P2P_MAXR + 1];
+};
+}  // namespace
+
+int stan_p2p_ipc_setup(stan_ctx *ctx) {
+    if (ctx->p2p) return STAN_OK;
+    const int n = ctx->nranks;
+    if (n < 2 || n > STAN_P2P_MAXR) { ctx->err = "peer-to-peer exchanges need 2.." + std::to_string(STAN_P2P_MAXR) + " ranks"; return STAN_E_UNSUPPORTED; }
+    stan_p2p *pp = new stan_p2p();
+    pp->n = n; pp->ipc = true; pp->ipc_me = ctx->rank;
+    pp->rk.resize((size_t)n);
+    pp->ipc_peer_block.assign((size_t)n, nullptr);
+    struct guard { stan_p2p *p; stan_ctx *c; bool ok = false; ~guard() { if (!ok) { c->p2p = p; stan_p2p_ipc_release(c); } } } g{pp, ctx};
+    stan_p2p::rank_res &me = pp->rk[(size_t)ctx->rank];
+    me.device = ctx->device;
+    // counters are plain fine-grained device memory here (signal memory cannot be shared between processes);
+    // hipStreamWaitValue64 takes them on this stack (profiles/r03/waitvalue_probe_*.txt) -- checked below
+    const size_t bytes = ipc_block_bytes(n);
+    if (hipExtMallocWithFlags(&pp->ipc_block, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->err = "peer-to-peer set-up: no fine-grained device memory";
+        return STAN_E_ALLOC;
+    }
+    HIPCHK(ctx, hipMemset(pp->ipc_block, 0, bytes));
+    ipc_carve(me, pp->ipc_block, n);
+    int can_wait = 0;
+    pp->wait_mode = 1;
+    if (hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, ctx->device) == hipSuccess && can_wait &&
+        hipStreamWaitValue64(ctx->stream, me.sig_red[0], 0, hipStreamWaitValueGte, ~0ULL) == hipSuccess &&
+        hipStreamSynchronize(ctx->stream) == hipSuccess)
+        pp->wait_mode = 0;
+    (void)hipGetLastError();
+    if (const char *m = getenv("STAN_P2P_WAIT_MODE")) pp->wait_mode = atoi(m) ? 1 : 0;
+    // every rank must end up in the same mode only for its own waits: no agreement needed
+    ipc_hello mine{};
+    if (hipIpcGetMemHandle(&mine.h, pp->ipc_block) != hipSuccess) {
+        ctx->err = std::string("peer-to-peer set-up: hipIpcGetMemHandle: ") + hipGetErrorString(hipGetLastError());
+        return STAN_E_HIP;
+    }
+    mine.device = ctx->device; mine.pid = (int32_t)getpid();
+    std::vector<ipc_hello> all((size_t)n);
+    STANCHK(stan_comm_allgather_bytes(ctx, &mine, sizeof(mine), all.data()));
+    for (int q = 0; q < n; q++) {
+        if (q == ctx->rank) continue;
+        pp->rk[(size_t)q].device = all[(size_t)q].device;
+        if (all[(size_t)q].pid == mine.pid) { ctx->err = "peer-to-peer set-up: two ranks in one process: use stan_hip_init_multi"; return STAN_E_UNSUPPORTED; }
+        void *b = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&b, all[(size_t)q].h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->err = "peer-to-peer set-up: hipIpcOpenMemHandle(rank " + std::to_string(q) + "): " + hipGetErrorString(e);
+            return STAN_E_HIP;
+        }
+        pp->ipc_peer_block[(size_t)q] = b;
+        ipc_carve(pp->rk[(size_t)q], b, n);
+    }
+    if (hipMalloc((void **)&me.d_dev, sizeof(stan_p2p_dev)) != hipSuccess || hipMalloc((void **)&me.d_tick, 128) != hipSuccess ||
+        hipMemset(me.d_tick, 0, 128) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->err = "peer-to-peer tables: hipMalloc failed";
+        return STAN_E_ALLOC;
+    }
+    std::string why;
+    if (stan_p2p_rank_finish(pp, ctx->rank, &why) != STAN_OK) { ctx->err = why; return STAN_E_HIP; }
+    g.ok = true;
+    ctx->p2p = pp;
+    return STAN_OK;
+}
+
+void stan_p2p_ipc_release(stan_ctx *ctx) {
+    stan_p2p *pp = ctx->p2p;
+    if (!pp || !pp->ipc) return;
+    hipSetDevice(ctx->device);
+    for (auto &kv : pp->ipc_open) if (kv.second) hipIpcCloseMemHandle(kv.second);
+    for (void *b : pp->ipc_peer_block) if (b) hipIpcCloseMemHandle(b);
+    stan_p2p::rank_res &me = pp->rk[(size_t)pp->ipc_me];
+    if (me.d_dev) hipFree(me.d_dev);
+    if (me.d_tick) hipFree(me.d_tick);
+    if (pp->ipc_block) hipFree(pp->ipc_block);
+    (void)hipGetLastError();
+    delete pp;
+    ctx->p2p = nullptr;
+    ctx->comm_p2p = false;
+}
+
+// IPC form of the publication: handles of my five vectors + my halo plan to everybody (a collective: it
+// also is the barrier), the peers' vectors mapped (once per allocation: cached by handle)
+static int ipc_publish_vectors(stan_ctx *ctx, const stan_matrix *K, double *const vec[5]) {
+    stan_p2p *pp = ctx->p2p;
+    const int n = pp->n;
+    ipc_vectors mine{};
+    for (int i = 0; i < 5; i++)
+        if (hipIpcGetMemHandle(&mine.h[i], vec[i]) != hipSuccess) {
+            ctx->err = std::string("peer-to-peer halo: hipIpcGetMemHandle: ") + hipGetErrorString(hipGetLastError());
+            return STAN_E_HIP;
+        }
+    mine.nloc = K->nloc;
+    mine.n_nbr = (int32_t)K->nbr.size();
+    for (size_t i = 0; i < K->nbr.size(); i++) mine.nbr[i] = K->nbr[i];
+    for (size_t i = 0; i < K->recv_off.size() && i <= (size_t)STAN_P2P_MAXR; i++) mine.recv_off[i] = K->recv_off[i];
+    std::vector<ipc_vectors> all((size_t)n);
+    STANCHK(stan_comm_allgather_bytes(ctx, &mine, sizeof(mine), all.data()));
+    for (int q = 0; q < n; q++) {
+        stan_p2p::rank_res &r = pp->rk[(size_t)q];
+        const ipc_vectors &v = all[(size_t)q];
+        r.nloc = v.nloc;
+        r.nbr.assign(v.nbr, v.nbr + v.n_nbr);
+        r.recv_off.assign(v.recv_off, v.recv_off + v.n_nbr + 1);
+        if (q == ctx->rank) { for (int i = 0; i < 5; i++) r.vec[i] = vec[i]; continue; }
+        // only the vectors of my neighbours are ever written to
+        bool nbr_of_mine = false;
+        for (int x : K->nbr) nbr_of_mine |= x == q;
+        for (int i = 0; i < 5; i++) {
+            r.vec[i] = nullptr;
+            if (!nbr_of_mine) continue;
+            const std::string key((const char *)&v.h[i], sizeof(hipIpcMemHandle_t));
+            auto it = pp->ipc_open.find(key);
+            if (it == pp->ipc_open.end()) {
+                void *m = nullptr;
+                const hipError_t e = hipIpcOpenMemHandle(&m, v.h[i], hipIpcMemLazyEnablePeerAccess);
+                if (e != hipSuccess) {
+                    (void)hipGetLastError();
+                    ctx->err = "peer-to-peer halo: hipIpcOpenMemHandle(rank " + std::to_string(q) + "): " + hipGetErrorString(e);
+                    return STAN_E_HIP;
+                }
+                it = pp->ipc_open.emplace(key, m).first;
+            }
+            r.vec[i] = (double *)it->second;
+        }
+    }
+    return STAN_OK;
+}
+
 // what my neighbours need to know before they write into my vectors; host barrier behind it
 int stan_p2p_publish_vectors(stan_ctx *ctx, const stan_matrix *K, double *const vec[5]) {
     stan_p2p *pp = ctx->p2p;
     stan_p2p::rank_res &me = pp->rk[(size_t)ctx->rank];
     if ((int)K->nbr.size() >= STAN_P2P_MAXR) { ctx->err = "peer-to-peer halo: too many neighbour ranks"; return STAN_E_UNSUPPORTED; }
+    if (pp->ipc) return ipc_publish_vectors(ctx, K, vec);
     for (int i = 0; i < 5; i++) me.vec[i] = vec[i];
     me.nloc = K->nloc;
     me.nbr = K->nbr;

@@ -92,3 +92,24 @@ def star_mesh(k=5, layers=3, rings=2, h=1.0):
                          q[0] + (z + 1) * n2, q[1] + (z + 1) * n2, q[2] + (z + 1) * n2,
                          q[3] + (z + 1) * n2])
     return xyz.astype(np.float64), np.array(conn, dtype=np.int32)
+
+
+def perforated_mesh(n, frac, seed=7):
+    """An IRREGULAR test mesh at a chosen size: the n^3 cube with a fraction `frac` of its elements knocked
+    out at random (the mesh class of tests/fuzz.py), largest connected component kept, unused nodes dropped.
+    Row lengths of K then vary from node to node (Database.ReadNastranMesh admits any CHEXA mesh,
+    Database.cs:39-111).  Returns xyz [n_nodes,3] float64 and conn [n_elem,8] int32."""
+    import scipy.sparse as sp
+    import scipy.sparse.csgraph
+    xyz, conn = cube_mesh(n)
+    rng = np.random.default_rng(seed)
+    conn = conn[rng.random(conn.shape[0]) >= frac]
+    ne = conn.shape[0]
+    inc = sp.csr_matrix((np.ones(ne * 8, dtype=np.int8), (np.repeat(np.arange(ne), 8), conn.ravel())),
+                        shape=(ne, xyz.shape[0]))
+    _, lab = sp.csgraph.connected_components((inc @ inc.T).tocsr(), directed=False)
+    conn = conn[lab == np.argmax(np.bincount(lab))]
+    used = np.unique(conn)
+    new = np.full(xyz.shape[0], -1, dtype=np.int64)
+    new[used] = np.arange(used.shape[0])
+    return xyz[used], new[conn].astype(np.int32)

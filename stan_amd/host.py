@@ -221,6 +221,15 @@ class Db:
         self._chk(self.lib.stan_host_db_write_stdb(self.h, os.fsencode(path), C.c_int32(int(packed))),
                   "write_stdb")
 
+    def write_stdb_with_results(self, path, disp, strain, stress, packed=False):
+        """ExportOutput straight from flat result arrays (same bytes as set_results + write_stdb)."""
+        disp = np.ascontiguousarray(disp, dtype=np.float64)
+        strain = np.ascontiguousarray(strain, dtype=np.float64)
+        stress = np.ascontiguousarray(stress, dtype=np.float64)
+        self._chk(self.lib.stan_host_db_write_stdb_with_results(
+            self.h, os.fsencode(path), C.c_int32(int(packed)), _p(disp, C.c_double), _p(strain, C.c_double),
+            _p(stress, C.c_double)), "write_stdb_with_results")
+
     def serialize(self, packed=False):
         n = C.c_int64(0)
         self._chk(self.lib.stan_host_db_serialize(self.h, C.c_int32(int(packed)), None, C.c_int64(0),

@@ -35,6 +35,17 @@ int stan_host_db_write_stdb(stan_db *d, const char *path, int32_t packed) {
     if (!d || !path) return STAN_HOST_E_ARG;
     return WriteStdb(d->db, path, packed != 0, &d->err) ? STAN_HOST_OK : STAN_HOST_E_IO;
 }
+int stan_host_db_write_stdb_with_results(stan_db *d, const char *path, int32_t packed, const double *disp,
+                                         const double *strain, const double *stress) {
+    if (!d || !path || !disp || !strain || !stress) return STAN_HOST_E_ARG;
+    d->db.results.disp = disp; d->db.results.strain = strain; d->db.results.stress = stress;
+    const int prev = d->db.AnalysisLib.Result_StepNo;
+    d->db.AnalysisLib.Result_StepNo = 1;   // Solver.cs:56
+    const bool ok = WriteStdb(d->db, path, packed != 0, &d->err);
+    d->db.results = Database::ResultView();
+    d->db.AnalysisLib.Result_StepNo = prev;
+    return ok ? STAN_HOST_OK : STAN_HOST_E_IO;
+}
 int stan_host_db_serialize(stan_db *d, int32_t packed, uint8_t *buf, int64_t cap, int64_t *size) {
     if (!d || !size) return STAN_HOST_E_ARG;
     std::string s;

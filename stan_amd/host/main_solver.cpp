@@ -46,7 +46,7 @@ static int fail(const char *what, const std::string &msg) {
 int main(int argc, char **argv) {
     std::string path;
     int device = 0, precision = STAN_PREC_FP64, placement_tries = 16;
-    bool merit_stop = true, packed = false, json = false;
+    bool merit_stop = true, packed = false, json = false, object_results = false;
     std::vector<int> devices;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
@@ -67,6 +67,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--no-merit-stop")) merit_stop = false;
         else if (!strcmp(argv[i], "--packed")) packed = true;
         else if (!strcmp(argv[i], "--json")) json = true;
+        else if (!strcmp(argv[i], "--object-results")) object_results = true;
         else path = argv[i];
     }
     if (path.empty()) {  // Path = path[0] -> IndexOutOfRangeException in the reference
@@ -154,8 +155,15 @@ int main(int argc, char **argv) {
         if (json) stan_hip_get_profile(K.ctx, &pr);
         // Solver.cs:81-90 (initialise step 0/1), :203-210 (update), Main :56
         t0 = clk::now();
+        // Solver.cs:81-90, 203-210: every node / element object is initialised and updated with the results, then
+        // ExportOutput serialises the objects.  By default the writer takes the results from the flat arrays
+        // instead (Database::ResultView: the same bytes without 13 million small heap objects);
+        // --object-results walks the reference's object path (tests/test_gpu_parity.py compares the files).
+        if (!object_results) {
+            DB.results.disp = disp.data(); DB.results.strain = strain.data(); DB.results.stress = stress.data();
+        }
         auto &nodes = DB.NodeLib.Items();
-        parallel_ranges(nodes.size(), [&](size_t a, size_t b) {
+        if (object_results) parallel_ranges(nodes.size(), [&](size_t a, size_t b) {
             for (size_t i = a; i < b; i++) {
                 Node &n = nodes[i].second;
                 n.Initialize_StepZero();
@@ -165,7 +173,7 @@ int main(int argc, char **argv) {
             }
         });
         auto &elems = DB.ElemLib.Items();
-        parallel_ranges(elems.size(), [&](size_t a, size_t b) {
+        if (object_results) parallel_ranges(elems.size(), [&](size_t a, size_t b) {
             for (size_t i = a; i < b; i++) {
                 Element &e = elems[i].second;
                 e.Initialize_StepZero();

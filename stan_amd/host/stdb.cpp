@@ -141,17 +141,46 @@ void enc_entry(int key, const T &v, bool packed, std::string &o) {  // map entry
     enc(v, packed, t);
     w.bytes(2, t);
 }
+// node / element with the results of increment 1 taken from flat arrays (Database::ResultView): the same
+// bytes as enc() of an object that went through the reference's initialise / update calls
+void enc_with_results(const Node &n, size_t i, const Database::ResultView &rv, bool packed, std::string &o) {
+    W w{o, packed};
+    w.i32(1, n.ID); w.f64(2, n.X); w.f64(3, n.Y); w.f64(4, n.Z);
+    w.rep_i32(5, n.EList); w.rep_i32(6, n.DOF);
+    thread_local std::vector<double> d(2, 0.0);   // {Disp[0] = 0, Disp[1] = 0 + dU}
+    for (int c = 0; c < 3; c++) { d[1] = 0.0 + rv.disp[3 * i + (size_t)c]; w.rep_f64(7 + c, d); }
+}
+void enc_with_results(const Element &e, size_t i, const Database::ResultView &rv, bool packed, std::string &o) {
+    W w{o, packed};
+    w.i32(1, e.ID); w.str(2, e.Type, e.has_type); w.i32(3, e.PID); w.i32(4, e.MatID);
+    w.rep_i32(5, e.NList);
+    thread_local std::string t;
+    thread_local MatrixST zero(8, 6), cur(8, 6);
+    t.clear(); enc(zero, packed, t); w.bytes(6, t);
+    memcpy(cur.M.data(), rv.strain + 48 * i, 48 * sizeof(double));
+    t.clear(); enc(cur, packed, t); w.bytes(6, t);
+    t.clear(); enc(zero, packed, t); w.bytes(7, t);
+    memcpy(cur.M.data(), rv.stress + 48 * i, 48 * sizeof(double));
+    t.clear(); enc(cur, packed, t); w.bytes(7, t);
+}
+template <typename T>
+void enc_with_results(const T &v, size_t, const Database::ResultView &, bool packed, std::string &o) { enc(v, packed, o); }
+inline bool has_results(const Node &, const Database::ResultView *rv) { return rv && rv->disp; }
+inline bool has_results(const Element &e, const Database::ResultView *rv) { return rv && rv->strain && rv->stress && e.NList.size() == 8; }
+template <typename T> inline bool has_results(const T &, const Database::ResultView *) { return false; }
+
 // field `field` of the root message for entries [i0, i1) of a library, appended to o
 template <typename T>
 void enc_lib_range(int field, const std::vector<std::pair<int, T>> &items, size_t i0, size_t i1, bool packed,
-                   std::string &o) {
+                   std::string &o, const Database::ResultView *rv = nullptr) {
     W w{o, packed};
     std::string entry, val;
     for (size_t i = i0; i < i1; i++) {
         entry.clear(); val.clear();
         W we{entry, packed};
         we.i32(1, items[i].first);
-        enc(items[i].second, packed, val);
+        if (has_results(items[i].second, rv)) enc_with_results(items[i].second, i, *rv, packed, val);
+        else enc(items[i].second, packed, val);
         we.bytes(2, val);
         w.bytes(field, entry);
     }
@@ -380,7 +409,8 @@ namespace {
 // One library to the file: chunks of entries are encoded by `threads` workers and written by the calling
 // thread in order; at most `window` encoded chunks wait for the writer (bounded memory whatever the model size).
 template <typename T>
-bool write_lib(FILE *fp, int field, const std::vector<std::pair<int, T>> &items, bool packed, int threads) {
+bool write_lib(FILE *fp, int field, const std::vector<std::pair<int, T>> &items, bool packed, int threads,
+               const Database::ResultView *rv = nullptr) {
     const size_t n = items.size();
     if (n == 0) return true;
     constexpr size_t CHUNK = 4096;
@@ -390,7 +420,7 @@ bool write_lib(FILE *fp, int field, const std::vector<std::pair<int, T>> &items,
         bool ok = true;
         for (size_t c = 0; c < nchunks && ok; c++) {
             buf.clear();
-            enc_lib_range(field, items, c * CHUNK, std::min(n, (c + 1) * CHUNK), packed, buf);
+            enc_lib_range(field, items, c * CHUNK, std::min(n, (c + 1) * CHUNK), packed, buf, rv);
             ok = fwrite(buf.data(), 1, buf.size(), fp) == buf.size();
         }
         return ok;
@@ -414,7 +444,7 @@ bool write_lib(FILE *fp, int field, const std::vector<std::pair<int, T>> &items,
             }
             std::string &buf = ring[c % window];
             buf.clear();
-            enc_lib_range(field, items, c * CHUNK, std::min(n, (c + 1) * CHUNK), packed, buf);
+            enc_lib_range(field, items, c * CHUNK, std::min(n, (c + 1) * CHUNK), packed, buf, rv);
             std::lock_guard<std::mutex> lk(m);
             ready[c % window] = 1;
             cv.notify_all();
@@ -452,8 +482,9 @@ bool WriteStdb(const Database &db, const std::string &path, bool packed, std::st
     iobuf.resize(8u << 20);
     setvbuf(fp, iobuf.data(), _IOFBF, iobuf.size());
     const int threads = HostThreads();
-    bool ok = write_lib(fp, 1, db.NodeLib.Items(), packed, threads);
-    ok = ok && write_lib(fp, 2, db.ElemLib.Items(), packed, threads);
+    const Database::ResultView *rv = (db.results.disp || db.results.strain) ? &db.results : nullptr;
+    bool ok = write_lib(fp, 1, db.NodeLib.Items(), packed, threads, rv);
+    ok = ok && write_lib(fp, 2, db.ElemLib.Items(), packed, threads, rv);
     ok = ok && write_lib(fp, 3, db.MatLib.Items(), packed, 1);
     ok = ok && write_lib(fp, 4, db.BCLib.Items(), packed, 1);
     std::string buf;

@@ -4,7 +4,7 @@ Solver.Main / SolverLinearStatics perform before calling the hot path
 import numpy as np
 
 from . import host
-from .cube import cube_bcs, cube_mesh
+from .cube import cube_bcs, cube_mesh, perforated_mesh
 
 HEX8_G1, HEX8_G2 = 1, 2
 
@@ -41,3 +41,12 @@ def cube_job(n, etype=HEX8_G2, h=1.0, jitter=0.0, clamp_faces=None, E=210000.0, 
     spc_vals = np.ones((spc.shape[0], 3))
     load_vals = np.tile(f, (ld.shape[0], 1))
     return make_job(xyz, conn, spc, spc_vals, ld, load_vals, etype=etype, E=E, nu=nu)
+
+
+def perforated_job(n, frac, seed=7, etype=HEX8_G2):
+    """The cube job on cube.perforated_mesh: clamp the nodes with x = 0, PointLoad (0,0,50) on x = n."""
+    xyz, conn = perforated_mesh(n, frac, seed)
+    spc = np.nonzero(xyz[:, 0] == 0.0)[0].astype(np.int32)
+    ld = np.nonzero(xyz[:, 0] == float(n))[0].astype(np.int32)
+    return make_job(xyz, conn, spc, np.ones((spc.shape[0], 3)), ld,
+                    np.tile(np.array([0.0, 0.0, 50.0]), (ld.shape[0], 1)), etype=etype)

@@ -11,6 +11,7 @@ import torch.distributed as dist  # noqa: E402
 from stan_amd import hip, problem  # noqa: E402
 
 spec, out_dir, overlap = sys.argv[1], sys.argv[2], int(sys.argv[3])
+p2p = len(sys.argv) > 4 and sys.argv[4] == "p2p"   # exchanges peer to peer between the PROCESSES (HIP IPC)
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 if spec.startswith("fuzz:"):   # tests/fuzz.py job: shuffled wire order, several neighbours, empty ranks
@@ -23,6 +24,10 @@ box = [ctx.unique_id() if rank == 0 else None]
 dist.broadcast_object_list(box, 0)
 ctx.comm_init(rank, world, box[0])
 ctx.set_option(hip.OPT_OVERLAP_HALO, overlap)
+if p2p:
+    ctx.set_option(hip.OPT_COMM_P2P, 1)    # a collective: the IPC handles travel over the communicator
+    assert ctx.comm_info()["p2p"]
+    ctx.set_profiling(True)
 K = ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
 info = K.info()
 res = {}
@@ -30,6 +35,9 @@ for tag, eps, prec in (("fp64", 1e-6, hip.PREC_FP64), ("mixed", 1e-5, hip.PREC_M
                        ("fixed48", 1e-6, hip.PREC_FIXED48)):
     U, rep = K.cg_solve(job.F, eps, precision_mode=prec)
     res[tag] = (U, rep)
+    if p2p:
+        pr = ctx.profile()
+        assert pr["loop_collectives"] == 0 and pr["loop_stream_waits"] > 0, (pr["loop_collectives"], pr["loop_stream_waits"])
 np.savez(os.path.join(out_dir, "rank%d.npz" % rank), U=res["fp64"][0], Um=res["mixed"][0],
          Ux=res["fixed48"][0], its_x=res["fixed48"][1]["iterations"],
          its=res["fp64"][1]["iterations"], term=res["fp64"][1]["terminationtype"],

@@ -168,10 +168,14 @@ def test_cg_parity_with_oracle(gpu_ctx, oracle, n, etype):
         U, rep = K.cg_solve(job.F, eps)
         Uo, repo = oracle.cg(A, job.F, eps)
         assert rep["terminationtype"] == repo["terminationtype"]
-        tol = U_TOL if eps == 1e-12 else 1e-3   # at loose eps both stop O(kappa*eps) from the solution
-        if etype == 1:
-            tol *= 20   # G1 has no hourglass control: kappa is ~100x larger, both stop on the type-7 floor
-        assert np.abs(U - Uo).max() <= tol * np.abs(Uo).max()
+        # Both sides stop within kappa * eps of the solution of the same system, so they are within
+        # 2 kappa eps of each other.  kappa = condition number of the Jacobi-scaled matrix S K S, measured:
+        # 12.7 n^2 for the x-clamped G2 cube (tools/cpu_sizes.py, profiles/r02/cpu_sizes_n100_*.jsonl),
+        # 2.4 n^4 for G1, which has no hourglass control (profiles/r02/CONFIG5.md).  (Rounds 1-2 allowed
+        # 1e-3 / 2e-2 here; the same recurrences in fact agree far better: 3e-11 at 56^3, 8.5e-11 at 148^3.)
+        kappa = 12.7 * n * n if etype == 2 else 2.4 * n ** 4
+        tol = max(U_TOL, 2 * kappa * eps)
+        assert np.abs(U - Uo).max() <= tol * np.abs(Uo).max(), (np.abs(U - Uo).max() / np.abs(Uo).max(), tol)
         # same algorithm => iteration counts agree up to rounding-induced drift
         # (a type-7 stop sits on the rounding floor, where the count is noise-dependent)
         slack = 10 if rep["terminationtype"] == 1 else 4

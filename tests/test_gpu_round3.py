@@ -159,9 +159,24 @@ one.close(); ctx.close()
     assert "ERR -8 True" in p.stdout and "ERR1 -8" in p.stdout, p.stdout
 
 
+def _run_script(code, env, timeout):
+    """A child python process whose output survives a hang: on timeout the process is killed and what it had
+    printed so far is shown (the scripts print with flush)."""
+    p = subprocess.Popen([sys.executable, "-u", "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         env=env, cwd=ROOT)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        out, err = p.communicate()
+        raise AssertionError("child timed out after %d s; stdout so far:\n%s\nstderr:\n%s" % (timeout, out[-3000:], err[-3000:]))
+    return p.returncode, out, err
+
+
 def test_a_failing_rank_does_not_hang_the_peer_to_peer_loop(built_libs):
-    """The peers of a rank that fails are blocked in stream waits, not in RCCL: the group releases every
-    wait (the arrival counters jump), the surviving loops see the flag at their next poll."""
+    """The peers of a rank that fails are blocked in stream waits / the host barrier of the publication, not
+    in RCCL: the group releases every wait (the arrival counters jump), wakes the barrier, the surviving
+    loops see the flag at their next poll."""
     code = r'''
 import os, sys, time
 sys.path.insert(0, %r)
@@ -169,30 +184,34 @@ import numpy as np, torch
 from stan_amd import hip, problem
 job = problem.cube_job(10)
 ctx = hip.Context(devices=[0, 0, 0])
+print("CONTEXT", flush=True)
 ctx.set_option(hip.OPT_COMM_P2P, 1)
 K = ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+print("ASSEMBLED", flush=True)
 U, rep = K.cg_solve(job.F, 1e-6)
+print("SOLVED", rep, flush=True)
 assert rep["terminationtype"] == 1
 os.environ["STAN_TEST_FAIL_RANK"] = "1"
 t0 = time.time()
 try:
     K.cg_solve(job.F, 1e-8)
-    print("NOERROR")
+    print("NOERROR", flush=True)
 except hip.StanHipError as e:
-    print("ERR1", e.code, "rank 1" in str(e), "%%.1f" %% (time.time() - t0))
+    print("ERR1", e.code, "rank 1" in str(e), "%%.1f" %% (time.time() - t0), flush=True)
 del os.environ["STAN_TEST_FAIL_RANK"]
 try:
     K.cg_solve(job.F, 1e-8)
-    print("NOERROR")
+    print("NOERROR", flush=True)
 except hip.StanHipError as e:
-    print("ERR2", e.code, "aborted" in str(e))
-K.free(); ctx.close()
-print("CLOSED")
+    print("ERR2", e.code, "aborted" in str(e), flush=True)
+K.free()
+print("FREED", flush=True)
+ctx.close()
+print("CLOSED", flush=True)
 ''' % ROOT
     env = dict(os.environ, STAN_RCCL_LIB=FAKE, GPU_MAX_HW_QUEUES="12")
-    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
-    out = p.stdout
-    assert p.returncode == 0, out[-2000:] + p.stderr[-3000:]
+    rc, out, err = _run_script(code, env, 150)
+    assert rc == 0, out[-2000:] + err[-3000:]
     l1 = [l for l in out.splitlines() if l.startswith("ERR1")][0].split()
     assert l1[1] == "-1" and l1[2] == "True" and float(l1[3]) < 60.0
     l2 = [l for l in out.splitlines() if l.startswith("ERR2")][0].split()
@@ -213,3 +232,40 @@ def test_group_solve_leaves_every_rank_its_own_segment(built_libs, oracle, tmp_p
     rc, A = oracle.assemble(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
     Uo, rep = oracle.cg(A, job.F, 1e-6)
     assert np.abs(d["U"] - Uo).max() <= 1e-4 * np.abs(Uo).max() and np.all(d["U"][job.F != 0] != 0)
+
+
+def test_console_driver_flat_result_writer_writes_the_object_path_bytes(built_libs, tmp_path):
+    """stan_solver (Solver.Main, Solver.cs:18-69) by default serialises the results straight from the flat
+    arrays the GPU returned (Database::ResultView) instead of first copying them into 4 MatrixST per element
+    (Solver.cs:81-90, 203-210): the output file must be byte-identical to the object path's
+    (--object-results), unpacked and packed; --json carries the host phase times."""
+    from stan_amd import host
+    from stan_amd.cube import cube_bcs, cube_mesh
+    exe = os.path.join(ROOT, "stan_amd", "bin", "stan_solver")
+    n = 7
+    xyz, conn = cube_mesh(n, jitter=0.1)
+    files = {}
+    for mode in ("flat", "object", "flat_packed", "object_packed"):
+        d = host.Db()
+        ne = conn.shape[0]
+        d.set_mesh(np.arange(1, xyz.shape[0] + 1), xyz, np.arange(1, ne + 1), np.ones(ne), conn + 1, "HEX8_G2")
+        d.add_material(1, "Steel", 210000.0, 0.3)
+        d.assign_part(1, 1, "HEX8_G2")
+        spc, ld, f = cube_bcs(n)
+        d.add_bc(1, "fix", "SPC", spc + 1, np.ones((len(spc), 3)))
+        d.add_bc(2, "load", "PointLoad", ld + 1, np.tile(f, (len(ld), 1)))
+        d.set_analysis(tol=1e-10)
+        path = str(tmp_path / (mode + ".STdb"))
+        d.write_stdb(path)
+        args = [exe, "--json"] + (["--object-results"] if mode.startswith("object") else []) + \
+               (["--packed"] if mode.endswith("packed") else []) + [path]
+        out = subprocess.run(args, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        js = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+        assert set(js["phases_s"]) >= {"read_parse", "assign_dof", "store_results", "serialize_write"} and js["t_wall_s"] > 0
+        files[mode] = open(path, "rb").read()
+    assert files["flat"] == files["object"] and files["flat_packed"] == files["object_packed"]
+    assert len(files["flat_packed"]) < len(files["flat"])
+    r = host.Db.read_stdb(str(tmp_path / "flat.STdb"))
+    disp, strain, stress = r.results(1)
+    assert np.abs(disp).max() > 0 and np.abs(stress).max() > 0

@@ -83,6 +83,25 @@ def test_sharded_solve_matches_oracle(built_libs, oracle, tmp_path, world, overl
     assert all(r[2] > 0 for r in rows if r[1] > r[0])     # every rank that owns rows has a halo
 
 
+@pytest.mark.parametrize("world,spec", [(2, "12"), (3, "12"), (4, "fuzz:124")])
+def test_sharded_solve_peer_to_peer_between_processes(built_libs, tmp_path, world, spec):
+    """STAN_OPT_COMM_P2P with one PROCESS per rank (what bench.py --gpus N --p2p runs under the launcher): the
+    ranks map each other's mailboxes, arrival counters and gather vectors through HIP IPC handles that travel
+    over the communicator they already have; the loop then makes no RCCL call.  Same bits as the RCCL path
+    (rank-ordered sums on both sides), every rank the same U."""
+    a, b = tmp_path / "rccl", tmp_path / "p2p"
+    a.mkdir(); b.mkdir()
+    out = _torchrun(world, [os.path.join(ROOT, "tests", "sharded_worker.py"), spec, str(a), "1"], {})
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    out = _torchrun(world, [os.path.join(ROOT, "tests", "sharded_worker.py"), spec, str(b), "1", "p2p"], {})
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    for r in range(world):
+        da, db = np.load(str(a / ("rank%d.npz" % r))), np.load(str(b / ("rank%d.npz" % r)))
+        assert int(da["its"]) == int(db["its"]) and int(da["term"]) == int(db["term"]) == 1
+        for k in ("U", "Um", "Ux"):
+            assert np.array_equal(da[k], db[k]), (r, k)
+
+
 def test_bench_multi_rank_code_path(built_libs):
     """bench.py --gpus 2 (gloo control plane, both ranks on GPU 0): one JSON line, converged."""
     out = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",

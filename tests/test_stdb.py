@@ -213,3 +213,31 @@ def test_results_file_streams_through_the_flush_boundary(built_libs, tmp_path):
     d.write_stdb(path, packed=True)
     assert os.path.getsize(path) < 0.95 * size
     assert host.Db.read_stdb(path).serialize() == d.serialize()
+
+
+def test_flat_result_writer_writes_the_object_path_bytes(built_libs, tmp_path):
+    """stan_host_db_write_stdb_with_results (what stan_solver uses by default): the results go from the flat
+    arrays straight into the encoder.  Same file as initialising / updating every Node and Element object
+    first (Solver.cs:81-90, 203-210) and serialising those, unpacked and packed, including negative zeros."""
+    n = 9
+    d, xyz, conn = _cube_db(n)
+    d.assign_dof()
+    rng = np.random.default_rng(3)
+    disp = rng.standard_normal((xyz.shape[0], 3))
+    disp[0, 0] = -0.0; disp[1, 1] = 0.0
+    strain = rng.standard_normal((n ** 3, 8, 6))
+    stress = rng.standard_normal((n ** 3, 8, 6))
+    stress[0, 0, 0] = -0.0
+    for packed in (False, True):
+        a, b = str(tmp_path / "flat.STdb"), str(tmp_path / "obj.STdb")
+        d.write_stdb_with_results(a, disp, strain, stress, packed=packed)
+        before = d.serialize()
+        d2, _, _ = _cube_db(n)
+        d2.assign_dof()
+        d2.set_results(disp, strain, stress)
+        d2.write_stdb(b, packed=packed)
+        assert open(a, "rb").read() == open(b, "rb").read()
+        assert d.serialize() == before            # the database itself is unchanged
+    r = host.Db.read_stdb(a)
+    d1, e1, s1 = r.results(1)
+    assert np.array_equal(d1, disp + 0.0) and np.array_equal(e1, strain) and np.array_equal(s1, stress)

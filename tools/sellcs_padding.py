@@ -10,23 +10,7 @@ from stan_amd import host
 from stan_amd.cube import cube_mesh
 
 
-def perforated(n, frac, seed=7):
-    xyz, conn = cube_mesh(n)
-    rng = np.random.default_rng(seed)
-    keep = rng.random(conn.shape[0]) >= frac
-    conn = conn[keep]
-    # keep the largest connected component (AssignDOF needs a connected mesh)
-    ne = conn.shape[0]
-    rows = np.repeat(np.arange(ne), 8)
-    inc = sp.csr_matrix((np.ones(ne * 8, dtype=np.int8), (rows, conn.ravel())), shape=(ne, xyz.shape[0]))
-    ee = (inc @ inc.T).tocsr()
-    ncomp, lab = sp.csgraph.connected_components(ee, directed=False)
-    big = np.argmax(np.bincount(lab))
-    conn = conn[lab == big]
-    used = np.unique(conn)
-    new = np.full(xyz.shape[0], -1, dtype=np.int64)
-    new[used] = np.arange(used.shape[0])
-    return xyz[used], new[conn].astype(np.int32)
+from stan_amd.cube import perforated_mesh as perforated
 
 
 def rowlens(n_nodes, conn, idx):
