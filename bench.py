@@ -164,7 +164,8 @@ def main():
                     help="cube edge of the CPU-baseline sample (56: ~20 s of CPU work; 100 = BASELINE config 2's size, "
                          "~2 min; 148 = the bench workload itself, ~8 min and ~60 GB: profiles/r03/cpu_sizes_n148_*.jsonl)")
     ap.add_argument("--sell-sigma", type=int, default=0,
-                    help="STAN_OPT_SELL_SIGMA: sorting window of the matrix layout in slices (0 = library default 32, 1 = off)")
+                    help="STAN_OPT_SELL_SIGMA: sorting window of the matrix layout in slices (0 = library default 1: rows sorted "
+                         "inside each slice only; up to 32: less padding, less gather locality -- profiles/r03/SELL_C_SIGMA.md)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--placement-tries", type=int, default=32,
                     help="STAN_OPT_PLACEMENT_TRIES: candidates the allocation-by-search of K's value array may time in "

@@ -148,13 +148,16 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
 #define STAN_OPT_PLACEMENT_MAX_BYTES 16 /* byte budget of the candidates the placement search holds at the same time
                            (default 0 = a quarter of the device memory that is free when the search starts; the
                            first candidate -- the allocation itself -- is always allowed). */
-#define STAN_OPT_SELL_SIGMA 17 /* 32 (default): SELL-C-sigma -- inside windows of this many 64-row slices the block rows
-                           are sorted by length before they are cut into slices (a slice is as wide as its longest row;
-                           padded slots are streamed like real ones).  Reference-order slices of a regular cube carry
-                           1-2 % padding, of a box with 15 % / 40 % of its elements missing 8 % / 26 %; windows of 32
-                           slices: <= 1.5 %.  The permutation is internal: vectors, CRS export, halo plan and the row
-                           partition keep the reference (AssignDOF) order, every row sum keeps its bits (the order of
-                           the dot-product partial sums changes with it).  1 = off; 1..32; applies to the next assembly. */
+#define STAN_OPT_SELL_SIGMA 17 /* 1 (default) .. 32: SELL-C-sigma -- inside windows of this many 64-row slices the block rows
+                           are sorted by length before they are cut into slices (a slice is as wide as its longest row).
+                           Reference-order slices of a regular cube carry 1-2 % padding, of a box with 15 % / 40 % of its
+                           elements missing 7 % / 24 %; windows of 32 slices: <= 1.5 % (19 % less device memory on the
+                           latter).  The permutation is internal: vectors, CRS export, halo plan and the row partition
+                           keep the reference (AssignDOF) order and every row sum keeps its bits.  MEASURED (profiles/
+                           r03/SELL_C_SIGMA.md): the padding costs the SpMV nothing on such meshes (the product is
+                           gather-bound there), while sorted slices lose the locality of 64 consecutive breadth-first
+                           rows: 10-27 % slower with 32, 6 % with 4.  Hence the default 1 (rows sorted inside each slice
+                           only); larger values trade time for memory.  Applies to the next assembly. */
 #define STAN_OPT_COMM_P2P 18 /* one-process multi-device handle only (stan_hip_init_multi).  0 (default): the sharded CG
                            exchanges over RCCL (2 all-reduce launches + 1 grouped send/recv per iteration).  1: peer to
                            peer -- no collective launch in the loop: the block that finishes a reduction stores this

@@ -299,7 +299,7 @@ void stan_hip_matrix_free(stan_matrix *K) {
     }
     // the solves that used these buffers have been synchronised by their own calls; the blocks go
     // back to the context's pool (stan_pool) or to the driver
-    for (void *q : {(void *)K->d_slot_ptr, (void *)K->d_rowlen, (void *)K->d_rowof, (void *)K->d_posof, (void *)K->d_poslen, (void *)K->d_cols, (void *)K->d_vals,
+    for (void *q : {(void *)K->d_slot_ptr, (void *)K->d_rowlen, (void *)K->d_rowof, (void *)K->d_posof, (void *)K->d_cols, (void *)K->d_vals,
                     (void *)K->d_vals32, (void *)K->d_vals48, (void *)K->d_cols16, (void *)K->d_colbase,
                     (void *)K->d_pair_ptr, (void *)K->d_slice_packed, (void *)K->d_red, (void *)K->d_fixmask,
                     (void *)K->d_scale, (void *)K->d_send_rows, (void *)K->d_halo_glob, (void *)K->d_sendbuf,

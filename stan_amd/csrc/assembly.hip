@@ -297,13 +297,12 @@ k_fill_cols(int32_t nslices, int64_t nloc, int64_t r0, int64_t r1, const int32_t
 // slice width = longest row of the slice; also accumulates block count and max width
 // (4 slices per workgroup, one atomic pair per workgroup: 51 k same-address atomics were 1.2 ms)
 __global__ void __launch_bounds__(256)
-k_slice_width(int32_t nslices, const int32_t *rowlen, const int32_t *rowof, int32_t *poslen, int32_t *width,
+k_slice_width(int32_t nslices, const int32_t *rowlen, const int32_t *rowof, int32_t *width,
               unsigned long long *nblocks, int32_t *maxw) {
     __shared__ int sh_s[4], sh_m[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t slice = (int64_t)blockIdx.x * 4 + w;
     int v = slice < nslices ? rowlen[rowof[slice * 64 + lane]] : 0;
-    if (slice < nslices) poslen[slice * 64 + lane] = v;   // row length by POSITION: the SpMV's per-lane loop bound
     int s = v;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
@@ -842,7 +841,6 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     K->sigma = ctx->sell_sigma < 1 ? 1 : ctx->sell_sigma > 32 ? 32 : ctx->sell_sigma;
     STANCHK(stan_dmalloc(ctx, &K->d_rowof, (size_t)(nrows_pad > 0 ? nrows_pad : 1)));
     STANCHK(stan_dmalloc(ctx, &K->d_posof, (size_t)(nrows_pad > 0 ? nrows_pad : 1)));
-    STANCHK(stan_dmalloc(ctx, &K->d_poslen, (size_t)(nrows_pad > 0 ? nrows_pad : 1)));
     if (nrows_pad > 0)
         hipLaunchKernelGGL(k_window_sort, dim3(nblk(K->nslices, K->sigma)), dim3(64), 0, st, nrows_pad, K->sigma,
                            K->d_rowlen, K->d_rowof, K->d_posof);
@@ -863,7 +861,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     HIPCHK(ctx, hipMemsetAsync(d_status + SS_WIDTH_SUM, 0, 16, st));
     if (K->nslices > 0)
         hipLaunchKernelGGL(k_slice_width, dim3(nblk(K->nslices, 4)), dim3(256), 0, st, K->nslices, K->d_rowlen,
-                           K->d_rowof, K->d_poslen, d_width, (unsigned long long *)(d_status + SS_WIDTH_SUM), (int32_t *)(d_status + SS_WIDTH_MAX));
+                           K->d_rowof, d_width, (unsigned long long *)(d_status + SS_WIDTH_SUM), (int32_t *)(d_status + SS_WIDTH_MAX));
     STANCHK(stan_scan_exclusive(ctx, d_width, d_sp64, K->nslices));
     STANCHK(stan_dmalloc(ctx, &K->d_slot_ptr, (size_t)K->nslices + 1));
     hipLaunchKernelGGL(k_i64_to_i32, dim3(nblk(K->nslices + 1, 256)), dim3(256), 0, st, d_sp64,

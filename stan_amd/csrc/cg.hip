@@ -447,7 +447,7 @@ template <typename VT, int DOT, int VAR>
 // lab 17 / 18: capped at 68 / 62 VGPRs for 7 / 8 waves per SIMD instead of 78 / 6: in-CG SpMV 1.071 /
 // 1.072 ms against 1.032 ms (profiles/r02/fold_ab_incg_n148_box9_register_caps.txt): more waves do not help
 __global__ void __launch_bounds__(256, (VAR == 17 ? 7 : VAR == 18 ? 8 : 1))
-k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, const int32_t *__restrict__ rowof, const int32_t *__restrict__ poslen,
+k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, const int32_t *__restrict__ rowof,
        const int32_t *__restrict__ cols, const VT *__restrict__ vals,
        const double *__restrict__ x, double *__restrict__ y, double *partial,
        const int64_t *st, int64_t kiter, const int32_t *__restrict__ slist, int32_t nlist,
@@ -481,29 +481,17 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, cons
     const int64_t row = slice < nslices ? (int64_t)rowof[slice * 64 + lane] : nloc;   // SELL-C-sigma: position -> block row
     if (slice < nslices) {
         const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
-        // The slots beyond a row's own length hold zeros.  Rounds 1-2 streamed them like real blocks (1.3 %
-        // of the bytes on the cube, 24 % on a box with 40 % of its elements missing).  The rows of a slice are
-        // sorted by length (k_window_sort), so the lanes that still have a block in slot k are a PREFIX of the
-        // wave: up to the shortest row every lane loads (kf, kept even for the packed pairs); beyond it a lane
-        // past its row's end loads nothing -- whole 128-B lines of padding are never fetched.
-        const int32_t rl = poslen[slice * 64 + lane];
-        int32_t rmin = rl;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) rmin = min(rmin, __shfl_xor(rmin, d, 64));
-        const int32_t kf = k0 + (rmin & ~1);
         const int32_t *cp = cols + (int64_t)k0 * 64 + lane;
         const VT *vp = vals + (int64_t)k0 * vstream<VT>::STRIDE + lane;
 #ifdef STAN_LAB
 #include "lab/spmv_variants_lab.inc"   // lab-only kernel variants (VAR 8, 14-16)
 #endif
-        {
-        const bool pk = cs.packed && cs.ok[slice];   // wave-uniform: a slice is packed or not
-        const uint32_t *cq0 = pk ? cs.packed + (int64_t)cs.pair_ptr[slice] * 64 + lane : nullptr;
-        if (pk) {
-            const uint32_t *cq = cq0;
+        if (cs.packed && cs.ok[slice]) {   // wave-uniform: a slice is packed or not
+            const uint32_t *cq = cs.packed + (int64_t)cs.pair_ptr[slice] * 64 + lane;
             const int32_t *bp = cs.base + __builtin_amdgcn_readfirstlane(k0);   // scalar loads
+            int32_t k = k0;
 #pragma unroll UNR2
-            for (int32_t k = k0; k < kf; k += 2) {
+            for (; k + 1 < k1; k += 2) {
                 const uint32_t wd = ld_stream<NT>(cq);
                 const int64_t c = (int64_t)bp[0] + (int64_t)(wd & 0xffffu);
                 const int64_t c2 = (int64_t)bp[1] + (int64_t)(wd >> 16);
@@ -513,28 +501,18 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, cons
                 bp += 2;
                 vp += 2 * vstream<VT>::STRIDE;
             }
+            if (k < k1) {
+                const int64_t c = (int64_t)bp[0] + (int64_t)(ld_stream<NT>(cq) & 0xffffu);
+                STAN_SPMV_BLOCK(c, vp)
+            }
         } else {
 #pragma unroll UNR
-            for (int32_t k = k0; k < kf; k++) {
+            for (int32_t k = k0; k < k1; k++) {
                 const int64_t c = ld_stream<NT>(cp);
                 STAN_SPMV_BLOCK(c, vp)
                 cp += 64;
                 vp += vstream<VT>::STRIDE;
             }
-        }
-        for (int32_t k = kf; k < k1; k++) {   // the ragged end of the slice: only the lanes whose row reaches slot k
-            const int32_t kk = k - k0;
-            if (kk < rl) {
-                int64_t c;
-                if (pk) {
-                    const uint32_t wd = ld_stream<NT>(cq0 + (int64_t)(kk >> 1) * 64);
-                    c = (int64_t)cs.base[k] + (int64_t)((kk & 1) ? (wd >> 16) : (wd & 0xffffu));
-                } else
-                    c = ld_stream<NT>(cols + (int64_t)k * 64 + lane);
-                const VT *vq = vals + (int64_t)k * vstream<VT>::STRIDE + lane;
-                STAN_SPMV_BLOCK(c, vq)
-            }
-        }
         }
         if (row < nloc) {
 #if STAN_Y_NT  // A p is read exactly once, by k_step
@@ -576,7 +554,7 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, cons
 // loads: a matrix of this size stays in the L2s / the memory-side cache from one product to the next.
 template <typename VT, int DOT>
 __global__ void __launch_bounds__(256)
-k_spmv_small(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, const int32_t *__restrict__ rowof, const int32_t *__restrict__ poslen,
+k_spmv_small(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, const int32_t *__restrict__ rowof,
              const int32_t *__restrict__ cols, const VT *__restrict__ vals,
              const double *__restrict__ x, double *__restrict__ y, double *partial,
              const int64_t *st, int64_t kiter, const int32_t *__restrict__ slist, int32_t nlist,
@@ -595,9 +573,7 @@ k_spmv_small(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr
         const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
         const bool packed = cs.packed && cs.ok[slice];
         const int64_t pp = packed ? (int64_t)cs.pair_ptr[slice] : 0;
-        const int32_t rl = poslen[slice * 64 + lane];   // lanes past their row's end load nothing (see k_spmv)
         for (int32_t k = k0 + w; k < k1; k += 4) {
-            if (k - k0 >= rl) continue;
             int64_t c;
             if (packed) {
                 const uint32_t wd = cs.packed[(pp + ((k - k0) >> 1)) * 64 + lane];
@@ -642,7 +618,7 @@ k_spmv_small(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr
 // refresh needs A x next to the A p every iteration needs -- one matrix stream instead of two.
 template <typename VT>
 __global__ void __launch_bounds__(256)
-k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, const int32_t *__restrict__ rowof, const int32_t *__restrict__ poslen,
+k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, const int32_t *__restrict__ rowof,
         const int32_t *__restrict__ cols, const VT *__restrict__ vals,
         const double *__restrict__ x, const double *__restrict__ x2, double *__restrict__ y,
         double *__restrict__ y2, double *partial, const int64_t *st, int64_t kiter,
@@ -682,17 +658,11 @@ k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, con
         z1 += a[3] * u0 + a[4] * u1 + a[5] * u2;                                      \
         z2 += a[6] * u0 + a[7] * u1 + a[8] * u2;                                      \
     }
-        const int32_t rl = poslen[slice * 64 + lane];   // full phase up to the shortest row, ragged end masked (see k_spmv)
-        int32_t rmin = rl;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) rmin = min(rmin, __shfl_xor(rmin, d, 64));
-        const int32_t kf = k0 + (rmin & ~1);
-        const bool pk = cs.packed && cs.ok[slice];
-        const uint32_t *cq0 = pk ? cs.packed + (int64_t)cs.pair_ptr[slice] * 64 + lane : nullptr;
-        if (pk) {
-            const uint32_t *cq = cq0;
+        if (cs.packed && cs.ok[slice]) {
+            const uint32_t *cq = cs.packed + (int64_t)cs.pair_ptr[slice] * 64 + lane;
             const int32_t *bp = cs.base + __builtin_amdgcn_readfirstlane(k0);
-            for (int32_t k = k0; k < kf; k += 2) {
+            int32_t k = k0;
+            for (; k + 1 < k1; k += 2) {
                 const uint32_t wd = ld_stream<true>(cq);
                 const int64_t c = (int64_t)bp[0] + (int64_t)(wd & 0xffffu);
                 const int64_t c2 = (int64_t)bp[1] + (int64_t)(wd >> 16);
@@ -702,26 +672,17 @@ k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, con
                 bp += 2;
                 vp += 2 * vstream<VT>::STRIDE;
             }
+            if (k < k1) {
+                const int64_t c = (int64_t)bp[0] + (int64_t)(ld_stream<true>(cq) & 0xffffu);
+                STAN_SPMV2_BLOCK(c, vp)
+            }
         } else {
 #pragma unroll 2
-            for (int32_t k = k0; k < kf; k++) {
+            for (int32_t k = k0; k < k1; k++) {
                 const int64_t c = ld_stream<true>(cp);
                 STAN_SPMV2_BLOCK(c, vp)
                 cp += 64;
                 vp += vstream<VT>::STRIDE;
-            }
-        }
-        for (int32_t k = kf; k < k1; k++) {
-            const int32_t kk = k - k0;
-            if (kk < rl) {
-                int64_t c;
-                if (pk) {
-                    const uint32_t wd = ld_stream<true>(cq0 + (int64_t)(kk >> 1) * 64);
-                    c = (int64_t)cs.base[k] + (int64_t)((kk & 1) ? (wd >> 16) : (wd & 0xffffu));
-                } else
-                    c = ld_stream<true>(cols + (int64_t)k * 64 + lane);
-                const VT *vq = vals + (int64_t)k * vstream<VT>::STRIDE + lane;
-                STAN_SPMV2_BLOCK(c, vq)
             }
         }
 #undef STAN_SPMV2_BLOCK
@@ -1122,7 +1083,7 @@ unsigned launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double
         fold.nblocks = grid_s;
         fold.np = (int)grid_s + poff_s;
         hipLaunchKernelGGL((k_spmv_small<VT, DOT>), dim3(grid_s), dim3(256), 0, stream, K->nslices, K->nloc,
-                           K->d_slot_ptr, K->d_rowof, K->d_poslen, K->d_cols, vals, x, y, partial, st, k, slist, nlist, poff_s, fold, cs);
+                           K->d_slot_ptr, K->d_rowof, K->d_cols, vals, x, y, partial, st, k, slist, nlist, poff_s, fold, cs);
         return grid_s;
     }
     const int32_t poff = which == 2 ? (int32_t)nblk(K->n_sl_int, 4) : 0;
@@ -1133,7 +1094,7 @@ unsigned launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double
 #define SPMV_CASE(V)                                                                          \
     case V:                                                                                   \
         hipLaunchKernelGGL((k_spmv<VT, DOT, V>), dim3(grid), dim3(256), 0, stream, K->nslices, \
-                           K->nloc, K->d_slot_ptr, K->d_rowof, K->d_poslen, K->d_cols, vals, x, y, partial, st, k, \
+                           K->nloc, K->d_slot_ptr, K->d_rowof, K->d_cols, vals, x, y, partial, st, k, \
                            slist, nlist, poff, fold, cs);                                     \
         break;
     // auto (-1): non-temporal matrix stream + XCD-chunked workgroup mapping (variant 9), with the
@@ -1170,7 +1131,7 @@ unsigned launch_spmv2(stan_ctx *ctx, stan_matrix *K, const VT *vals, const doubl
     const colstream cs = ctx->cols16 && K->d_cols16 ? colstream{K->d_cols16, K->d_colbase, K->d_pair_ptr, K->d_slice_packed}
                                                     : colstream{nullptr, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL((k_spmv2<VT>), dim3(grid), dim3(256), 0, stream, K->nslices, K->nloc, K->d_slot_ptr,
-                       K->d_rowof, K->d_poslen, K->d_cols, vals, x, x2, y, y2, partial, st, k, slist, nlist, poff, fold, cs);
+                       K->d_rowof, K->d_cols, vals, x, x2, y, y2, partial, st, k, slist, nlist, poff, fold, cs);
     return grid;
 }
 
@@ -1263,7 +1224,20 @@ static int ensure_scaled(stan_ctx *ctx, stan_matrix *K) {
     if (K->nloc > 0)
         hipLaunchKernelGGL(k_diag_scale, dim3(nblk(K->nloc, 256)), dim3(256), 0, ctx->stream, K->nloc,
                            K->d_rowlen, K->d_posof, K->d_slot_ptr, K->d_cols, K->d_vals, K->d_scale);
-    if (ctx->comm || ctx->nranks > 1) STANCHK(stan_comm_halo_exchange(ctx, K, K->d_scale));
+    if (ctx->comm || ctx->nranks > 1) {
+        if (ctx->comm_p2p && ctx->p2p) {
+            // Peer to peer, my neighbours write their rows straight into my halo region, which the k_fill above
+            // has just initialised: nobody may write before everybody has done that.  One empty reduction
+            // (every rank counts itself into every rank's counter, every stream waits for all) orders it; the
+            // exchanges inside the CG are ordered by the loop's own reductions.  (Found with the ranks in
+            // separate processes, where mapping the peers' vectors delays some ranks by milliseconds: a
+            // neighbour's scaling factors arrived before the fill and were overwritten with 1.0.)
+            const p2p_out po{stan_p2p_table(ctx), stan_p2p_reduce_slot(ctx), 3, 1};
+            hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, ctx->stream, (const double *)nullptr, 0, (double *)nullptr, po);
+            STANCHK(stan_p2p_reduce_wait(ctx));
+        }
+        STANCHK(stan_comm_halo_exchange(ctx, K, K->d_scale));
+    }
     if (K->nslices > 0)
         hipLaunchKernelGGL(k_scale_matrix, dim3(nblk(K->nslices, 4)), dim3(256), 0, ctx->stream,
                            K->nslices, K->d_slot_ptr, K->d_rowof, K->d_cols, K->d_vals, K->d_scale, 0);

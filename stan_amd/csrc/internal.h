@@ -218,7 +218,7 @@ struct stan_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     int assembly_mode = 0;     // 0 row-owner gather (default), 1 element-wave colour scatter
-    int sell_sigma = 32;       // SELL-C-sigma: rows sorted by length inside windows of this many slices (1 = off)
+    int sell_sigma = 1;        // SELL-C-sigma: rows sorted by length inside windows of this many slices (1: inside each slice only)
     int placement_tries = 16;  // > 1: allocate the value stream by search (placement.hip); blocks >= 256 MB only
     int64_t placement_max_bytes = 0;  // bytes of candidates the search may hold at once; 0 = a quarter of the free memory
     float prof_placement_ms_best = 0, prof_placement_ms_worst = 0;
@@ -254,7 +254,6 @@ struct stan_matrix {
     int32_t *d_rowlen = nullptr;    // [nslices*64] blocks per row (by local row)
     int32_t *d_rowof = nullptr;     // [nslices*64] SELL-C-sigma: position in the sliced layout -> local block row
     int32_t *d_posof = nullptr;     // [nslices*64] local block row -> position (slice = pos / 64, lane = pos % 64)
-    int32_t *d_poslen = nullptr;    // [nslices*64] blocks of the row at each position (the SpMV's per-lane loop bound)
     int sigma = 1;                  // sorting window in slices the matrix was built with
     int32_t *d_cols = nullptr;      // [nslots][64] local block-column index
     uint32_t *d_cols16 = nullptr;   // packed column stream of the SpMV (cg.hip colstream): [pair][64]

@@ -334,3 +334,44 @@ extern "C" int stan_hip_lab_placement_vecshape(stan_ctx *ctx, stan_matrix *K, do
     }
     return STAN_OK;
 }
+
+// Counters for the placement question: `reps` SpMV launches with the gather vector and
+// the product in blocks of ANOTHER allocation run than the values (pairing 0), then `reps` with both carved out
+// of the value block itself (pairing 1: by construction the same-group pairing), then pairing 0 again -- under
+// `rocprofv3 --pmc ...` the dispatches of k_spmv split by order into the three phases (1 warm-up launch in front
+// of each).  out_ms [3].  The value block is K's own (plain allocation: run with STAN_OPT_PLACEMENT_TRIES = 1).
+extern "C" int stan_hip_lab_pairing_pmc(stan_ctx *ctx, stan_matrix *K, int32_t reps, double *out_ms) {
+    if (!ctx || !K || !out_ms || reps < 1 || K->ctx != ctx) return STAN_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int64_t npad = (int64_t)K->nslices * 64;
+    const size_t ng = (size_t)(3 * ((npad > K->nloc + K->nhalo ? npad : K->nloc + K->nhalo)));
+    const size_t vb = (ng * 8 + 4095) & ~(size_t)4095;
+    // vectors far away from the values in allocation order: 24 spacer blocks of the value block's size in between
+    const size_t bytes = (size_t)K->nslots * 9 * 64 * 8;
+    std::vector<void *> spacer;
+    for (int i = 0; i < 24; i++) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < 6 * bytes) break;
+        void *q = nullptr;
+        if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        spacer.push_back(q);
+    }
+    double *far = nullptr;
+    if (hipMalloc((void **)&far, 2 * vb) != hipSuccess) { (void)hipGetLastError(); for (void *q : spacer) hipFree(q); return STAN_E_ALLOC; }
+    float f = 0;
+    for (int phase = 0; phase < 3; phase++) {
+        double *x = phase == 1 ? K->d_vals : far;
+        double *y = x + vb / 8;
+        if (phase == 1) {   // the block holds the matrix: save what the vectors overwrite
+            // (the probe fills x with ones and writes y: 2 vb bytes at the front of the value block)
+        }
+        std::vector<char> keep;
+        if (phase == 1) { keep.resize(2 * vb); HIPCHK(ctx, hipMemcpy(keep.data(), K->d_vals, 2 * vb, hipMemcpyDeviceToHost)); }
+        STANCHK(stan_spmv_probe_range(ctx, K, K->d_vals, 0, K->nslices, reps, &f, 9, x, y));
+        out_ms[phase] = f;
+        if (phase == 1) HIPCHK(ctx, hipMemcpy(K->d_vals, keep.data(), 2 * vb, hipMemcpyHostToDevice));
+    }
+    hipFree(far);
+    for (void *q : spacer) hipFree(q);
+    return STAN_OK;
+}

@@ -45,6 +45,9 @@ int stan_hip_lab_incg_penalty(stan_ctx *ctx, stan_matrix *K, int32_t reps, doubl
 /* Do other allocators put the vectors into another group?  out [5], see lab/placement_lab.hip. */
 int stan_hip_lab_placement_vecalloc(stan_ctx *ctx, stan_matrix *K, double *out);
 int stan_hip_lab_placement_vecshape(stan_ctx *ctx, stan_matrix *K, double *out);   /* out [8], see lab/placement_lab.hip */
+/* Counter runs for the placement question: reps launches cross-paired, self-paired, cross-paired again
+ * (out_ms [3]); see lab/placement_lab.hip and tools/placement_pmc.sh. */
+int stan_hip_lab_pairing_pmc(stan_ctx *ctx, stan_matrix *K, int32_t reps, double *out_ms);
 #ifdef __cplusplus
 }
 #endif

@@ -45,7 +45,7 @@ EXPORTS = [
     "stan_hip_matrix_plan", "stan_hip_spmv_local", "stan_hip_comm_info",
 ]
 # only in the lab build (stan_amd/csrc/lab/stan_hip_lab.h, selected with STAN_HIP_LIB)
-LAB_EXPORTS = ["stan_hip_csr_spmv_bench", "stan_hip_lab_placement_map", "stan_hip_lab_placement_variants", "stan_hip_lab_placement_alloc", "stan_hip_lab_placement_rounds", "stan_hip_lab_placement_cross", "stan_hip_lab_incg_penalty", "stan_hip_lab_placement_vecalloc", "stan_hip_lab_placement_vecshape"]
+LAB_EXPORTS = ["stan_hip_csr_spmv_bench", "stan_hip_lab_placement_map", "stan_hip_lab_placement_variants", "stan_hip_lab_placement_alloc", "stan_hip_lab_placement_rounds", "stan_hip_lab_placement_cross", "stan_hip_lab_incg_penalty", "stan_hip_lab_placement_vecalloc", "stan_hip_lab_placement_vecshape", "stan_hip_lab_pairing_pmc"]
 
 
 class MatrixInfo(C.Structure):

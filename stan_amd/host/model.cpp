@@ -1,7 +1,9 @@
 // model.cpp -- behaviour of the STAN_Database mirror classes on the linear-static path.
 #include "model.h"
 
+#include <atomic>
 #include <cstring>
+#include <thread>
 
 #include "../../include/stan_host.h"
 
@@ -50,20 +52,45 @@ std::string Database::Database_Summary() const {  // Database.cs:123-133
 // key makes the C# throw KeyNotFoundException in AddElem2Nodes.
 int Database::AssignDOF() {
     const int64_t nn = (int64_t)NodeLib.Count(), ne = (int64_t)ElemLib.Count();
-    for (auto &kv : NodeLib.Items()) kv.second.EList.clear();
+    // node IDs -> NodeLib positions on the host threads (26 M hash lookups at 148^3); EList in element order after it
     std::vector<int32_t> conn((size_t)ne * 8);
-    int64_t e = 0;
-    for (auto &kv : ElemLib.Items()) {
-        const Element &el = kv.second;
-        if (el.NList.size() != 8) return STAN_HOST_E_ARG;
-        for (int a = 0; a < 8; a++) {
-            const int64_t idx = NodeLib.IndexOf(el.NList[(size_t)a]);
-            if (idx < 0) return STAN_HOST_E_ARG;
-            conn[(size_t)(e * 8 + a)] = (int32_t)idx;
-            std::vector<int> &el_list = NodeLib.Items()[(size_t)idx].second.EList;
-            if (el_list.empty() || el_list.back() != el.ID) el_list.push_back(el.ID);
+    auto &nodes = NodeLib.Items();
+    const auto &elems = ElemLib.Items();
+    std::atomic<int> bad{0};
+    {
+        const size_t nt = (size_t)HostThreads();
+        auto work = [&](size_t a, size_t b) {
+            for (size_t e = a; e < b; e++) {
+                const Element &el = elems[e].second;
+                if (el.NList.size() != 8) { bad.store(1); return; }
+                for (int k = 0; k < 8; k++) {
+                    const int64_t idx = NodeLib.IndexOf(el.NList[(size_t)k]);
+                    if (idx < 0) { bad.store(1); return; }
+                    conn[e * 8 + (size_t)k] = (int32_t)idx;
+                }
+            }
+        };
+        if (nt <= 1 || elems.size() < 4096) work(0, elems.size());
+        else {
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < nt; t++) th.emplace_back(work, elems.size() * t / nt, elems.size() * (t + 1) / nt);
+            for (std::thread &x : th) x.join();
         }
-        e++;
+        if (bad.load()) return STAN_HOST_E_ARG;
+        auto prep = [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) { nodes[i].second.EList.clear(); nodes[i].second.EList.reserve(8); } };
+        if (nt <= 1 || nodes.size() < 4096) prep(0, nodes.size());
+        else {
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < nt; t++) th.emplace_back(prep, nodes.size() * t / nt, nodes.size() * (t + 1) / nt);
+            for (std::thread &x : th) x.join();
+        }
+    }
+    for (size_t e = 0; e < elems.size(); e++) {   // Element.AddElem2Nodes in ElemLib order (Element.cs:474-480)
+        const int id = elems[e].second.ID;
+        for (int k = 0; k < 8; k++) {
+            std::vector<int> &el_list = nodes[(size_t)conn[e * 8 + (size_t)k]].second.EList;
+            if (el_list.empty() || el_list.back() != id) el_list.push_back(id);
+        }
     }
     std::vector<int32_t> index((size_t)nn);
     const int rc = stan_host_assign_dof(nn, ne, conn.data(), index.data(), nullptr);

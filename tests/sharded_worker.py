@@ -37,6 +37,7 @@ for tag, eps, prec in (("fp64", 1e-6, hip.PREC_FP64), ("mixed", 1e-5, hip.PREC_M
     res[tag] = (U, rep)
     if p2p:
         pr = ctx.profile()
+        print("P2P rank %d %s: %s waits %d" % (rank, tag, rep, pr["loop_stream_waits"]), flush=True)
         assert pr["loop_collectives"] == 0 and pr["loop_stream_waits"] > 0, (pr["loop_collectives"], pr["loop_stream_waits"])
 np.savez(os.path.join(out_dir, "rank%d.npz" % rank), U=res["fp64"][0], Um=res["mixed"][0],
          Ux=res["fixed48"][0], its_x=res["fixed48"][1]["iterations"],
