@@ -137,7 +137,7 @@ struct stan_p2p_dev {               // device-resident, one copy per rank
 };
 struct stan_p2p {                   // host side, shared by the ranks of a group (owned by multi.hip)
     int n = 0;
-    int wait_mode = 0;              // 0: hipStreamWaitValue64 on signal memory; 1: a one-wave polling kernel on a device flag
+    int wait_mode = 0;              // 0: hipStreamWaitValue64 on the counter (fine-grained device memory); 1: a one-wave polling kernel
     struct rank_res {
         int device = 0;
         double *mbox = nullptr;

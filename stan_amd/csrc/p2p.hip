@@ -11,8 +11,8 @@
 //   [wait: reduction count]  k_step   (adds the N partials in rank order; r.r and merit likewise)
 //   [wait: reduction count]  k_update
 // = 4 kernels, 3 stream waits, no RCCL launch (RCCL path: 4 kernels + 3 collective launches).
-// The waits are hipStreamWaitValue64 on signal memory where the device offers it (the command
-// processor waits, no wavefront spins), else a one-wave polling kernel on a device flag.
+// The waits are hipStreamWaitValue64 on the arrival counter (fine-grained device memory of the waiting rank) where
+// the device offers it (the command processor waits, no wavefront spins), else a one-wave polling kernel.
 #include <unistd.h>
 
 #include <chrono>
@@ -70,13 +70,14 @@ __global__ void k_wait_flag(const unsigned long long *flag, unsigned long long w
     }
 }
 
-int alloc_counter(stan_p2p *pp, unsigned long long **out) {
+// An arrival counter: 128 B of fine-grained DEVICE memory of the rank that waits on it.  (The first version
+// used HSA signal memory, which is what the documentation of hipStreamWaitValue64 asks for; its value lives in
+// HOST memory, every arrival then was a GPU atomic across PCIe, and with several ranks adding to one counter the
+// three-rank test hung about once in five runs -- a count was lost.  hipStreamWaitValue64 takes device memory
+// on this stack, within one process and through an IPC mapping: profiles/r03/waitvalue_probe_*.txt,
+// ipc_probe_two_processes_gpu0.txt; checked again at set-up, the polling kernel being the fallback.)
+int alloc_counter(stan_p2p *, unsigned long long **out) {
     *out = nullptr;
-    if (pp->wait_mode == 0) {
-        if (hipExtMallocWithFlags((void **)out, 8, hipMallocSignalMemory) != hipSuccess) { (void)hipGetLastError(); return STAN_E_ALLOC; }
-        **out = 0;   // the value of an HSA signal lives in host-visible memory
-        return STAN_OK;
-    }
     if (hipExtMallocWithFlags((void **)out, 128, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return STAN_E_ALLOC; }
     return hipMemset(*out, 0, 128) == hipSuccess ? STAN_OK : STAN_E_HIP;
 }
@@ -143,6 +144,13 @@ int stan_p2p_rank_setup(stan_p2p *pp, int rank, std::string *err) {
         *err = "peer-to-peer tables: hipMalloc failed";
         return STAN_E_ALLOC;
     }
+    // does the stream wait take this kind of memory here?  (a wait that is already satisfied)
+    if (pp->wait_mode == 0 &&
+        (hipStreamWaitValue64(nullptr, me.sig_red[0], 0, hipStreamWaitValueGte, ~0ULL) != hipSuccess ||
+         hipStreamSynchronize(nullptr) != hipSuccess)) {
+        (void)hipGetLastError();
+        pp->wait_mode = 1;   // (every rank polls then: the flag is shared; a racing reader sees 0 or 1, both work)
+    }
     return STAN_OK;
 }
 
@@ -190,8 +198,9 @@ void stan_p2p_abort(stan_p2p *pp) {
         for (int s = 0; s < STAN_P2P_RING; s++)
             for (unsigned long long *c : {r.sig_red[s], r.sig_halo[s]}) {
                 if (!c) continue;
-                if (pp->wait_mode == 0) __atomic_store_n(c, RELEASE_ALL, __ATOMIC_RELEASE);   // host-visible signal value
-                else { const unsigned long long v = RELEASE_ALL; (void)hipMemcpy(c, &v, 8, hipMemcpyHostToDevice); }
+                const unsigned long long v = RELEASE_ALL;
+                (void)hipSetDevice(r.device);
+                (void)hipMemcpy(c, &v, 8, hipMemcpyHostToDevice);
             }
     std::lock_guard<std::mutex> lk(pp->m);
     pp->cv.notify_all();

@@ -10,7 +10,10 @@
 // Extra switches (never stored in the STdb): --device N, --gpus N (devices 0..N-1) or --devices a,b,c
 // (several GPUs from this ONE process: stan_hip_init_multi, rows of K sharded, RCCL inside the CG),
 // --mixed, --fixed48, --no-merit-stop, --packed, --placement-tries N (default 16; 1 = plain allocation),
-// --json (one JSON line with sizes, iterations, phase times and the SpMV's HBM rate).
+// --p2p (several GPUs: the CG exchanges peer to peer instead of over RCCL, STAN_OPT_COMM_P2P),
+// --object-results (store the results in the Node / Element objects before the export, as the reference does,
+// instead of encoding them from the flat arrays: same bytes), --json (one JSON line with sizes, iterations,
+// device and host phase times and the SpMV's HBM rate).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -46,7 +49,7 @@ static int fail(const char *what, const std::string &msg) {
 int main(int argc, char **argv) {
     std::string path;
     int device = 0, precision = STAN_PREC_FP64, placement_tries = 16;
-    bool merit_stop = true, packed = false, json = false, object_results = false;
+    bool merit_stop = true, packed = false, json = false, object_results = false, p2p = false;
     std::vector<int> devices;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
@@ -68,15 +71,17 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--packed")) packed = true;
         else if (!strcmp(argv[i], "--json")) json = true;
         else if (!strcmp(argv[i], "--object-results")) object_results = true;
+        else if (!strcmp(argv[i], "--p2p")) p2p = true;
         else path = argv[i];
     }
     if (path.empty()) {  // Path = path[0] -> IndexOutOfRangeException in the reference
-        fprintf(stderr, "usage: stan_solver [--device N | --gpus N | --devices a,b,..] [--mixed|--fixed48] "
-                        "[--no-merit-stop] [--packed] [--json] <model.STdb>\n");
+        fprintf(stderr, "usage: stan_solver [--device N | --gpus N | --devices a,b,..] [--p2p] [--mixed|--fixed48] "
+                        "[--no-merit-stop] [--packed] [--object-results] [--json] <model.STdb>\n");
         return 2;
     }
     SolverOptions opt;
     opt.device = device; opt.devices = devices; opt.precision = precision; opt.placement_tries = placement_tries; opt.merit_stop = merit_stop; opt.profile = json;
+    opt.p2p = p2p;
     SolverFunctions Functions(opt);  // Solver.cs:16
     Functions.Welcome_Messsage();
 

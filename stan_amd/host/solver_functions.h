@@ -39,6 +39,7 @@ struct SolverOptions {  // extras of the native driver, never stored in the STdb
     int precision = STAN_PREC_FP64;
     bool merit_stop = true;
     bool profile = false;
+    bool p2p = false;           // STAN_OPT_COMM_P2P on a multi-device handle (throws where the devices cannot reach each other)
     int placement_tries = 16;   // STAN_OPT_PLACEMENT_TRIES: K's value stream is placed by search (only blocks >= 256 MB)
 };
 

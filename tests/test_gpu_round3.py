@@ -271,3 +271,40 @@ def test_console_driver_flat_result_writer_writes_the_object_path_bytes(built_li
     r = host.Db.read_stdb(str(tmp_path / "flat.STdb"))
     disp, strain, stress = r.results(1)
     assert np.abs(disp).max() > 0 and np.abs(stress).max() > 0
+
+
+def test_console_driver_on_two_ranks_peer_to_peer(built_libs, tmp_path):
+    """stan_solver --devices 0,0 --p2p: the reference's console entry point (Solver.cs:18-69) driving two ranks
+    whose CG exchanges go peer to peer; the result file is byte-identical to the RCCL-path run's (rank-ordered
+    sums on both transports), and --p2p is refused with the reason when the ranks share a device without a
+    hardware queue per stream."""
+    from stan_amd import host
+    from stan_amd.cube import cube_bcs, cube_mesh
+    exe = os.path.join(ROOT, "stan_amd", "bin", "stan_solver")
+    n = 8
+    xyz, conn = cube_mesh(n, jitter=0.1)
+    out_bytes = {}
+    for mode in ("rccl", "p2p"):
+        d = host.Db()
+        ne = conn.shape[0]
+        d.set_mesh(np.arange(1, xyz.shape[0] + 1), xyz, np.arange(1, ne + 1), np.ones(ne), conn + 1, "HEX8_G2")
+        d.add_material(1, "Steel", 210000.0, 0.3)
+        d.assign_part(1, 1, "HEX8_G2")
+        spc, ld, f = cube_bcs(n)
+        d.add_bc(1, "fix", "SPC", spc + 1, np.ones((len(spc), 3)))
+        d.add_bc(2, "load", "PointLoad", ld + 1, np.tile(f, (len(ld), 1)))
+        d.set_analysis(tol=1e-9)
+        path = str(tmp_path / (mode + ".STdb"))
+        d.write_stdb(path)
+        env = dict(os.environ, STAN_RCCL_LIB=FAKE, GPU_MAX_HW_QUEUES="8")
+        args = [exe, "--devices", "0,0", "--json"] + (["--p2p"] if mode == "p2p" else []) + [path]
+        out = subprocess.run(args, capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "NORMAL" in out.stdout
+        out_bytes[mode] = open(path, "rb").read()
+    assert out_bytes["rccl"] == out_bytes["p2p"]
+    env = dict(os.environ, STAN_RCCL_LIB=FAKE)
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    out = subprocess.run([exe, "--devices", "0,0", "--p2p", str(tmp_path / "p2p.STdb")], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert out.returncode != 0 and "GPU_MAX_HW_QUEUES" in (out.stdout + out.stderr)
