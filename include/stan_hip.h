@@ -162,7 +162,7 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
                            exchanges over RCCL (2 all-reduce launches + 1 grouped send/recv per iteration).  1: peer to
                            peer -- no collective launch in the loop: the block that finishes a reduction stores this
                            rank's partial sums into every rank's mailbox and counts itself into every rank's arrival
-                           counter; the consumer's STREAM waits for the count (hipStreamWaitValue64) and the consuming
+                           counter; the consumer's STREAM waits for the count (a one-wave polling kernel) and the consuming
                            kernel adds the partials in rank order (identical bits on every rank, and the bits of a
                            rank-ordered all-reduce); boundary rows are written straight into the neighbours' gather
                            vectors.  Needs peer access between all devices of the handle (STAN_E_UNSUPPORTED

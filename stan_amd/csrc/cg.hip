@@ -1355,6 +1355,9 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     const bool dist = ctx->comm != nullptr || ctx->nranks > 1;  // exchanges in the loop
     // peer to peer (one-process group handle, STAN_OPT_COMM_P2P): no RCCL call below this line
     const bool p2p = dist && ctx->comm_p2p && ctx->p2p != nullptr;
+    // no hipFree while the peers' streams wait for this rank's future exchanges (stan_ctx::defer_frees)
+    struct free_later { stan_ctx *c; bool on; ~free_later() { if (on) stan_flush_deferred(c); } } free_guard{ctx, p2p};
+    if (p2p) ctx->defer_frees = true;
     STANCHK(stan_cg_workspace(ctx, K));   // the context's vectors (the placement search probed with them)
     if (p2p) {
         // my neighbours write their boundary rows straight into these vectors: tell them where they are

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include <atomic>
 #include <condition_variable>
@@ -123,7 +124,7 @@ struct stan_cg_ws {
 // All devices of a group handle live in ONE address space, so the sharded CG needs no RCCL launch
 // in its loop: the block that finishes a reduction stores its partial sums into EVERY rank's
 // mailbox and then counts itself into every rank's arrival counter; the consumer's stream waits
-// for the count (hipStreamWaitValue64: no spinning kernel) and the consuming kernel adds the
+// for the count (a one-wave polling kernel, or hipStreamWaitValue64: p2p.hip) and the consuming kernel adds the
 // partials of all ranks in rank order (the result is the same on every rank, bit for bit, and
 // the same as a rank-ordered all-reduce gives).  Halo rows are written straight into the
 // neighbour's gather vector, followed by the same kind of count.
@@ -137,7 +138,7 @@ struct stan_p2p_dev {               // device-resident, one copy per rank
 };
 struct stan_p2p {                   // host side, shared by the ranks of a group (owned by multi.hip)
     int n = 0;
-    int wait_mode = 0;              // 0: hipStreamWaitValue64 on the counter (fine-grained device memory); 1: a one-wave polling kernel
+    int wait_mode = 1;              // 1 (default): a one-wave polling kernel; 0: hipStreamWaitValue64 on the counter (STAN_P2P_WAIT_MODE=0)
     struct rank_res {
         int device = 0;
         double *mbox = nullptr;
@@ -174,6 +175,7 @@ int stan_p2p_rank_finish(stan_p2p *pp, int rank, std::string *err);   // after e
 void stan_p2p_rank_release(stan_p2p *pp, int rank);
 void stan_p2p_destroy(stan_p2p *pp);
 void stan_p2p_abort(stan_p2p *pp);                 // frees every stream wait and every host barrier
+void stan_p2p_dump(stan_p2p *pp, FILE *f);         // call counts, expected and actual arrivals of every counter
 int stan_p2p_barrier(stan_p2p *pp);                // STAN_E_COMM when aborted / timed out
 struct stan_ctx;
 int stan_p2p_ipc_setup(stan_ctx *ctx);             // collective over the context's RCCL communicator
@@ -204,6 +206,13 @@ struct stan_ctx {
     stan_p2p *p2p = nullptr;   // set on the rank contexts of a group whose devices can reach each other
     bool comm_p2p = false;     // STAN_OPT_COMM_P2P: the CG's reductions and halo exchanges go peer to peer
     bool result_segment = false;  // group rank: the solve leaves only this rank's own entries of U (no gather)
+    // hipFree waits for EVERY stream of the device.  Inside a peer-to-peer solve the other ranks' streams hold
+    // waits for exchanges this rank has not issued yet; when ranks share a device (the test topology) a hipFree
+    // in the middle of the solve therefore never returns (found as a stall in 7 of 32 runs: the stall dump showed
+    // every expectation of the stuck ranks met -- they sat in the hipFree of a temporary).  Blocks released
+    // during such a solve are kept and freed when it has ended (stan_cg_device).
+    bool defer_frees = false;
+    std::vector<void *> deferred;
     // solver options (include/stan_hip.h STAN_OPT_*)
     bool cg_merit_stop = true;
     int cg_rupdate = 10;
@@ -394,8 +403,8 @@ static inline void stan_dfree(stan_ctx *ctx, void *p) {
                 ctx->pool.bytes_avail += cap;
                 // a host cycling through many sizes, or one sharing the GPU with another
                 // allocator: drop the oldest parked blocks beyond the block / byte budget
-                while (!ctx->pool.avail.empty() && (ctx->pool.avail.size() > stan_pool::MAX_BLOCKS ||
-                                                    ctx->pool.bytes_avail > ctx->pool.max_bytes)) {
+                while (!ctx->defer_frees && !ctx->pool.avail.empty() &&
+                       (ctx->pool.avail.size() > stan_pool::MAX_BLOCKS || ctx->pool.bytes_avail > ctx->pool.max_bytes)) {
                     hipFree(ctx->pool.avail.front().p);
                     ctx->pool.bytes_avail -= ctx->pool.avail.front().cap;
                     ctx->pool.avail.erase(ctx->pool.avail.begin());
@@ -403,8 +412,14 @@ static inline void stan_dfree(stan_ctx *ctx, void *p) {
                 return;
             }
         }
+        if (ctx->defer_frees) { ctx->deferred.push_back(p); return; }   // (see stan_ctx::defer_frees)
     }
     hipFree(p);
+}
+static inline void stan_flush_deferred(stan_ctx *ctx) {
+    ctx->defer_frees = false;
+    for (void *q : ctx->deferred) hipFree(q);
+    ctx->deferred.clear();
 }
 
 // ---- multi.hip: fan-out of the public entry points for a group handle ------------------------

@@ -96,9 +96,17 @@ int run_all(stan_group *g, const std::function<int(int)> &fn, run_mode mode) {
         }
     } else {
         using clock = std::chrono::steady_clock;
-        bool aborted = false;
+        bool aborted = false, dumped = false;
         clock::time_point t_fail, t_abort;
+        const clock::time_point t_start = clock::now();
+        // STAN_DEBUG_STALL_S = n: a call that has not returned after n seconds writes the state of the
+        // peer-to-peer exchanges to stderr once (diagnosis of a stalled multi-GPU solve; the call goes on)
+        const char *stall = getenv("STAN_DEBUG_STALL_S");
         for (;;) {
+            if (stall && !dumped && g->p2p && clock::now() - t_start > std::chrono::seconds(atoi(stall) > 0 ? atoi(stall) : 30)) {
+                stan_p2p_dump(g->p2p, stderr);
+                dumped = true;
+            }
             int running = 0;
             for (int r = 0; r < n; r++) {
                 stan_group::worker *w = g->w[r];

@@ -11,11 +11,15 @@
 //   [wait: reduction count]  k_step   (adds the N partials in rank order; r.r and merit likewise)
 //   [wait: reduction count]  k_update
 // = 4 kernels, 3 stream waits, no RCCL launch (RCCL path: 4 kernels + 3 collective launches).
-// The waits are hipStreamWaitValue64 on the arrival counter (fine-grained device memory of the waiting rank) where
-// the device offers it (the command processor waits, no wavefront spins), else a one-wave polling kernel.
+// The waits are a one-wave polling kernel on the arrival counter (fine-grained device memory of the waiting rank);
+// STAN_P2P_WAIT_MODE=0 selects hipStreamWaitValue64 on the same counter instead (stan_p2p_create).
+// One rule follows from the waits: NO hipFree inside a peer-to-peer solve -- hipFree waits for every stream of
+// the device, and when ranks share a device (the test topology) the other ranks' streams are waiting for this
+// rank's future exchanges (stan_ctx::defer_frees; found as stalls in a quarter of the three- and four-rank runs).
 #include <unistd.h>
 
 #include <chrono>
+#include <cstdio>
 
 #include "internal.h"
 #include "p2p_device.h"
@@ -70,12 +74,11 @@ __global__ void k_wait_flag(const unsigned long long *flag, unsigned long long w
     }
 }
 
-// An arrival counter: 128 B of fine-grained DEVICE memory of the rank that waits on it.  (The first version
-// used HSA signal memory, which is what the documentation of hipStreamWaitValue64 asks for; its value lives in
-// HOST memory, every arrival then was a GPU atomic across PCIe, and with several ranks adding to one counter the
-// three-rank test hung about once in five runs -- a count was lost.  hipStreamWaitValue64 takes device memory
-// on this stack, within one process and through an IPC mapping: profiles/r03/waitvalue_probe_*.txt,
-// ipc_probe_two_processes_gpu0.txt; checked again at set-up, the polling kernel being the fallback.)
+// An arrival counter: 128 B of fine-grained DEVICE memory of the rank that waits on it (arrivals are atomics over
+// xGMI into the waiter's own HBM, the waiter polls local memory).  Both kinds of wait take it, within one process
+// and through an IPC mapping: profiles/r03/waitvalue_probe_*.txt, ipc_probe_two_processes_gpu0.txt.  (The first
+// version used HSA signal memory, which hipStreamWaitValue64's documentation asks for; its value lives in HOST
+// memory: every arrival a GPU atomic across PCIe.)
 int alloc_counter(stan_p2p *, unsigned long long **out) {
     *out = nullptr;
     if (hipExtMallocWithFlags((void **)out, 128, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return STAN_E_ALLOC; }
@@ -103,16 +106,22 @@ int stan_p2p_create(stan_p2p **out, const std::vector<int> &devices, std::string
     pp->n = n;
     pp->rk.resize((size_t)n);
     for (int r = 0; r < n; r++) pp->rk[(size_t)r].device = devices[r];
-    int can_wait = 0;
-    pp->wait_mode = 0;
-    for (int r = 0; r < n; r++) {
-        can_wait = 0;
-        if (hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, devices[r]) != hipSuccess || !can_wait) {
-            (void)hipGetLastError();
-            pp->wait_mode = 1;
+    // How a stream waits for an arrival count.  1 (default): a one-wave polling kernel (k_wait_flag): nothing but
+    // documented HIP.  0 (STAN_P2P_WAIT_MODE=0): hipStreamWaitValue64 on the counter -- no wavefront spins, as fast
+    // (2.3-4.2 us against 2.4 us, profiles/r03/waitvalue_probe_*.txt), and it works on plain device memory on this
+    // stack, but its documentation asks for signal memory (host-resident: every arrival an atomic across PCIe).
+    // Both pass the same repetitions (24 of 24 each, profiles/r03/p2p_hang_hunt/).
+    pp->wait_mode = 1;
+    if (const char *m = getenv("STAN_P2P_WAIT_MODE")) {
+        pp->wait_mode = atoi(m) ? 1 : 0;
+        for (int r = 0; r < n && pp->wait_mode == 0; r++) {
+            int can_wait = 0;
+            if (hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, devices[r]) != hipSuccess || !can_wait) {
+                (void)hipGetLastError();
+                pp->wait_mode = 1;
+            }
         }
     }
-    if (const char *m = getenv("STAN_P2P_WAIT_MODE")) pp->wait_mode = atoi(m) ? 1 : 0;   // lab: force the polling kernel
     *out = pp;
     return STAN_OK;
 }
@@ -206,6 +215,28 @@ void stan_p2p_abort(stan_p2p *pp) {
     pp->cv.notify_all();
 }
 
+// Where does a stalled exchange stand?  Every rank's call counts, the arrivals each of its counters must have
+// reached and the arrivals it has (read from another thread: the ranks' streams are non-blocking streams).
+void stan_p2p_dump(stan_p2p *pp, FILE *f) {
+    if (!pp) return;
+    fprintf(f, "peer-to-peer state (%d ranks, %s, wait mode %d, broken %d)\n", pp->n, pp->ipc ? "IPC" : "one process", pp->wait_mode,
+            (int)pp->broken.load());
+    for (int r = 0; r < pp->n; r++) {
+        stan_p2p::rank_res &k = pp->rk[(size_t)r];
+        if (pp->ipc && r != pp->ipc_me) continue;
+        (void)hipSetDevice(k.device);
+        fprintf(f, "  rank %d: reductions issued %lld, halo exchanges issued %lld\n", r, (long long)k.red_calls, (long long)k.halo_calls);
+        for (int s = 0; s < STAN_P2P_RING; s++) {
+            unsigned long long a = 0, b = 0;
+            if (k.sig_red[s]) (void)hipMemcpy(&a, k.sig_red[s], 8, hipMemcpyDeviceToHost);
+            if (k.sig_halo[s]) (void)hipMemcpy(&b, k.sig_halo[s], 8, hipMemcpyDeviceToHost);
+            fprintf(f, "    slot %d: reduction arrivals %llu of %llu expected%s | halo arrivals %llu of %llu expected%s\n", s, a,
+                    k.red_expect[s], a < k.red_expect[s] ? "  <-- waiting" : "", b, k.halo_expect[s], b < k.halo_expect[s] ? "  <-- waiting" : "");
+        }
+    }
+    fflush(f);
+}
+
 int stan_p2p_barrier(stan_p2p *pp) {
     std::unique_lock<std::mutex> lk(pp->m);
     if (pp->broken.load()) return STAN_E_COMM;
@@ -291,14 +322,15 @@ int stan_p2p_ipc_setup(stan_ctx *ctx) {
     }
     HIPCHK(ctx, hipMemset(pp->ipc_block, 0, bytes));
     ipc_carve(me, pp->ipc_block, n);
-    int can_wait = 0;
-    pp->wait_mode = 1;
-    if (hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, ctx->device) == hipSuccess && can_wait &&
-        hipStreamWaitValue64(ctx->stream, me.sig_red[0], 0, hipStreamWaitValueGte, ~0ULL) == hipSuccess &&
-        hipStreamSynchronize(ctx->stream) == hipSuccess)
-        pp->wait_mode = 0;
-    (void)hipGetLastError();
-    if (const char *m = getenv("STAN_P2P_WAIT_MODE")) pp->wait_mode = atoi(m) ? 1 : 0;
+    pp->wait_mode = 1;   // polling kernel (see stan_p2p_create); STAN_P2P_WAIT_MODE=0: hipStreamWaitValue64 where it is accepted
+    if (const char *m = getenv("STAN_P2P_WAIT_MODE")) {
+        int can_wait = 0;
+        if (atoi(m) == 0 && hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, ctx->device) == hipSuccess && can_wait &&
+            hipStreamWaitValue64(ctx->stream, me.sig_red[0], 0, hipStreamWaitValueGte, ~0ULL) == hipSuccess &&
+            hipStreamSynchronize(ctx->stream) == hipSuccess)
+            pp->wait_mode = 0;
+        (void)hipGetLastError();
+    }
     // every rank must end up in the same mode only for its own waits: no agreement needed
     ipc_hello mine{};
     if (hipIpcGetMemHandle(&mine.h, pp->ipc_block) != hipSuccess) {

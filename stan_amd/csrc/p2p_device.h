@@ -7,8 +7,8 @@
 //   producer   sc0 sc1 (write-through) stores of the payload -> release fence at system scope
 //              (s_waitcnt vmcnt(0) behind it: the stores are acknowledged by their destination)
 //              -> system-scope atomic add to the consumer's arrival counter
-//   consumer   the STREAM waits for the counter (hipStreamWaitValue64, or a one-wave polling
-//              kernel); the kernel behind the wait starts with the usual acquire and reads the
+//   consumer   the STREAM waits for the counter (a one-wave polling kernel; optionally
+//              hipStreamWaitValue64); the kernel behind the wait starts with the usual acquire and reads the
 //              mailbox with sc0 sc1 loads (fine-grained memory: never served from a stale L2 line)
 #pragma once
 #include "internal.h"
