@@ -173,6 +173,8 @@ def main():
     ap.add_argument("--p2p", action="store_true",
                     help="STAN_OPT_COMM_P2P (N > 1): the CG's reductions and halo exchanges go peer to peer between the "
                          "rank processes (HIP IPC mappings; no RCCL launch in the loop) instead of over RCCL")
+    ap.add_argument("--spmv-variant", type=int, default=-1,
+                    help="STAN_OPT_SPMV_VARIANT (lab): -1 = the library's choice; 0 / 9 / 12 in the product library, more in the lab build")
     ap.add_argument("--knockout", type=float, default=0.0,
                     help="not the headline workload: the cube with this fraction of its elements knocked out at random "
                          "(an irregular mesh: row lengths vary; SELL-C-sigma evidence, profiles/r03)")
@@ -226,6 +228,8 @@ def main():
         ctx.set_option(hip.OPT_CG_SINGLE_REDUCE, 1)
     if args.sell_sigma > 0:
         ctx.set_option(hip.OPT_SELL_SIGMA, args.sell_sigma)
+    if args.spmv_variant >= 0:
+        ctx.set_option(hip.OPT_SPMV_VARIANT, args.spmv_variant)
     if args.p2p and world > 1:
         ctx.set_option(hip.OPT_COMM_P2P, 1)
     ctx.set_profiling(True)
