@@ -124,6 +124,23 @@ def test_bench_multi_rank_code_path(built_libs):
     assert d["roofline"]["two_product_launches"] >= d["config"]["cg_iterations"] // 10
 
 
+def test_bench_multi_rank_peer_to_peer(built_libs):
+    """bench.py --gpus 2 --p2p: the rank processes exchange peer to peer (HIP IPC); the line says so, the loop
+    enqueued no collective, and the result is the RCCL-path line's (same iterations, converged)."""
+    lines = {}
+    for flag in ([], ["--p2p"]):
+        out = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                            "--size", "14", "--no-cpu"] + flag,
+                        {"STAN_BENCH_BACKEND": "gloo", "STAN_BENCH_DEVICE": "0"})
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+        lines[bool(flag)] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    a, b = lines[False], lines[True]
+    assert "peer to peer" in b["config"]["transport"] and "peer to peer" not in a["config"]["transport"]
+    assert a["config"]["cg_iterations"] == b["config"]["cg_iterations"] and b["config"]["converged"]
+    assert a["config"]["rel_residual"] == b["config"]["rel_residual"]          # rank-ordered sums on both transports
+    assert min(b["config"]["exchange"]["allreduce_us_per_call"]) > 0
+
+
 def test_bench_watchdog_ends_a_stuck_multi_rank_run(built_libs):
     """First contact with an 8-GPU node must not hang the driver: rank 1 never starts its steps (test hook),
     rank 0 blocks in the first exchange; the watchdog prints one JSON error line and the job exits non-zero
