@@ -88,55 +88,33 @@ __device__ __forceinline__ void hex8_grad(const double *inv, int i, double px, d
     gr[2] = inv[6] * d[0] + inv[7] * d[1] + inv[8] * d[2];
 }
 
-// The (a,b) 3x3 block of K_e, summed over the element's Gauss points, by an aligned GROUP OF 8 LANES that hold
-// the same row node `a` and the eight column nodes b = lane & 7 (every caller's layout: lane = 8 * group + b).
-// gp: per Gauss point 10 doubles {J^-1, c = det J w} with stride `gstride` doubles between points.
-//   * lane b forms ONE scaled gradient of the row node, c_g grad N_a at Gauss point g = b; the group passes the
-//     eight of them around by shuffles (rounds 1-2: every lane recomputed all eight);
-//   * every lane forms the gradients of its own node b and accumulates M = sum_g (c_g grad N_a)(grad N_b)'
-//     -- 9 multiply-adds per Gauss point -- and only then combines
-//         K_ab = lambda M + G M' + G tr(M) I
-//     (rounds 1-2 formed lambda ga gb' + G gb ga' + G (ga.gb) I at every Gauss point: 34 operations per point).
-// ~230 fp64 operations per block instead of ~560: this arithmetic was 3.5 ms of k_numeric's 13.5 ms at 148^3, at
-// the fp64 VALU rate.  Same algebra as Element.K_Initial (Element.cs:118-155), another rounding order: the parity
-// bar stays <= 1e-13 of max |K_e| against the oracle.  All 8 lanes of a group must be active.
+// Accumulate the (a,b) 3x3 block of K_e over the element's Gauss points.
+// gp: per Gauss point 10 doubles {J^-1, c} with stride `gstride` doubles between points.
 #ifndef STAN_GP_UNROLL
-#define STAN_GP_UNROLL 2
+#define STAN_GP_UNROLL 2  // 231 VGPRs, no spill at 2 waves/SIMD (full unroll spills)
 #endif
 __device__ __forceinline__ void hex8_block_ab(const double *gp, int gstride, int type, int a,
                                               int b, double lam, double G, double k[9]) {
     const double gl = hex8_gauss_loc(type);
-    const int grp = (int)(threadIdx.x & 63u) & ~7;
-    double gs[3];   // c_b * grad N_a at Gauss point b
-    {
-        const double *q = gp + b * gstride;
-        const double px = hex8_sign(HEX8_SX, b) * gl, py = hex8_sign(HEX8_SY, b) * gl, pz = hex8_sign(HEX8_SZ, b) * gl;
-        double ga[3];
-        hex8_grad(q, a, px, py, pz, ga);
-        const double c = q[9];
-        gs[0] = c * ga[0]; gs[1] = c * ga[1]; gs[2] = c * ga[2];
-    }
-    double M[9];
 #pragma unroll
-    for (int j = 0; j < 9; j++) M[j] = 0.0;
+    for (int j = 0; j < 9; j++) k[j] = 0.0;
 #pragma unroll STAN_GP_UNROLL
     for (int g = 0; g < 8; g++) {
         const double *q = gp + g * gstride;
+        const double c = q[9];
         const double px = hex8_sign(HEX8_SX, g) * gl, py = hex8_sign(HEX8_SY, g) * gl,
                      pz = hex8_sign(HEX8_SZ, g) * gl;
-        double gb[3];
+        double ga[3], gb[3];
+        hex8_grad(q, a, px, py, pz, ga);
         hex8_grad(q, b, px, py, pz, gb);
-        const double a0 = __shfl(gs[0], grp | g, 64), a1 = __shfl(gs[1], grp | g, 64), a2 = __shfl(gs[2], grp | g, 64);
-        M[0] += a0 * gb[0]; M[1] += a0 * gb[1]; M[2] += a0 * gb[2];
-        M[3] += a1 * gb[0]; M[4] += a1 * gb[1]; M[5] += a1 * gb[2];
-        M[6] += a2 * gb[0]; M[7] += a2 * gb[1]; M[8] += a2 * gb[2];
+        const double t = c * lam, u = c * G;
+        const double dot = u * (ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2]);
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+#pragma unroll
+            for (int n = 0; n < 3; n++)
+                k[3 * m + n] += t * ga[m] * gb[n] + u * ga[n] * gb[m] + (m == n ? dot : 0.0);
     }
-    const double tr = G * ((M[0] + M[4]) + M[8]);
-#pragma unroll
-    for (int m = 0; m < 3; m++)
-#pragma unroll
-        for (int n = 0; n < 3; n++)
-            k[3 * m + n] = lam * M[3 * m + n] + G * M[3 * n + m] + (m == n ? tr : 0.0);
 }
 
 // Lame constants exactly as Material.SetElastic forms them (Material.cs:39-40).

@@ -62,7 +62,8 @@ def test_sell_c_sigma_on_a_perforated_box(gpu_ctx, oracle, frac):
     for sigma in (1, 32):
         U, rep = out[sigma][3], out[sigma][4]
         assert rep["terminationtype"] == repo["terminationtype"]
-        assert abs(rep["iterations"] - repo["iterations"]) <= max(3, repo["iterations"] // 50)
+        # (eps 1e-10 ends on alglib's merit-function floor, type 7: where exactly is rounding's choice)
+        assert abs(rep["iterations"] - repo["iterations"]) <= max(3, repo["iterations"] // (10 if rep["terminationtype"] == 7 else 50))
         assert np.abs(U - Uo).max() <= 1e-6 * np.abs(Uo).max()
 
 
