@@ -1423,14 +1423,14 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     std::vector<hipEvent_t> red_ev, halo_ev;   // profiling: events around the exchanges
     int64_t n_coll = 0, n_wait = 0;            // RCCL collectives / stream waits enqueued by the loop (profile)
     auto exchange_sums = [&](double *scalars, int count, red_src *rs) -> int {
-        *rs = red_src{nullptr, 0};
+        *rs = red_src{nullptr, 0, nullptr, 0};
         if (!dist) return STAN_OK;
         if (ctx->profiling) { red_ev.push_back(events.make()); hipEventRecord(red_ev.back(), st_); }
         int rc_ = STAN_OK;
         if (p2p) {
-            *rs = red_src{stan_p2p_mailbox(ctx, stan_p2p_reduce_slot(ctx)), ctx->nranks};
-            rc_ = stan_p2p_reduce_wait(ctx);
-            n_wait++;
+            *rs = red_src{stan_p2p_mailbox(ctx, stan_p2p_reduce_slot(ctx)), ctx->nranks, nullptr, 0};
+            rc_ = stan_p2p_reduce_wait(ctx, &rs->ctr, &rs->want);   // (wait mode 2: the consumers poll rs->ctr themselves)
+            if (!rs->ctr) n_wait++;
         } else {
             rc_ = stan_comm_allreduce_sum_f64(ctx, scalars, (size_t)count);
             n_coll++;
@@ -1576,7 +1576,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     HIPCHK(ctx, hipMemcpyAsync(h_st, stt, T_NSTAT * 8, hipMemcpyDeviceToHost, st_));
     HIPCHK(ctx, hipStreamSynchronize(st_));
     if (h_st[T_ITER_A] == 0) done = true;
-    red_src rs_sr{nullptr, 0}, rs_vmv{nullptr, 0}, rs_r2{nullptr, 0};
+    red_src rs_sr{nullptr, 0, nullptr, 0}, rs_vmv{nullptr, 0, nullptr, 0}, rs_r2{nullptr, 0, nullptr, 0};
     if (sr && !done) {   // w_0 = A r_0 with gamma_0, delta_0 (merit_0 = 0 sits in the zeroed scalars)
         if (p2p)         // ... or, peer to peer, is sent as this rank's zero into the slot of the first reduction
             hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, 0, sc + S_SR_MERIT, p2p_to(2, false));

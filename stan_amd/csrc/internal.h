@@ -138,7 +138,7 @@ struct stan_p2p_dev {               // device-resident, one copy per rank
 };
 struct stan_p2p {                   // host side, shared by the ranks of a group (owned by multi.hip)
     int n = 0;
-    int wait_mode = 1;              // 1 (default): a one-wave polling kernel; 0: hipStreamWaitValue64 on the counter (STAN_P2P_WAIT_MODE=0)
+    int wait_mode = 1;              // STAN_P2P_WAIT_MODE: 1 (default) a one-wave polling kernel; 0 hipStreamWaitValue64; 2 reductions polled by the consuming kernel itself
     struct rank_res {
         int device = 0;
         double *mbox = nullptr;
@@ -182,7 +182,7 @@ int stan_p2p_ipc_setup(stan_ctx *ctx);             // collective over the contex
 void stan_p2p_ipc_release(stan_ctx *ctx);
 struct stan_matrix;
 int stan_p2p_reduce_slot(stan_ctx *ctx);           // mailbox slot / counter of this rank's NEXT reduction
-int stan_p2p_reduce_wait(stan_ctx *ctx);           // stream-ordered wait for it (advances the slot)
+int stan_p2p_reduce_wait(stan_ctx *ctx, const unsigned long long **ctr = nullptr, unsigned long long *want = nullptr);   // the wait for it (advances the slot): enqueued, or (wait mode 2, ctr / want given) left to the consuming kernel
 const stan_p2p_dev *stan_p2p_table(stan_ctx *ctx);
 const double *stan_p2p_mailbox(stan_ctx *ctx, int slot);
 int stan_p2p_publish_vectors(stan_ctx *ctx, const stan_matrix *K, double *const vec[5]);

@@ -111,9 +111,13 @@ int stan_p2p_create(stan_p2p **out, const std::vector<int> &devices, std::string
     // (2.3-4.2 us against 2.4 us, profiles/r03/waitvalue_probe_*.txt), and it works on plain device memory on this
     // stack, but its documentation asks for signal memory (host-resident: every arrival an atomic across PCIe).
     // Both pass the same repetitions (24 of 24 each, profiles/r03/p2p_hang_hunt/).
+    // 2: like 1 for the halo, but the REDUCTIONS enqueue no wait at all -- the consuming kernel polls the counter
+    // itself (red_get: the "single-kernel one-shot" of SURVEY.md section 5; two launches less per iteration).  For
+    // one device per rank: a consumer spinning in all its workgroups must not share its device with the producer
+    // it waits for (the tests do that with systems small enough to be resident together).
     pp->wait_mode = 1;
     if (const char *m = getenv("STAN_P2P_WAIT_MODE")) {
-        pp->wait_mode = atoi(m) ? 1 : 0;
+        pp->wait_mode = atoi(m) == 2 ? 2 : atoi(m) ? 1 : 0;
         for (int r = 0; r < n && pp->wait_mode == 0; r++) {
             int can_wait = 0;
             if (hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, devices[r]) != hipSuccess || !can_wait) {
@@ -267,10 +271,18 @@ static int p2p_wait(stan_ctx *ctx, unsigned long long *c, unsigned long long wan
 // the slot the NEXT reduction of this rank uses (cg.hip passes it to the producing kernel), and the wait
 // for it; every rank makes the same sequence of calls
 int stan_p2p_reduce_slot(stan_ctx *ctx) { return (int)(ctx->p2p->rk[(size_t)ctx->rank].red_calls % STAN_P2P_RING); }
-int stan_p2p_reduce_wait(stan_ctx *ctx) {
+// ctr / want non-null and wait mode 2: nothing is enqueued, the consuming kernels poll *ctr >= *want themselves
+int stan_p2p_reduce_wait(stan_ctx *ctx, const unsigned long long **ctr, unsigned long long *want) {
     stan_p2p::rank_res &me = ctx->p2p->rk[(size_t)ctx->rank];
     const int slot = (int)(me.red_calls++ % STAN_P2P_RING);
     me.red_expect[slot] += (unsigned long long)ctx->p2p->n;   // every rank counts once per reduction
+    if (ctr) *ctr = nullptr;
+    if (ctr && want && ctx->p2p->wait_mode == 2) {
+        if (ctx->p2p->broken.load()) { ctx->err = "peer-to-peer exchange: a peer rank failed"; return STAN_E_COMM; }
+        *ctr = me.sig_red[slot];
+        *want = me.red_expect[slot];
+        return STAN_OK;
+    }
     return p2p_wait(ctx, me.sig_red[slot], me.red_expect[slot]);
 }
 const stan_p2p_dev *stan_p2p_table(stan_ctx *ctx) { return ctx->p2p->rk[(size_t)ctx->rank].d_dev; }
@@ -324,6 +336,7 @@ int stan_p2p_ipc_setup(stan_ctx *ctx) {
     ipc_carve(me, pp->ipc_block, n);
     pp->wait_mode = 1;   // polling kernel (see stan_p2p_create); STAN_P2P_WAIT_MODE=0: hipStreamWaitValue64 where it is accepted
     if (const char *m = getenv("STAN_P2P_WAIT_MODE")) {
+        if (atoi(m) == 2) pp->wait_mode = 2;
         int can_wait = 0;
         if (atoi(m) == 0 && hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, ctx->device) == hipSuccess && can_wait &&
             hipStreamWaitValue64(ctx->stream, me.sig_red[0], 0, hipStreamWaitValueGte, ~0ULL) == hipSuccess &&

@@ -56,6 +56,12 @@ __device__ __forceinline__ void p2p_publish(const p2p_out &o, const double r[NV]
 struct red_src {
     const double *mb;   // own mailbox + slot * n * 4; nullptr: read the scalar
     int32_t n;
+    // STAN_P2P_WAIT_MODE=2: no wait was enqueued in front of this kernel -- it waits itself ("single-kernel
+    // one-shot"): thread 0 of every block polls the arrival counter until it has reached `want`.  Safe for the
+    // mailbox only: its entries are read with system-scope loads from fine-grained memory, whereas a halo region
+    // written by a peer becomes visible to plain loads at a kernel boundary only (that wait stays a launch).
+    const unsigned long long *ctr;
+    unsigned long long want;
 };
 // NV values for the whole block; `sh` = NV doubles of LDS; call from ALL threads (one barrier).
 template <int NV>
@@ -64,6 +70,11 @@ __device__ __forceinline__ void red_get(const double *scalars, const red_src &rs
 #pragma unroll
         for (int j = 0; j < NV; j++) out[j] = scalars[j];
         return;
+    }
+    if (rs.ctr) {   // block-uniform
+        if (threadIdx.x == 0)
+            while (__hip_atomic_load(rs.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < rs.want) __builtin_amdgcn_s_sleep(2);
+        __syncthreads();
     }
     if (threadIdx.x < 64) {   // lane q loads rank q's partials (the loads overlap), lane 0 adds them in order
         double v[NV];

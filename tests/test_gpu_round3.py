@@ -90,23 +90,28 @@ def test_sell_c_sigma_keeps_the_cube(gpu_ctx):
     assert np.abs(res[1][2] - res[32][2]).max() <= 1e-6 * np.abs(res[1][2]).max()
 
 
-def _p2p_run(tmp_path, spec, nranks):
+def _p2p_run(tmp_path, spec, nranks, wait_mode=None):
     out = str(tmp_path / "p2p.npz")
     env = dict(os.environ, STAN_RCCL_LIB=FAKE, GPU_MAX_HW_QUEUES=str(2 * nranks + 4))
+    if wait_mode is not None:
+        env["STAN_P2P_WAIT_MODE"] = str(wait_mode)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "p2p_worker.py"), spec, str(nranks), out],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0 and "P2P_WORKER_OK" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
     return np.load(out)
 
 
-@pytest.mark.parametrize("spec,nranks", [("12", 2), ("12", 3), ("perf:10:0.3", 4), ("3", 4)])
-def test_peer_to_peer_exchanges_give_the_bits_of_the_rccl_path(built_libs, tmp_path, spec, nranks):
+@pytest.mark.parametrize("spec,nranks,wait_mode", [("12", 2, None), ("12", 3, None), ("perf:10:0.3", 4, None), ("3", 4, None),
+                                                   ("12", 3, 0), ("12", 3, 2), ("perf:10:0.3", 4, 2)])
+def test_peer_to_peer_exchanges_give_the_bits_of_the_rccl_path(built_libs, tmp_path, spec, nranks, wait_mode):
     """STAN_OPT_COMM_P2P: the sharded CG's reductions and halo exchanges without one collective launch
     (mailboxes + arrival counters + stream waits, p2p.hip).  The partials are added in rank order, like
     the stand-in transport's all-reduce: U, the iteration count and the termination code are IDENTICAL,
     classic and single-reduction loop, fp64 and FIXED-48 stream, a MaxIts stop inside a refresh cycle,
-    folded and unfolded reductions; "3" on 4 ranks = three ranks own no rows."""
-    d = _p2p_run(tmp_path, spec, nranks)
+    folded and unfolded reductions; "3" on 4 ranks = three ranks own no rows.  wait_mode: how a stream waits for
+    an arrival count (STAN_P2P_WAIT_MODE): default a one-wave polling kernel, 0 hipStreamWaitValue64, 2 the
+    reductions are polled by the consuming kernel itself (no wait launch for them at all)."""
+    d = _p2p_run(tmp_path, spec, nranks, wait_mode)
     for loop in ("classic", "sr"):
         for prec in ("f64", "fx48", "cap"):
             a, b = "rccl_%s_%s" % (loop, prec), "p2p_%s_%s" % (loop, prec)
@@ -122,6 +127,8 @@ def test_peer_to_peer_exchanges_give_the_bits_of_the_rccl_path(built_libs, tmp_p
                 # classic: 2 reduction waits (+ 1 halo wait on a rank with neighbours) per iteration; single reduction: 1 (+ 1)
                 per_it = waits / its
                 lo, hi = (1.9, 3.4) if loop == "classic" else (0.95, 2.4)
+                if wait_mode == 2:     # only the halo waits are launches (rank 0 has one neighbour: ~1.1 per iteration)
+                    lo, hi = 0.9, 1.4
                 assert lo <= per_it <= hi, (b, per_it)
         assert int(d["rep_rccl_%s_cap" % loop][0]) == 5 and int(d["rep_rccl_%s_cap" % loop][1]) == 37
         assert int(d["rep_rccl_%s_f64" % loop][0]) in (1, 7)
