@@ -227,6 +227,7 @@ struct stan_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     int assembly_mode = 0;     // 0 row-owner gather (default), 1 element-wave colour scatter
+    int ragged = 0;            // STAN_OPT_RAGGED_STREAM: 1 = the products read re-packed streams without padding (cg.hip)
     int sell_sigma = 1;        // SELL-C-sigma: rows sorted by length inside windows of this many slices (1: inside each slice only)
     int placement_tries = 16;  // > 1: allocate the value stream by search (placement.hip); blocks >= 256 MB only
     int64_t placement_max_bytes = 0;  // bytes of candidates the search may hold at once; 0 = a quarter of the free memory
@@ -274,6 +275,17 @@ struct stan_matrix {
     float *d_vals32 = nullptr;      // same layout, fp32 copy (mixed precision)
     uint32_t *d_vals48 = nullptr;   // FIXED-48 stream of the scaled values, [slot][14][64] dwords
     bool fx48_refused = false;      // some |a_ij| >= 2 after scaling (K not SPD): fp64 is streamed
+    // Ragged copy of the streams (cg.hip: stan_matrix_make_ragged, STAN_OPT_RAGGED_STREAM): slot k keeps the
+    // entries of the lanes whose rows reach slot k only (a prefix of the wave: the rows of a slice are sorted by
+    // length), stored back to back -- no padding is streamed.  vals: [slot][ROWS][cnt_k], cols: [slot][cnt_k].
+    int64_t *d_rag_ptr = nullptr;       // [nslots + 1] entries in front of every slot
+    int32_t *d_rag_cols = nullptr;      // [rag_blocks]
+    uint16_t *d_rag_cols16 = nullptr;   // [rag_blocks] offsets from d_colbase[slot] (packed slices), or nullptr
+    double *d_rag_vals = nullptr;       // the three value streams in ragged form (built on demand)
+    float *d_rag_vals32 = nullptr;
+    uint32_t *d_rag_vals48 = nullptr;
+    int64_t rag_blocks = 0;
+    int rag_state = 0;                  // 0: not examined, 1: structure built, -1: not applicable to this matrix
     int32_t *d_red = nullptr;       // [n_dof] nDOF_reduction
     uint8_t *d_fixmask = nullptr;   // [nb_glob] bit m = DOF m of the node fixed
     double *d_scale = nullptr;      // [3*(nloc+nhalo)] s_i = 1/sqrt(K_ii)
@@ -328,6 +340,8 @@ int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode
                            double *avg_ms);
 int stan_spmv_local(stan_ctx *ctx, stan_matrix *K, const double *d_x, double *d_y);
 int stan_matrix_make_fp32(stan_ctx *ctx, stan_matrix *K);
+int stan_matrix_make_ragged(stan_ctx *ctx, stan_matrix *K, int32_t stream_kind);
+void stan_matrix_drop_ragged_values(stan_ctx *ctx, stan_matrix *K);
 int stan_matrix_make_fx48(stan_ctx *ctx, stan_matrix *K);
 int stan_matrix_make_cols16(stan_ctx *ctx, stan_matrix *K);
 int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K);

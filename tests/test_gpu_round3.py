@@ -316,3 +316,79 @@ def test_console_driver_on_two_ranks_peer_to_peer(built_libs, tmp_path):
     out = subprocess.run([exe, "--devices", "0,0", "--p2p", str(tmp_path / "p2p.STdb")], capture_output=True, text=True,
                          timeout=300, env=env)
     assert out.returncode != 0 and "GPU_MAX_HW_QUEUES" in (out.stdout + out.stderr)
+
+
+OPT_RAGGED = 19
+
+
+@pytest.mark.parametrize("prec", [0, 1, 2])
+def test_ragged_streams_keep_every_bit(gpu_ctx, prec):
+    """STAN_OPT_RAGGED_STREAM (off by default): on a mesh with ragged slices (Database.cs:39-111 admits any CHEXA
+    mesh) the products read re-packed streams without the padding -- every row still adds the same products in
+    the same order: U, the iteration count and a plain product are identical, bit for bit, with the option off
+    and on, for the fp64, the fp32 and the FIXED-48 value stream, on a perforated box and on the cube."""
+    from tests.perforated import perforated_job
+    perf = perforated_job(20, 0.4)
+    cube = problem.cube_job(10, jitter=0.05)
+    x = np.random.default_rng(11).standard_normal(perf.n_red)
+    out = {}
+    try:
+        gpu_ctx.set_profiling(True)
+        gpu_ctx.set_option(15, 0)              # STAN_OPT_SPMV_SMALL off: the small-system kernel never reads ragged streams
+        for name, job in (("perforated", perf), ("cube", cube)):
+            args = (job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+            for rag in (0, 1):
+                gpu_ctx.set_option(OPT_RAGGED, rag)
+                K = gpu_ctx.assemble_hex8(*args)
+                if name == "perforated":
+                    assert _padding(K.info()) > 0.15
+                U, rep = K.cg_solve(job.F, 1e-9, precision_mode=prec)
+                used = gpu_ctx.profile()["ragged_stream"]
+                y = K.spmv(x) if name == "perforated" else None
+                out[(name, rag)] = (U, rep["iterations"], rep["terminationtype"], y, used)
+                K.free()
+    finally:
+        gpu_ctx.set_option(OPT_RAGGED, 0)
+        gpu_ctx.set_option(15, 1)
+        gpu_ctx.set_profiling(False)
+    for name in ("perforated", "cube"):
+        a, b = out[(name, 0)], out[(name, 1)]
+        assert a[4] == 0 and b[4] == 1
+        assert a[1:3] == b[1:3] and np.array_equal(a[0], b[0])
+        assert a[2] in (1, 7) and np.abs(a[0]).max() > 0
+    assert np.array_equal(out[("perforated", 0)][3], out[("perforated", 1)][3])
+
+
+def test_ragged_streams_in_a_sharded_solve(built_libs):
+    """The interior and the boundary product of a shard (slice lists) and the two-product launch of the refresh
+    iterations read the ragged streams as well: a three-rank solve of a perforated box gives the same bits with
+    the option off and on, classic and single-reduction loop."""
+    code = r'''
+import numpy as np
+from stan_amd import hip
+from tests.perforated import perforated_job
+job = perforated_job(14, 0.35)
+args = (job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+ctx = hip.Context(devices=[0, 0, 0])
+ctx.set_profiling(True)
+ctx.set_option(15, 0)   # STAN_OPT_SPMV_SMALL off (the small-system kernel never reads ragged streams)
+res = {}
+for sr in (0, 1):
+    for rag in (0, 1):
+        ctx.set_option(19, rag)
+        ctx.set_option(10, sr)
+        K = ctx.assemble_hex8(*args)
+        U, rep = K.cg_solve(job.F, 1e-9)
+        res[(sr, rag)] = (U, rep["iterations"], rep["terminationtype"], ctx.profile()["ragged_stream"])
+        K.free()
+for sr in (0, 1):
+    a, b = res[(sr, 0)], res[(sr, 1)]
+    assert a[3] == 0 and b[3] == 1, (a[3], b[3])
+    assert a[1:3] == b[1:3] and np.array_equal(a[0], b[0]), (sr, a[1:3], b[1:3])
+    assert a[2] in (1, 7) and np.abs(a[0]).max() > 0
+ctx.close()
+print("RAGGED SHARDED OK")
+'''
+    env = dict(os.environ, STAN_RCCL_LIB=FAKE)
+    rc, out, err = _run_script(code, env, 300)
+    assert rc == 0 and "RAGGED SHARDED OK" in out, out[-2000:] + err[-3000:]
