@@ -175,8 +175,9 @@ def main():
                          "rank processes (HIP IPC mappings; no RCCL launch in the loop) instead of over RCCL")
     ap.add_argument("--spmv-variant", type=int, default=-1,
                     help="STAN_OPT_SPMV_VARIANT (lab): -1 = the library's choice; 0 / 9 / 12 in the product library, more in the lab build")
-    ap.add_argument("--ragged", type=int, default=0,
-                    help="STAN_OPT_RAGGED_STREAM: 1 = the products read re-packed streams without the ELL padding")
+    ap.add_argument("--fold", type=int, default=-1,
+                    help="STAN_OPT_ROW_FOLDING: -1 = auto (library default), 0 = never, 1 = long rows always lend their tails to the "
+                         "idle slots of their slice (fold.hip)")
     ap.add_argument("--knockout", type=float, default=0.0,
                     help="not the headline workload: the cube with this fraction of its elements knocked out at random "
                          "(an irregular mesh: row lengths vary; SELL-C-sigma evidence, profiles/r03)")
@@ -230,8 +231,8 @@ def main():
         ctx.set_option(hip.OPT_CG_SINGLE_REDUCE, 1)
     if args.sell_sigma > 0:
         ctx.set_option(hip.OPT_SELL_SIGMA, args.sell_sigma)
-    if args.ragged:
-        ctx.set_option(hip.OPT_RAGGED_STREAM, 1)
+    if args.fold != -1:
+        ctx.set_option(hip.OPT_ROW_FOLDING, args.fold)
     if args.spmv_variant >= 0:
         ctx.set_option(hip.OPT_SPMV_VARIANT, args.spmv_variant)
     if args.p2p and world > 1:
@@ -391,7 +392,7 @@ def main():
                                          else "fp64", 100.0 * prof["col_slots_packed"] / max(info["n_slots"], 1)),
                        # SELL-C-sigma: slots streamed per structural block - 1 (padded slots are streamed like real ones)
                        "ell_padding": info["n_slots"] * 64.0 / max(info["n_blocks"], 1) - 1.0,
-                       "sell_sigma": info["sell_sigma"], "ragged_stream": bool(prof["ragged_stream"]),
+                       "sell_sigma": info["sell_sigma"], "repacked_streams": "folded rows" if prof["repacked_streams"] else "none",
                        "parallelism": "rows sharded x%d" % world,
                        "transport": ("one rank" if world == 1 else
                                      "RCCL %s (ncclGetVersion %d), communicator of %d ranks, this = rank %d%s" %

@@ -155,18 +155,20 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
                            latter).  The permutation is internal: vectors, CRS export, halo plan and the row partition
                            keep the reference (AssignDOF) order and every row sum keeps its bits.  MEASURED (profiles/
                            r03/SELL_C_SIGMA.md): a wave executes the slots of its slice's longest row, and the time of the
-                           product follows that count, not the bytes (STAN_OPT_RAGGED_STREAM); sorted slices have fewer
+                           product follows that count, not the bytes (STAN_OPT_ROW_FOLDING cuts it); sorted slices have fewer
                            slots but lose the locality of 64 consecutive breadth-first rows: 10-27 % slower with 32,
                            6 % with 4.  Hence the default 1 (rows sorted inside each slice
                            only); larger values trade time for memory.  Applies to the next assembly. */
-#define STAN_OPT_RAGGED_STREAM 19 /* 0 (default) / 1: the SpMV reads RE-PACKED streams in which slot k of a slice holds the entries
-                           of the rows that reach slot k only (a prefix of the wave, as the rows of a slice are sorted by
-                           length), all slots back to back: no padding is streamed, every access stays one contiguous
-                           run, every row adds the same products in the same order (same bits).  Built at the first
-                           solve, next to the padded streams (which the scaling, the export and the placement search
-                           keep using).  MEASURED (profiles/r03/SELL_C_SIGMA.md, addendum): on a box with 24 % padding
-                           15 % less HBM traffic and 1-2 % less time, slower below 7 % padding and on the cube -- the
-                           product's time follows its slot iterations, not its bytes.  Kept as that evidence. */
+#define STAN_OPT_ROW_FOLDING 19 /* -1 (default) / 0 / 1: on a mesh whose rows differ in length the SpMV reads a re-packed copy of
+                           the streams in which the long rows of a slice lend their tails to the idle slots of its short
+                           rows (fold.hip): a wave walks about blocks/64 slots instead of the slots of its slice's
+                           longest row, and no row leaves its slice (the gather locality of 64 consecutive AssignDOF rows
+                           stays -- SELL-C-sigma windows give that up).  A folded row is summed as own part + pieces:
+                           another order than the padded layout's (deterministic; identical for a shard and the whole
+                           matrix); rows that are not folded keep their bits.  Built at the first solve next to the
+                           padded streams, which the scaling, the export and the placement search keep using.  -1: when
+                           the plan saves more than 5 % of the slots (a box with 40 % of its elements missing: 16 %, SpMV
+                           -16 %, FIXED-48 -19 %; the cube: 0 %, never); 1: always; 0: never. */
 #define STAN_OPT_COMM_P2P 18 /* one-process multi-device handle only (stan_hip_init_multi).  0 (default): the sharded CG
                            exchanges over RCCL (2 all-reduce launches + 1 grouped send/recv per iteration).  1: peer to
                            peer -- no collective launch in the loop: the block that finishes a reduction stores this
@@ -354,7 +356,7 @@ typedef struct stan_profile {
     float placement_ms_best, placement_ms_worst; /* SpMV probe time of the kept / the slowest candidate */
     int64_t col_slots_packed;         /* ELL slots whose columns the last solve read from the packed stream */
     int32_t placement_moved_vectors;  /* 1: no candidate was clear of the vectors' group and the search re-allocated the CG's vectors instead */
-    int32_t ragged_stream;            /* 1: the last solve's products read the re-packed (ragged) streams (STAN_OPT_RAGGED_STREAM) */
+    int32_t repacked_streams;         /* 1: the last solve's products read the folded streams (STAN_OPT_ROW_FOLDING) */
     int64_t loop_stream_waits;        /* peer-to-peer exchanges (STAN_OPT_COMM_P2P): stream waits the loop enqueued instead of collectives */
     double comm_reduce_ms_total;      /* sharded loop: stream time between "reduction issued" and "sums available", summed   */
     int64_t comm_reduce_calls;        /*   over this many reduction points (RCCL all-reduce launches or peer-to-peer waits)   */

@@ -148,7 +148,7 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
     else if (option == STAN_OPT_SELL_SIGMA && value >= 1 && value <= 32) ctx->sell_sigma = (int)value;
     else if (option == STAN_OPT_PLACEMENT_TRIES && value >= 1 && value <= 64) ctx->placement_tries = (int)value;
     else if (option == STAN_OPT_PLACEMENT_MAX_BYTES && value >= 0) ctx->placement_max_bytes = value;
-    else if (option == STAN_OPT_RAGGED_STREAM && (value == 0 || value == 1)) ctx->ragged = (int)value;
+    else if (option == STAN_OPT_ROW_FOLDING && value >= -1 && value <= 1) ctx->row_folding = (int)value;
 #ifdef STAN_LAB
     else if (option == STAN_OPT_SPMV_VARIANT && value >= -1 && value <= 18) ctx->spmv_variant = (int)value;
 #else   // the product library carries the three variants that give right answers (cg.hip)
@@ -304,8 +304,9 @@ void stan_hip_matrix_free(stan_matrix *K) {
                     (void *)K->d_vals32, (void *)K->d_vals48, (void *)K->d_cols16, (void *)K->d_colbase,
                     (void *)K->d_pair_ptr, (void *)K->d_slice_packed, (void *)K->d_red, (void *)K->d_fixmask,
                     (void *)K->d_scale, (void *)K->d_send_rows, (void *)K->d_halo_glob, (void *)K->d_sendbuf,
-                    (void *)K->d_sl_int, (void *)K->d_sl_bnd, (void *)K->d_rag_ptr, (void *)K->d_rag_cols, (void *)K->d_rag_cols16,
-                    (void *)K->d_rag_vals, (void *)K->d_rag_vals32, (void *)K->d_rag_vals48})
+                    (void *)K->d_sl_int, (void *)K->d_sl_bnd, (void *)K->d_fold_ptr, (void *)K->d_fold_meta,
+                    (void *)K->d_fold_plan, (void *)K->d_fold_cols, (void *)K->d_fold_cols16, (void *)K->d_fold_colbase,
+                    (void *)K->d_fold_pair_ptr, (void *)K->d_fold_packed, (void *)K->d_fold_vals, (void *)K->d_fold_vals32, (void *)K->d_fold_vals48})
         stan_dfree(K->ctx, q);
     delete K;
 }

@@ -706,110 +706,102 @@ k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, con
 }
 
 
-// ---- ragged streams (STAN_OPT_RAGGED_STREAM) -----------------------------------------------------------
-// A slice is as wide as its longest row, and k_spmv streams every slot of every lane: on a mesh whose rows differ
-// in length (the reference reads arbitrary CHEXA meshes, Database.cs:39-111) a quarter of the streamed bytes can
-// be padding, and the product is bound by the bytes it streams there as much as on the cube (same FETCH_SIZE,
-// same time for a 120^3 box whole and with 40 % of its elements removed:
-// profiles/r03/gather_pmc_whole_vs_perforated_n120.txt).  Skipping the loads of the idle lanes in place does not
-// help (round 3, "masked" build: the runs that remain are fragments of 512-B rows).  Here the streams are
-// re-packed once per matrix: the rows of a slice are sorted by length (k_window_sort), so the lanes that reach
-// slot k are a PREFIX of the wave, cnt_k lanes; slot k stores cnt_k columns and ROWS x cnt_k value words, all
-// slots back to back (ptr[k] = entries in front of slot k).  A wave still walks max-row-length slots, every
-// access is still a contiguous run -- cnt_k * 8 B instead of 512 B -- and no padding is read.  Idle lanes load
-// the entry of the last active lane (same address, no traffic) and multiply it with x = 0: no divergence in the
-// loop.  Every row adds the same products in the same order as in k_spmv: same bits.
-struct ragstream {
-    const int64_t *ptr;      // [nslots + 1]
-    const int32_t *cols;     // [entries]
-    const uint16_t *cols16;  // [entries] offsets from base[slot] where ok[slice], or nullptr
-    const int32_t *base;     // [nslots]
-    const uint8_t *ok;       // [nslices]
-};
-
-template <bool NT, typename VT>
-__device__ __forceinline__ void load9_ragged(const VT *vp, int64_t cnt, double a[9]) {
-    if constexpr (vstream<VT>::FX) {
-        uint32_t lo[9], hw[5];
-#pragma unroll
-        for (int j = 0; j < 9; j++) lo[j] = ld_stream<NT>(vp + j * cnt);
-#pragma unroll
-        for (int m = 0; m < 5; m++) hw[m] = ld_stream<NT>(vp + (9 + m) * cnt);
-#pragma unroll
-        for (int j = 0; j < 9; j++) {
-            const uint32_t h = (j & 1) ? (hw[j >> 1] >> 16) : (hw[j >> 1] & 0xffffu);
-            a[j] = __hiloint2double((int)(0x43300000u | h), (int)lo[j]) - FX48_BIAS;
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 9; j++) a[j] = (double)ld_stream<NT>(vp + j * cnt);
-    }
-}
-
-// NRHS = 1: k_spmv (DOT as there); NRHS = 2: k_spmv2 (y = A x, y2 = A x2, partial of x . y)
-template <typename VT, int DOT, int NRHS, bool NT>
+// ---- folded rows (STAN_OPT_ROW_FOLDING, fold.hip) ---------------------------------------------------------
+// The streams of fold.hip: padded-slot layout ([slot][ROWS][64]) with W ~ blocks/64 slots per slice; slots
+// < own[lane] hold the lane's own row, the slots behind them a piece of ONE longer row of the slice (or zeros).
+// Two accumulators per lane; the foreign ones go through LDS and each folded row adds its helpers' sums in a
+// fixed order (descending lane).  NRHS = 1: k_spmv (DOT as there); NRHS = 2: k_spmv2.
+template <typename VT, int DOT, int NRHS>
 __global__ void __launch_bounds__(256)
-k_spmv_rag(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, const int32_t *__restrict__ rowof,
-           ragstream rg, const VT *__restrict__ vals, const double *__restrict__ x, const double *__restrict__ x2,
-           double *__restrict__ y, double *__restrict__ y2, double *partial, const int64_t *st, int64_t kiter,
-           const int32_t *__restrict__ slist, int32_t nlist, int32_t poff, fold_args fold) {
+k_spmv_fold(int32_t nslices, int64_t nloc, const int32_t *__restrict__ fold_ptr, const int32_t *__restrict__ rowof,
+            const uint32_t *__restrict__ meta, const int32_t *__restrict__ cols, const VT *__restrict__ vals,
+            const double *__restrict__ x, const double *__restrict__ x2, double *__restrict__ y, double *__restrict__ y2,
+            double *partial, const int64_t *st, int64_t kiter, const int32_t *__restrict__ slist, int32_t nlist,
+            int32_t poff, fold_args fold, colstream cs) {
     __shared__ double sh[4];
     __shared__ int sh_last;
+    __shared__ double fsh[4][3 * NRHS][64];
     if (stopped(st, kiter)) { fold_skip(fold); return; }
-    constexpr int ROWS = vstream<VT>::STRIDE / 64;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int64_t bid = blockIdx.x;
     {   // XCD-chunked workgroup mapping, as in k_spmv (variant 9)
         constexpr int CH = 32;
         const int64_t win = 8 * CH, grp = bid / win, within = bid - grp * win;
         if ((grp + 1) * win <= (int64_t)gridDim.x) bid = grp * win + (within & 7) * CH + (within >> 3);
     }
-    int64_t slice = bid * 4 + (threadIdx.x >> 6);
+    int64_t slice = bid * 4 + w;
     if (slist) slice = slice < nlist ? (int64_t)slist[slice] : (int64_t)nslices;
-    double y0 = 0, y1 = 0, yy2 = 0, z0 = 0, z1 = 0, z2 = 0;
+    double y0 = 0, y1 = 0, yy2 = 0, z0 = 0, z1 = 0, z2 = 0;     // own row
+    double f0 = 0, f1 = 0, f2 = 0, g0 = 0, g1 = 0, g2 = 0;      // the piece of a longer row this lane carries
     const int64_t row = slice < nslices ? (int64_t)rowof[slice * 64 + lane] : nloc;
+    uint32_t m = 0;
     if (slice < nslices) {
-        const int32_t k0 = __builtin_amdgcn_readfirstlane(slot_ptr[slice]), k1 = __builtin_amdgcn_readfirstlane(slot_ptr[slice + 1]);
-        const int64_t *ap = rg.ptr + k0;   // wave-uniform: scalar loads
-#define STAN_RAG_BLOCK(COL)                                                                    \
-    {                                                                                          \
-        const int64_t a1 = ap[1];                                                              \
-        const int64_t cnt = a1 - a0;                                                           \
-        const bool act = lane < cnt;                                                           \
-        const int64_t e = a0 + (act ? (int64_t)lane : cnt - 1);                                \
-        const int64_t c = COL;                                                                 \
-        double a[9];                                                                           \
-        load9_ragged<NT, VT>(vals + a0 * ROWS + (e - a0), cnt, a);                                 \
-        double x0 = x[3 * c], x1 = x[3 * c + 1], xx2 = x[3 * c + 2];                           \
-        if (vstream<VT>::FX) { x0 *= FX48_INV; x1 *= FX48_INV; xx2 *= FX48_INV; }              \
-        x0 = act ? x0 : 0.0; x1 = act ? x1 : 0.0; xx2 = act ? xx2 : 0.0;                       \
-        y0 += a[0] * x0 + a[1] * x1 + a[2] * xx2;                                              \
-        y1 += a[3] * x0 + a[4] * x1 + a[5] * xx2;                                              \
-        yy2 += a[6] * x0 + a[7] * x1 + a[8] * xx2;                                             \
-        if (NRHS == 2) {                                                                       \
-            double u0 = x2[3 * c], u1 = x2[3 * c + 1], u2 = x2[3 * c + 2];                     \
-            if (vstream<VT>::FX) { u0 *= FX48_INV; u1 *= FX48_INV; u2 *= FX48_INV; }           \
-            u0 = act ? u0 : 0.0; u1 = act ? u1 : 0.0; u2 = act ? u2 : 0.0;                     \
-            z0 += a[0] * u0 + a[1] * u1 + a[2] * u2;                                           \
-            z1 += a[3] * u0 + a[4] * u1 + a[5] * u2;                                           \
-            z2 += a[6] * u0 + a[7] * u1 + a[8] * u2;                                           \
-        }                                                                                      \
-        a0 = a1;                                                                               \
-        ap++;                                                                                  \
+        m = meta[slice * 64 + lane];
+        const int32_t own = (int32_t)(m & 0xffffu);
+        const int32_t k0 = fold_ptr[slice], k1 = fold_ptr[slice + 1];
+        const int32_t *cp = cols + (int64_t)k0 * 64 + lane;
+        const VT *vp = vals + (int64_t)k0 * vstream<VT>::STRIDE + lane;
+#define STAN_FOLD_BLOCK(C, VP, KL)                                                              \
+    {                                                                                           \
+        double a[9];                                                                            \
+        load9<true, VT>(VP, a);                                                                 \
+        double x0 = x[3 * (C)], x1 = x[3 * (C) + 1], xx2 = x[3 * (C) + 2];                      \
+        if (vstream<VT>::FX) { x0 *= FX48_INV; x1 *= FX48_INV; xx2 *= FX48_INV; }               \
+        const double t0 = a[0] * x0 + a[1] * x1 + a[2] * xx2;                                   \
+        const double t1 = a[3] * x0 + a[4] * x1 + a[5] * xx2;                                   \
+        const double t2 = a[6] * x0 + a[7] * x1 + a[8] * xx2;                                   \
+        const bool mine = (KL) < own;                                                           \
+        y0 += mine ? t0 : 0.0; y1 += mine ? t1 : 0.0; yy2 += mine ? t2 : 0.0;                   \
+        f0 += mine ? 0.0 : t0; f1 += mine ? 0.0 : t1; f2 += mine ? 0.0 : t2;                    \
+        if (NRHS == 2) {                                                                        \
+            double u0 = x2[3 * (C)], u1 = x2[3 * (C) + 1], u2 = x2[3 * (C) + 2];                \
+            if (vstream<VT>::FX) { u0 *= FX48_INV; u1 *= FX48_INV; u2 *= FX48_INV; }            \
+            const double s0 = a[0] * u0 + a[1] * u1 + a[2] * u2;                                \
+            const double s1 = a[3] * u0 + a[4] * u1 + a[5] * u2;                                \
+            const double s2 = a[6] * u0 + a[7] * u1 + a[8] * u2;                                \
+            z0 += mine ? s0 : 0.0; z1 += mine ? s1 : 0.0; z2 += mine ? s2 : 0.0;                \
+            g0 += mine ? 0.0 : s0; g1 += mine ? 0.0 : s1; g2 += mine ? 0.0 : s2;                \
+        }                                                                                       \
     }
-        int64_t a0 = ap[0];
-        if (rg.cols16 && rg.ok[slice]) {   // wave-uniform
-            const int32_t *bp = rg.base + k0;
-#pragma unroll 2
-            for (int32_t k = k0; k < k1; k++) {
-                STAN_RAG_BLOCK((int64_t)bp[0] + (int64_t)ld_stream<NT>(rg.cols16 + e))
-                bp++;
+        if (cs.packed && cs.ok[slice]) {   // wave-uniform: the folded copy has its own packed column stream
+            const uint32_t *cq = cs.packed + (int64_t)cs.pair_ptr[slice] * 64 + lane;
+            const int32_t *bp = cs.base + __builtin_amdgcn_readfirstlane(k0);
+            int32_t k = k0;
+            for (; k + 1 < k1; k += 2) {
+                const uint32_t wd = __builtin_nontemporal_load(cq);
+                const int64_t c = (int64_t)bp[0] + (int64_t)(wd & 0xffffu);
+                const int64_t c2 = (int64_t)bp[1] + (int64_t)(wd >> 16);
+                STAN_FOLD_BLOCK(c, vp, k - k0)
+                STAN_FOLD_BLOCK(c2, vp + vstream<VT>::STRIDE, k - k0 + 1)
+                cq += 64;
+                bp += 2;
+                vp += 2 * vstream<VT>::STRIDE;
+            }
+            if (k < k1) {
+                const int64_t c = (int64_t)bp[0] + (int64_t)(__builtin_nontemporal_load(cq) & 0xffffu);
+                STAN_FOLD_BLOCK(c, vp, k - k0)
             }
         } else {
 #pragma unroll 2
-            for (int32_t k = k0; k < k1; k++) STAN_RAG_BLOCK((int64_t)ld_stream<NT>(rg.cols + e))
+            for (int32_t k = k0; k < k1; k++) {
+                const int64_t c = __builtin_nontemporal_load(cp);
+                STAN_FOLD_BLOCK(c, vp, k - k0)
+                cp += 64;
+                vp += vstream<VT>::STRIDE;
+            }
         }
-#undef STAN_RAG_BLOCK
+#undef STAN_FOLD_BLOCK
+    }
+    fsh[w][0][lane] = f0; fsh[w][1][lane] = f1; fsh[w][2][lane] = f2;
+    if (NRHS == 2) { fsh[w][3][lane] = g0; fsh[w][4][lane] = g1; fsh[w][5][lane] = g2; }
+    __syncthreads();
+    if (slice < nslices) {
+        const int hfirst = (int)((m >> 16) & 0xffu), nh = (int)(m >> 24);
+        for (int h = 0; h < nh; h++) {   // a folded row: own part + its pieces, last lane first
+            const int j = hfirst - h;
+            y0 += fsh[w][0][j]; y1 += fsh[w][1][j]; yy2 += fsh[w][2][j];
+            if (NRHS == 2) { z0 += fsh[w][3][j]; z1 += fsh[w][4][j]; z2 += fsh[w][5][j]; }
+        }
         if (row < nloc) {
 #if STAN_Y_NT
             __builtin_nontemporal_store(y0, y + 3 * row); __builtin_nontemporal_store(y1, y + 3 * row + 1);
@@ -840,55 +832,6 @@ k_spmv_rag(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, 
             }
         } else if (threadIdx.x == 0) st_agent(partial + blockIdx.x + poff, t);
         if (fold.counter && fold_arrive(fold, &sh_last)) fold_finish<(DOT == 2 ? 2 : 1)>(fold, partial, sh);
-    }
-}
-
-// entries of every slot: the lanes whose rows reach it (must be a prefix of the wave, else *bad counts)
-__global__ void __launch_bounds__(256)
-k_rag_counts(int32_t nslices, int64_t nloc, const int32_t *slot_ptr, const int32_t *rowof, const int32_t *rowlen,
-             int32_t *cnt, unsigned long long *bad) {
-    const int lane = threadIdx.x & 63;
-    const int64_t slice = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (slice >= nslices) return;
-    const int64_t row = rowof[slice * 64 + lane];
-    const int32_t len = row < nloc ? rowlen[row] : 0;
-    const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
-    bool wrong = false;
-    for (int32_t k = k0; k < k1; k++) {
-        const unsigned long long m = __ballot(len > k - k0);
-        const int c = __popcll(m);
-        wrong |= m != (c == 64 ? ~0ULL : ((1ULL << c) - 1ULL)) || c == 0;
-        if (lane == 0) cnt[k] = c;
-    }
-    if (wrong && lane == 0) atomicAdd(bad, 1ULL);
-}
-__global__ void __launch_bounds__(256)
-k_rag_cols(int32_t nslices, const int32_t *slot_ptr, const int64_t *rp, const int32_t *cols, const int32_t *base,
-           const uint8_t *ok, int32_t *oc, uint16_t *oc16) {
-    const int lane = threadIdx.x & 63;
-    const int64_t slice = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (slice >= nslices) return;
-    const bool pk = oc16 && ok[slice];
-    for (int32_t k = slot_ptr[slice]; k < slot_ptr[slice + 1]; k++) {
-        const int64_t a0 = rp[k], cnt = rp[k + 1] - a0;
-        if (lane >= cnt) continue;
-        const int32_t c = cols[(int64_t)k * 64 + lane];
-        oc[a0 + lane] = c;
-        if (oc16) oc16[a0 + lane] = pk ? (uint16_t)(c - base[k]) : (uint16_t)0;
-    }
-}
-template <typename VT>
-__global__ void __launch_bounds__(256)
-k_to_ragged(int32_t nslices, const int32_t *slot_ptr, const int64_t *rp, const VT *in, VT *out) {
-    constexpr int ROWS = vstream<VT>::STRIDE / 64;
-    const int lane = threadIdx.x & 63;
-    const int64_t slice = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (slice >= nslices) return;
-    for (int32_t k = slot_ptr[slice]; k < slot_ptr[slice + 1]; k++) {
-        const int64_t a0 = rp[k], cnt = rp[k + 1] - a0;
-        if (lane >= cnt) continue;
-#pragma unroll
-        for (int j = 0; j < ROWS; j++) out[a0 * ROWS + j * cnt + lane] = in[((int64_t)k * ROWS + j) * 64 + lane];
     }
 }
 
@@ -1249,22 +1192,21 @@ inline bool stan_small_system(const stan_ctx *ctx, const stan_matrix *K) {
     return ctx->spmv_variant < 0 && K->nb_glob <= ctx->spmv_small_rows;
 }
 
-// the ragged form of the value stream `vals` of K, if the products are to read it (stan_matrix_make_ragged)
-template <typename VT> const VT *rag_vals(const stan_ctx *ctx, const stan_matrix *K, const VT *vals);
-template <> const double *rag_vals<double>(const stan_ctx *ctx, const stan_matrix *K, const double *vals) {
-    return ctx->ragged != 0 && vals == K->d_vals ? K->d_rag_vals : nullptr;
+// the folded form of the value stream `vals` of K, if the products are to read it (fold.hip)
+template <typename VT> const VT *fold_vals(const stan_ctx *ctx, const stan_matrix *K, const VT *vals);
+template <> const double *fold_vals<double>(const stan_ctx *ctx, const stan_matrix *K, const double *vals) {
+    return ctx->row_folding != 0 && vals == K->d_vals ? K->d_fold_vals : nullptr;
 }
-template <> const float *rag_vals<float>(const stan_ctx *ctx, const stan_matrix *K, const float *vals) {
-    return ctx->ragged != 0 && vals == K->d_vals32 ? K->d_rag_vals32 : nullptr;
+template <> const float *fold_vals<float>(const stan_ctx *ctx, const stan_matrix *K, const float *vals) {
+    return ctx->row_folding != 0 && vals == K->d_vals32 ? K->d_fold_vals32 : nullptr;
 }
-template <> const uint32_t *rag_vals<uint32_t>(const stan_ctx *ctx, const stan_matrix *K, const uint32_t *vals) {
-    return ctx->ragged != 0 && vals == K->d_vals48 ? K->d_rag_vals48 : nullptr;
+template <> const uint32_t *fold_vals<uint32_t>(const stan_ctx *ctx, const stan_matrix *K, const uint32_t *vals) {
+    return ctx->row_folding != 0 && vals == K->d_vals48 ? K->d_fold_vals48 : nullptr;
 }
-inline ragstream rag_of(const stan_ctx *ctx, const stan_matrix *K) {
-    const bool pk = ctx->cols16 && K->d_rag_cols16 && K->d_colbase && K->d_slice_packed;
-    return ragstream{K->d_rag_ptr, K->d_rag_cols, pk ? K->d_rag_cols16 : nullptr, K->d_colbase, K->d_slice_packed};
+inline colstream fold_cols_of(const stan_ctx *ctx, const stan_matrix *K) {
+    return ctx->cols16 && K->d_fold_cols16 ? colstream{K->d_fold_cols16, K->d_fold_colbase, K->d_fold_pair_ptr, K->d_fold_packed}
+                                           : colstream{nullptr, nullptr, nullptr, nullptr};
 }
-
 // which: 0 = all slices, 1 = interior list, 2 = boundary list (partials offset by the
 // interior launch's block count).  Returns the number of partial slots this launch writes.
 // `fold`: counter/out of the folded reduction (counter == nullptr: partials only); nblocks and np
@@ -1294,15 +1236,10 @@ unsigned launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double
     if (grid == 0) return 0;
     fold.nblocks = grid;
     fold.np = (int)grid + poff;
-    if (const VT *rv = rag_vals<VT>(ctx, K, vals)) {
-        if (ctx->spmv_variant == 0)   // A/B: plain loads
-            hipLaunchKernelGGL((k_spmv_rag<VT, DOT, 1, false>), dim3(grid), dim3(256), 0, stream, K->nslices, K->nloc, K->d_slot_ptr,
-                               K->d_rowof, rag_of(ctx, K), rv, x, (const double *)nullptr, y, (double *)nullptr, partial, st, k,
-                               slist, nlist, poff, fold);
-        else
-            hipLaunchKernelGGL((k_spmv_rag<VT, DOT, 1, true>), dim3(grid), dim3(256), 0, stream, K->nslices, K->nloc, K->d_slot_ptr,
-                               K->d_rowof, rag_of(ctx, K), rv, x, (const double *)nullptr, y, (double *)nullptr, partial, st, k,
-                               slist, nlist, poff, fold);
+    if (const VT *fv = fold_vals<VT>(ctx, K, vals)) {
+        hipLaunchKernelGGL((k_spmv_fold<VT, DOT, 1>), dim3(grid), dim3(256), 0, stream, K->nslices, K->nloc, K->d_fold_ptr,
+                           K->d_rowof, K->d_fold_meta, K->d_fold_cols, fv, x, (const double *)nullptr, y, (double *)nullptr,
+                           partial, st, k, slist, nlist, poff, fold, fold_cols_of(ctx, K));
         return grid;
     }
 #define SPMV_CASE(V)                                                                          \
@@ -1342,9 +1279,10 @@ unsigned launch_spmv2(stan_ctx *ctx, stan_matrix *K, const VT *vals, const doubl
     if (grid == 0) return 0;
     fold.nblocks = grid;
     fold.np = (int)grid + poff;
-    if (const VT *rv = rag_vals<VT>(ctx, K, vals)) {
-        hipLaunchKernelGGL((k_spmv_rag<VT, 1, 2, true>), dim3(grid), dim3(256), 0, stream, K->nslices, K->nloc, K->d_slot_ptr,
-                           K->d_rowof, rag_of(ctx, K), rv, x, x2, y, y2, partial, st, k, slist, nlist, poff, fold);
+    if (const VT *fv = fold_vals<VT>(ctx, K, vals)) {
+        hipLaunchKernelGGL((k_spmv_fold<VT, 1, 2>), dim3(grid), dim3(256), 0, stream, K->nslices, K->nloc, K->d_fold_ptr,
+                           K->d_rowof, K->d_fold_meta, K->d_fold_cols, fv, x, x2, y, y2, partial, st, k, slist, nlist, poff, fold,
+                           fold_cols_of(ctx, K));
         return grid;
     }
     const colstream cs = ctx->cols16 && K->d_cols16 ? colstream{K->d_cols16, K->d_colbase, K->d_pair_ptr, K->d_slice_packed}
@@ -1466,7 +1404,7 @@ static int ensure_scaled(stan_ctx *ctx, stan_matrix *K) {
     // hold the unscaled K: a later solve must not iterate on them
     if (K->d_vals32) { stan_dfree(ctx, K->d_vals32); K->d_vals32 = nullptr; }
     if (K->d_vals48) { stan_dfree(ctx, K->d_vals48); K->d_vals48 = nullptr; }
-    stan_matrix_drop_ragged_values(ctx, K);
+    stan_matrix_drop_folded_values(ctx, K);
     K->fx48_refused = false;
     return STAN_OK;
 }
@@ -1506,102 +1444,47 @@ int stan_matrix_make_fx48(stan_ctx *ctx, stan_matrix *K) {
     return STAN_OK;
 }
 
-// Ragged copies of the column stream and of the value stream `stream_kind` (k_spmv_rag), built when
-// STAN_OPT_RAGGED_STREAM is 1.  The padded streams stay (the scaling, export and placement code works on them);
-// a matrix whose slices are not sorted by length, or that the small-system kernel serves, keeps streaming them.
-void stan_matrix_drop_ragged_values(stan_ctx *ctx, stan_matrix *K) {
-    if (K->d_rag_vals) { stan_dfree(ctx, K->d_rag_vals); K->d_rag_vals = nullptr; }
-    if (K->d_rag_vals32) { stan_dfree(ctx, K->d_rag_vals32); K->d_rag_vals32 = nullptr; }
-    if (K->d_rag_vals48) { stan_dfree(ctx, K->d_rag_vals48); K->d_rag_vals48 = nullptr; }
-}
-int stan_matrix_make_ragged(stan_ctx *ctx, stan_matrix *K, int32_t stream_kind) {
-    if (ctx->ragged == 0 || K->rag_state < 0 || K->nslots <= 0 || K->nblocks <= 0 || stan_small_system(ctx, K)) return STAN_OK;
-    hipStream_t st_ = ctx->stream;
-    const unsigned grid = nblk(K->nslices, 4);
-    if (K->rag_state == 0) {
-        dev_bufs bufs;
-        int32_t *cnt;
-        STANCHK(alloc(ctx, bufs, &cnt, (size_t)K->nslots + 1));
-        unsigned long long *d_bad = (unsigned long long *)(ctx->d_status + SS_COUNTER);
-        HIPCHK(ctx, hipMemsetAsync(d_bad, 0, 8, st_));
-        hipLaunchKernelGGL(k_rag_counts, dim3(grid), dim3(256), 0, st_, K->nslices, K->nloc, K->d_slot_ptr, K->d_rowof,
-                           K->d_rowlen, cnt, d_bad);
-        STANCHK(stan_dmalloc(ctx, &K->d_rag_ptr, (size_t)K->nslots + 2));
-        STANCHK(stan_scan_exclusive(ctx, cnt, K->d_rag_ptr, K->nslots));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_COUNTER, d_bad, 8, hipMemcpyDeviceToHost, st_));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_H_COUNT_A, K->d_rag_ptr + K->nslots, 8, hipMemcpyDeviceToHost, st_));
-        HIPCHK(ctx, hipStreamSynchronize(st_));
-        if (ctx->h_status[SS_COUNTER] != 0 || ctx->h_status[SS_H_COUNT_A] != K->nblocks) {
-            // slices not sorted by length (a matrix of another build), or counts that disagree with the symbolic phase
-            stan_dfree(ctx, K->d_rag_ptr); K->d_rag_ptr = nullptr;
-            K->rag_state = -1;
-            return STAN_OK;
-        }
-        K->rag_blocks = ctx->h_status[SS_H_COUNT_A];
-        STANCHK(stan_dmalloc(ctx, &K->d_rag_cols, (size_t)K->rag_blocks));
-        const bool pk = K->d_cols16 && K->d_colbase && K->d_slice_packed;
-        if (pk) STANCHK(stan_dmalloc(ctx, &K->d_rag_cols16, (size_t)K->rag_blocks));
-        hipLaunchKernelGGL(k_rag_cols, dim3(grid), dim3(256), 0, st_, K->nslices, K->d_slot_ptr, K->d_rag_ptr, K->d_cols,
-                           K->d_colbase, K->d_slice_packed, K->d_rag_cols, K->d_rag_cols16);
-        HIPCHK(ctx, hipGetLastError());
-        K->rag_state = 1;
-    }
-    if (stream_kind == STAN_PREC_MIXED) {
-        if (!K->d_rag_vals32 && K->d_vals32) {
-            STANCHK(stan_dmalloc(ctx, &K->d_rag_vals32, (size_t)K->rag_blocks * 9));
-            hipLaunchKernelGGL(k_to_ragged<float>, dim3(grid), dim3(256), 0, st_, K->nslices, K->d_slot_ptr, K->d_rag_ptr,
-                               K->d_vals32, K->d_rag_vals32);
-        }
-    } else if (stream_kind == STAN_PREC_FIXED48) {
-        if (!K->d_rag_vals48 && K->d_vals48) {
-            STANCHK(stan_dmalloc(ctx, &K->d_rag_vals48, (size_t)K->rag_blocks * 14));
-            hipLaunchKernelGGL(k_to_ragged<uint32_t>, dim3(grid), dim3(256), 0, st_, K->nslices, K->d_slot_ptr, K->d_rag_ptr,
-                               K->d_vals48, K->d_rag_vals48);
-        }
-    } else if (!K->d_rag_vals) {
-        STANCHK(stan_dmalloc(ctx, &K->d_rag_vals, (size_t)K->rag_blocks * 9));
-        hipLaunchKernelGGL(k_to_ragged<double>, dim3(grid), dim3(256), 0, st_, K->nslices, K->d_slot_ptr, K->d_rag_ptr, K->d_vals,
-                           K->d_rag_vals);
-    }
-    HIPCHK(ctx, hipGetLastError());
-    return STAN_OK;
-}
-
 // Packed column stream of K (struct colstream), built once per matrix; the int32 columns stay (the
 // assembly, scaling and export kernels use them).
 int stan_matrix_make_cols16(stan_ctx *ctx, stan_matrix *K) {
     if (K->d_cols16 || K->nslices <= 0) return STAN_OK;
+    return stan_pack_columns(ctx, K->nslices, K->nslots, K->d_slot_ptr, K->d_cols, &K->d_cols16, &K->d_colbase, &K->d_pair_ptr,
+                             &K->d_slice_packed, &K->slots_packed);
+}
+// the same for any sliced column stream (the folded copy of fold.hip has its own); *packed stays nullptr when the
+// pair index would not fit an int32
+int stan_pack_columns(stan_ctx *ctx, int32_t nslices, int64_t nslots, const int32_t *d_slot_ptr, const int32_t *d_cols,
+                      uint32_t **packed_out, int32_t **base_out, int32_t **pair_ptr_out, uint8_t **ok_out, int64_t *slots_packed) {
     hipStream_t st_ = ctx->stream;
     dev_bufs bufs;
     int32_t *cnt; int64_t *ptr64;
-    STANCHK(alloc(ctx, bufs, &cnt, (size_t)K->nslices + 1));
-    STANCHK(alloc(ctx, bufs, &ptr64, (size_t)K->nslices + 2));
-    hipLaunchKernelGGL(k_pair_counts, dim3(nblk(K->nslices, 256)), dim3(256), 0, st_, K->nslices, K->d_slot_ptr, cnt);
-    STANCHK(stan_scan_exclusive(ctx, cnt, ptr64, K->nslices));
-    std::vector<int64_t> h((size_t)K->nslices + 1);
+    STANCHK(alloc(ctx, bufs, &cnt, (size_t)nslices + 1));
+    STANCHK(alloc(ctx, bufs, &ptr64, (size_t)nslices + 2));
+    hipLaunchKernelGGL(k_pair_counts, dim3(nblk(nslices, 256)), dim3(256), 0, st_, nslices, d_slot_ptr, cnt);
+    STANCHK(stan_scan_exclusive(ctx, cnt, ptr64, nslices));
+    std::vector<int64_t> h((size_t)nslices + 1);
     HIPCHK(ctx, hipMemcpyAsync(h.data(), ptr64, h.size() * 8, hipMemcpyDeviceToHost, st_));
     HIPCHK(ctx, hipStreamSynchronize(st_));
-    const int64_t npairs = h[(size_t)K->nslices];
+    const int64_t npairs = h[(size_t)nslices];
     if (npairs >= ((int64_t)1 << 31)) return STAN_OK;   // pair index is int32: keep the plain columns
     std::vector<int32_t> h32(h.size());
     for (size_t i = 0; i < h.size(); i++) h32[i] = (int32_t)h[i];
-    STANCHK(stan_dmalloc(ctx, &K->d_pair_ptr, h32.size()));
-    STANCHK(stan_dmalloc(ctx, &K->d_colbase, (size_t)(K->nslots > 0 ? K->nslots : 1)));
-    STANCHK(stan_dmalloc(ctx, &K->d_slice_packed, (size_t)K->nslices));
+    STANCHK(stan_dmalloc(ctx, pair_ptr_out, h32.size()));
+    STANCHK(stan_dmalloc(ctx, base_out, (size_t)(nslots > 0 ? nslots : 1)));
+    STANCHK(stan_dmalloc(ctx, ok_out, (size_t)nslices));
     uint32_t *packed;
     STANCHK(stan_dmalloc(ctx, &packed, (size_t)(npairs > 0 ? npairs : 1) * 64));
-    HIPCHK(ctx, hipMemcpyAsync(K->d_pair_ptr, h32.data(), h32.size() * 4, hipMemcpyHostToDevice, st_));
-    hipLaunchKernelGGL(k_pack_cols, dim3(nblk(K->nslices, 4)), dim3(256), 0, st_, K->nslices, K->d_slot_ptr, K->d_cols,
-                       K->d_pair_ptr, packed, K->d_colbase, K->d_slice_packed);
+    HIPCHK(ctx, hipMemcpyAsync(*pair_ptr_out, h32.data(), h32.size() * 4, hipMemcpyHostToDevice, st_));
+    hipLaunchKernelGGL(k_pack_cols, dim3(nblk(nslices, 4)), dim3(256), 0, st_, nslices, d_slot_ptr, d_cols, *pair_ptr_out, packed,
+                       *base_out, *ok_out);
     unsigned long long *d_cnt = (unsigned long long *)(ctx->d_status + SS_COUNTER);
     HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 8, st_));
-    hipLaunchKernelGGL(k_count_ok, dim3(nblk(K->nslices, 256)), dim3(256), 0, st_, K->nslices, K->d_slice_packed,
-                       K->d_slot_ptr, d_cnt);
+    hipLaunchKernelGGL(k_count_ok, dim3(nblk(nslices, 256)), dim3(256), 0, st_, nslices, *ok_out, d_slot_ptr, d_cnt);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_COUNTER, d_cnt, 8, hipMemcpyDeviceToHost, st_));
     HIPCHK(ctx, hipStreamSynchronize(st_));   // h32 must outlive the copy
-    K->slots_packed = ctx->h_status[SS_COUNTER];
-    K->d_cols16 = packed;
+    *slots_packed = ctx->h_status[SS_COUNTER];
+    *packed_out = packed;
     return STAN_OK;
 }
 
@@ -1654,7 +1537,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     // the stream the products really read (FIXED-48 falls back to fp64 when K is not SPD-scalable)
     const int vs = precision_mode == STAN_PREC_FIXED48 ? (K->d_vals48 ? STAN_PREC_FIXED48 : STAN_PREC_FP64)
                                                        : precision_mode;
-    STANCHK(stan_matrix_make_ragged(ctx, K, vs));
+    if (!stan_small_system(ctx, K)) STANCHK(stan_matrix_make_folded(ctx, K, vs));
     const bool sr = ctx->cg_single_reduce;
     const bool foldr = ctx->cg_fold_reduce;
 
@@ -2028,11 +1911,16 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         const double packed_frac = packed && K->nslots > 0 ? (double)K->slots_packed / (double)K->nslots : 0.0;
         ctx->prof.spmv_bytes = K->nblocks * blk_bytes + 3 * K->nloc * 16 + K->nloc * 4
                                - (int64_t)(packed_frac * (double)K->nblocks * 2.0) + (packed ? K->slots_packed * 4 : 0);
-        // the ragged stream: the same bytes per entry + 8 B per slot for its position (wave-uniform)
-        const bool rag = ctx->ragged != 0 && (vs == STAN_PREC_FIXED48 ? K->d_rag_vals48 != nullptr : vs == STAN_PREC_MIXED ? K->d_rag_vals32 != nullptr
-                                                                                                                            : K->d_rag_vals != nullptr);
-        if (rag) ctx->prof.spmv_bytes += K->nslots * 8;
-        ctx->prof.ragged_stream = rag ? 1 : 0;
+        const bool folded = ctx->row_folding != 0 && (vs == STAN_PREC_FIXED48 ? K->d_fold_vals48 != nullptr : vs == STAN_PREC_MIXED ? K->d_fold_vals32 != nullptr
+                                                                                                                                    : K->d_fold_vals != nullptr);
+        if (folded) {   // its own packed column stream, 4 B of plan per row
+            const bool fp = ctx->cols16 && K->d_fold_cols16;
+            const double ff = fp && K->nfslots > 0 ? (double)K->fold_slots_packed / (double)K->nfslots : 0.0;
+            ctx->prof.spmv_bytes = K->nblocks * blk_bytes + 3 * K->nloc * 16 + K->nloc * 8 - (int64_t)(ff * (double)K->nblocks * 2.0) +
+                                   (fp ? K->fold_slots_packed * 4 : 0);
+            ctx->prof.col_slots_packed = fp ? K->fold_slots_packed : 0;
+        }
+        ctx->prof.repacked_streams = folded ? 1 : 0;
         ctx->prof.col_slots_packed = packed ? K->slots_packed : 0;
         ctx->prof.value_stream = vs;
         // vector passes of one classic iteration: k_step reads r, v (+ p, x unless deferred; + b^ for the
@@ -2208,7 +2096,7 @@ int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K) {
     K->scaled = false;
     if (K->d_vals32) { stan_dfree(ctx, K->d_vals32); K->d_vals32 = nullptr; }
     if (K->d_vals48) { stan_dfree(ctx, K->d_vals48); K->d_vals48 = nullptr; }
-    stan_matrix_drop_ragged_values(ctx, K);
+    stan_matrix_drop_folded_values(ctx, K);
     K->fx48_refused = false;
     return STAN_OK;
 }

@@ -227,7 +227,7 @@ struct stan_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     int assembly_mode = 0;     // 0 row-owner gather (default), 1 element-wave colour scatter
-    int ragged = 0;            // STAN_OPT_RAGGED_STREAM: 1 = the products read re-packed streams without padding (cg.hip)
+    int row_folding = -1;      // STAN_OPT_ROW_FOLDING: -1 = products read the folded streams (fold.hip) when they save > 5 % of the slots; 1 always; 0 never
     int sell_sigma = 1;        // SELL-C-sigma: rows sorted by length inside windows of this many slices (1: inside each slice only)
     int placement_tries = 16;  // > 1: allocate the value stream by search (placement.hip); blocks >= 256 MB only
     int64_t placement_max_bytes = 0;  // bytes of candidates the search may hold at once; 0 = a quarter of the free memory
@@ -275,17 +275,23 @@ struct stan_matrix {
     float *d_vals32 = nullptr;      // same layout, fp32 copy (mixed precision)
     uint32_t *d_vals48 = nullptr;   // FIXED-48 stream of the scaled values, [slot][14][64] dwords
     bool fx48_refused = false;      // some |a_ij| >= 2 after scaling (K not SPD): fp64 is streamed
-    // Ragged copy of the streams (cg.hip: stan_matrix_make_ragged, STAN_OPT_RAGGED_STREAM): slot k keeps the
-    // entries of the lanes whose rows reach slot k only (a prefix of the wave: the rows of a slice are sorted by
-    // length), stored back to back -- no padding is streamed.  vals: [slot][ROWS][cnt_k], cols: [slot][cnt_k].
-    int64_t *d_rag_ptr = nullptr;       // [nslots + 1] entries in front of every slot
-    int32_t *d_rag_cols = nullptr;      // [rag_blocks]
-    uint16_t *d_rag_cols16 = nullptr;   // [rag_blocks] offsets from d_colbase[slot] (packed slices), or nullptr
-    double *d_rag_vals = nullptr;       // the three value streams in ragged form (built on demand)
-    float *d_rag_vals32 = nullptr;
-    uint32_t *d_rag_vals48 = nullptr;
-    int64_t rag_blocks = 0;
-    int rag_state = 0;                  // 0: not examined, 1: structure built, -1: not applicable to this matrix
+    // Folded copy of the streams (fold.hip, STAN_OPT_ROW_FOLDING): long rows lend their tails to the idle slots of
+    // the short rows of their slice; padded-slot layout with ~blocks/64 slots per slice.
+    int32_t *d_fold_ptr = nullptr;      // [nslices + 1] first folded slot of every slice
+    uint32_t *d_fold_meta = nullptr;    // [nslices * 64] own slots (16 bits) | first helper lane << 16 | helper lanes << 24
+    int4 *d_fold_plan = nullptr;        // [nslices * 64] own slots, owner lane (-1), offset in the owner's row, slots taken
+    int32_t *d_fold_cols = nullptr;     // [nfslots][64]
+    uint32_t *d_fold_cols16 = nullptr;  // packed column stream of the folded copy (cg.hip colstream) and its
+    int32_t *d_fold_colbase = nullptr;  //   per-slot bases,
+    int32_t *d_fold_pair_ptr = nullptr; //   per-slice first pairs,
+    uint8_t *d_fold_packed = nullptr;   //   per-slice flags
+    int64_t fold_slots_packed = 0;
+    double *d_fold_vals = nullptr;      // [nfslots][9][64], built on demand (per value stream)
+    float *d_fold_vals32 = nullptr;
+    uint32_t *d_fold_vals48 = nullptr;  // [nfslots][14][64]
+    int64_t nfslots = 0;
+    bool fold_cols_filled = false, fold_pack_tried = false;
+    int fold_state = 0;                 // 0: not examined, 1: planned, -1: not worth it / not applicable
     int32_t *d_red = nullptr;       // [n_dof] nDOF_reduction
     uint8_t *d_fixmask = nullptr;   // [nb_glob] bit m = DOF m of the node fixed
     double *d_scale = nullptr;      // [3*(nloc+nhalo)] s_i = 1/sqrt(K_ii)
@@ -340,10 +346,13 @@ int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode
                            double *avg_ms);
 int stan_spmv_local(stan_ctx *ctx, stan_matrix *K, const double *d_x, double *d_y);
 int stan_matrix_make_fp32(stan_ctx *ctx, stan_matrix *K);
-int stan_matrix_make_ragged(stan_ctx *ctx, stan_matrix *K, int32_t stream_kind);
-void stan_matrix_drop_ragged_values(stan_ctx *ctx, stan_matrix *K);
+// ---- fold.hip -------------------------------------------------------------------------------
+int stan_matrix_make_folded(stan_ctx *ctx, stan_matrix *K, int32_t stream_kind);
+void stan_matrix_drop_folded_values(stan_ctx *ctx, stan_matrix *K);
 int stan_matrix_make_fx48(stan_ctx *ctx, stan_matrix *K);
 int stan_matrix_make_cols16(stan_ctx *ctx, stan_matrix *K);
+int stan_pack_columns(stan_ctx *ctx, int32_t nslices, int64_t nslots, const int32_t *d_slot_ptr, const int32_t *d_cols,
+                      uint32_t **packed_out, int32_t **base_out, int32_t **pair_ptr_out, uint8_t **ok_out, int64_t *slots_packed);
 int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K);
 int stan_cg_workspace(stan_ctx *ctx, const stan_matrix *K);  // (re)allocates ctx->ws for K's sizes
 void stan_cg_workspace_free(stan_ctx *ctx);

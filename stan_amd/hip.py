@@ -31,7 +31,7 @@ OPT_SPMV_SMALL = 15
 OPT_PLACEMENT_MAX_BYTES = 16
 OPT_SELL_SIGMA = 17
 OPT_COMM_P2P = 18
-OPT_RAGGED_STREAM = 19
+OPT_ROW_FOLDING = 19
 E_HIP, E_ARG, E_ALLOC, E_DETJ, E_DOF_LAYOUT, E_VALENCE, E_COMM, E_UNSUPPORTED = (
     -1, -2, -3, -4, -5, -6, -7, -8)
 
@@ -67,7 +67,7 @@ class Profile(C.Structure):
                 ("loop_kernel_launches", C.c_int64), ("loop_collectives", C.c_int64),
                 ("loop_iterations_enqueued", C.c_int64), ("placement_candidates", C.c_int32),
                 ("placement_ms_best", C.c_float), ("placement_ms_worst", C.c_float),
-                ("col_slots_packed", C.c_int64), ("placement_moved_vectors", C.c_int32), ("ragged_stream", C.c_int32),
+                ("col_slots_packed", C.c_int64), ("placement_moved_vectors", C.c_int32), ("repacked_streams", C.c_int32),
                 ("loop_stream_waits", C.c_int64), ("comm_reduce_ms_total", C.c_double),
                 ("comm_reduce_calls", C.c_int64), ("comm_halo_ms_total", C.c_double), ("comm_halo_calls", C.c_int64)]
 

@@ -318,51 +318,73 @@ def test_console_driver_on_two_ranks_peer_to_peer(built_libs, tmp_path):
     assert out.returncode != 0 and "GPU_MAX_HW_QUEUES" in (out.stdout + out.stderr)
 
 
-OPT_RAGGED = 19
+OPT_FOLD = 19
+
+
+def _star_job(k, layers=3, rings=2):
+    from stan_amd.cube import star_mesh
+    xyz, conn = star_mesh(k, layers, rings)
+    z0 = np.nonzero(xyz[:, 2] == 0)[0]
+    top = np.nonzero(xyz[:, 2] == xyz[:, 2].max())[0]
+    return problem.make_job(xyz, conn, z0, np.ones((len(z0), 3)), top, np.tile([0.0, 10.0, 5.0], (len(top), 1)))
 
 
 @pytest.mark.parametrize("prec", [0, 1, 2])
-def test_ragged_streams_keep_every_bit(gpu_ctx, prec):
-    """STAN_OPT_RAGGED_STREAM (off by default): on a mesh with ragged slices (Database.cs:39-111 admits any CHEXA
-    mesh) the products read re-packed streams without the padding -- every row still adds the same products in
-    the same order: U, the iteration count and a plain product are identical, bit for bit, with the option off
-    and on, for the fp64, the fp32 and the FIXED-48 value stream, on a perforated box and on the cube."""
+@pytest.mark.parametrize("mesh", ["perforated", "star12", "cube"])
+def test_folded_rows_give_the_same_product(gpu_ctx, oracle, mesh, prec):
+    """STAN_OPT_ROW_FOLDING (fold.hip): the long rows of a slice lend their tails to the idle slots of its short
+    rows, so a wave walks ~blocks/64 slots instead of its slice's longest row -- without a row leaving its slice.
+    A folded row is summed as own part + pieces (another order): the product agrees with the padded layout's to
+    rounding, rows that are not folded keep their bits, the solve meets the oracle.  star12: rows of 75 blocks
+    (the centre line of a 12-sector star) among rows of 10-30: several helper lanes for one row."""
     from tests.perforated import perforated_job
-    perf = perforated_job(20, 0.4)
-    cube = problem.cube_job(10, jitter=0.05)
-    x = np.random.default_rng(11).standard_normal(perf.n_red)
+    job = perforated_job(18, 0.4) if mesh == "perforated" else _star_job(12, rings=1) if mesh == "star12" else problem.cube_job(9, jitter=0.05)
+    args = (job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+    x = np.random.default_rng(3).standard_normal(job.n_red)
+    eps = 1e-10 if prec == 0 else 1e-8
     out = {}
     try:
         gpu_ctx.set_profiling(True)
-        gpu_ctx.set_option(15, 0)              # STAN_OPT_SPMV_SMALL off: the small-system kernel never reads ragged streams
-        for name, job in (("perforated", perf), ("cube", cube)):
-            args = (job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
-            for rag in (0, 1):
-                gpu_ctx.set_option(OPT_RAGGED, rag)
-                K = gpu_ctx.assemble_hex8(*args)
-                if name == "perforated":
-                    assert _padding(K.info()) > 0.15
-                U, rep = K.cg_solve(job.F, 1e-9, precision_mode=prec)
-                used = gpu_ctx.profile()["ragged_stream"]
-                y = K.spmv(x) if name == "perforated" else None
-                out[(name, rag)] = (U, rep["iterations"], rep["terminationtype"], y, used)
-                K.free()
+        gpu_ctx.set_option(15, 0)              # STAN_OPT_SPMV_SMALL off: the small-system kernel reads the padded streams
+        for fold in (0, 1):
+            gpu_ctx.set_option(OPT_FOLD, fold)
+            K = gpu_ctx.assemble_hex8(*args)
+            U, rep = K.cg_solve(job.F, eps, precision_mode=prec)
+            used = gpu_ctx.profile()["repacked_streams"]
+            y = K.spmv(x)
+            out[fold] = (U, rep, y, used, K.info())
+            K.free()
+        # the default (-1): on where the plan saves more than 5 % of the slots, never on the cube
+        gpu_ctx.set_option(OPT_FOLD, -1)
+        K = gpu_ctx.assemble_hex8(*args)
+        K.cg_solve(job.F, eps, precision_mode=prec)
+        auto = gpu_ctx.profile()["repacked_streams"]
+        K.free()
     finally:
-        gpu_ctx.set_option(OPT_RAGGED, 0)
+        gpu_ctx.set_option(OPT_FOLD, -1)
         gpu_ctx.set_option(15, 1)
         gpu_ctx.set_profiling(False)
-    for name in ("perforated", "cube"):
-        a, b = out[(name, 0)], out[(name, 1)]
-        assert a[4] == 0 and b[4] == 1
-        assert a[1:3] == b[1:3] and np.array_equal(a[0], b[0])
-        assert a[2] in (1, 7) and np.abs(a[0]).max() > 0
-    assert np.array_equal(out[("perforated", 0)][3], out[("perforated", 1)][3])
+    a, b = out[0], out[1]
+    assert a[3] == 0 and b[3] == 1
+    assert auto == (0 if mesh == "cube" else 1)
+    ymax = np.abs(a[2]).max()
+    assert np.abs(b[2] - a[2]).max() <= 1e-13 * ymax, np.abs(b[2] - a[2]).max() / ymax
+    same = np.mean(b[2] == a[2])
+    assert same > (0.3 if mesh != "cube" else 0.9), same           # unfolded rows keep their bits
+    for r in (a[1], b[1]):
+        assert r["terminationtype"] in (1, 7)
+    assert abs(a[1]["iterations"] - b[1]["iterations"]) <= max(3, a[1]["iterations"] // 20)
+    rc, A = oracle.assemble(*args)
+    Uo, repo = oracle.cg(A, job.F, 1e-12)
+    tol = 1e-6 if prec == 0 else 1e-4
+    for U in (a[0], b[0]):
+        assert np.abs(U - Uo).max() <= tol * np.abs(Uo).max(), np.abs(U - Uo).max() / np.abs(Uo).max()
 
 
-def test_ragged_streams_in_a_sharded_solve(built_libs):
-    """The interior and the boundary product of a shard (slice lists) and the two-product launch of the refresh
-    iterations read the ragged streams as well: a three-rank solve of a perforated box gives the same bits with
-    the option off and on, classic and single-reduction loop."""
+def test_folded_rows_in_a_sharded_solve(built_libs):
+    """Folding plans slice by slice, and shards are cut on slice boundaries: the interior / boundary products of a
+    three-rank solve and the two-product launches of the refresh iterations read the folded streams; the solve
+    agrees with the unfolded one to the solver's tolerance."""
     code = r'''
 import numpy as np
 from stan_amd import hip
@@ -371,24 +393,25 @@ job = perforated_job(14, 0.35)
 args = (job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
 ctx = hip.Context(devices=[0, 0, 0])
 ctx.set_profiling(True)
-ctx.set_option(15, 0)   # STAN_OPT_SPMV_SMALL off (the small-system kernel never reads ragged streams)
+ctx.set_option(15, 0)   # STAN_OPT_SPMV_SMALL off
 res = {}
 for sr in (0, 1):
-    for rag in (0, 1):
-        ctx.set_option(19, rag)
+    for fold in (0, 1):
+        ctx.set_option(19, fold)
         ctx.set_option(10, sr)
         K = ctx.assemble_hex8(*args)
-        U, rep = K.cg_solve(job.F, 1e-9)
-        res[(sr, rag)] = (U, rep["iterations"], rep["terminationtype"], ctx.profile()["ragged_stream"])
+        U, rep = K.cg_solve(job.F, 1e-10)
+        res[(sr, fold)] = (U, rep["iterations"], rep["terminationtype"], ctx.profile()["repacked_streams"])
         K.free()
 for sr in (0, 1):
     a, b = res[(sr, 0)], res[(sr, 1)]
     assert a[3] == 0 and b[3] == 1, (a[3], b[3])
-    assert a[1:3] == b[1:3] and np.array_equal(a[0], b[0]), (sr, a[1:3], b[1:3])
-    assert a[2] in (1, 7) and np.abs(a[0]).max() > 0
+    assert a[2] in (1, 7) and b[2] in (1, 7)
+    assert abs(a[1] - b[1]) <= max(3, a[1] // 20), (a[1], b[1])
+    assert np.abs(a[0] - b[0]).max() <= 1e-6 * np.abs(a[0]).max(), np.abs(a[0] - b[0]).max() / np.abs(a[0]).max()
 ctx.close()
-print("RAGGED SHARDED OK")
+print("FOLDED SHARDED OK")
 '''
     env = dict(os.environ, STAN_RCCL_LIB=FAKE)
     rc, out, err = _run_script(code, env, 300)
-    assert rc == 0 and "RAGGED SHARDED OK" in out, out[-2000:] + err[-3000:]
+    assert rc == 0 and "FOLDED SHARDED OK" in out, out[-2000:] + err[-3000:]
