@@ -1195,12 +1195,15 @@ inline bool stan_small_system(const stan_ctx *ctx, const stan_matrix *K) {
 // the folded form of the value stream `vals` of K, if the products are to read it (fold.hip)
 template <typename VT> const VT *fold_vals(const stan_ctx *ctx, const stan_matrix *K, const VT *vals);
 template <> const double *fold_vals<double>(const stan_ctx *ctx, const stan_matrix *K, const double *vals) {
+    if (ctx->fold_probe && (const void *)vals == ctx->fold_probe) return vals;
     return ctx->row_folding != 0 && vals == K->d_vals ? K->d_fold_vals : nullptr;
 }
 template <> const float *fold_vals<float>(const stan_ctx *ctx, const stan_matrix *K, const float *vals) {
+    if (ctx->fold_probe && (const void *)vals == ctx->fold_probe) return vals;
     return ctx->row_folding != 0 && vals == K->d_vals32 ? K->d_fold_vals32 : nullptr;
 }
 template <> const uint32_t *fold_vals<uint32_t>(const stan_ctx *ctx, const stan_matrix *K, const uint32_t *vals) {
+    if (ctx->fold_probe && (const void *)vals == ctx->fold_probe) return vals;
     return ctx->row_folding != 0 && vals == K->d_vals48 ? K->d_fold_vals48 : nullptr;
 }
 inline colstream fold_cols_of(const stan_ctx *ctx, const stan_matrix *K) {

@@ -146,34 +146,44 @@ int stan_matrix_make_folded(stan_ctx *ctx, stan_matrix *K, int32_t stream_kind) 
         K->fold_state = 1;
     }
     const size_t n = (size_t)(K->nfslots > 0 ? K->nfslots : 1) * 64;
-    // the first fill also writes the columns (ocols); later fills (another value stream) only the values
-    int32_t *oc = K->fold_cols_filled ? nullptr : K->d_fold_cols;
+    if (!K->fold_cols_filled) {
+        // the columns first (k_fold_fill without values), then their packed stream (16-bit offsets from a per-slot
+        // base, cg.hip colstream): the placement search below times the real product on its candidates
+        hipLaunchKernelGGL((k_fold_fill<double, 0>), dim3(grid), dim3(256), 0, st, K->nslices, K->d_slot_ptr, K->d_fold_ptr,
+                           K->d_fold_plan, K->d_cols, (const double *)nullptr, K->d_fold_cols, (double *)nullptr);
+        HIPCHK(ctx, hipGetLastError());
+        K->fold_cols_filled = true;
+        if (ctx->cols16)
+            STANCHK(stan_pack_columns(ctx, K->nslices, K->nfslots, K->d_fold_ptr, K->d_fold_cols, &K->d_fold_cols16, &K->d_fold_colbase,
+                                      &K->d_fold_pair_ptr, &K->d_fold_packed, &K->fold_slots_packed));
+    }
+    // the value block is allocated by trial like the padded one (placement.hip): the folded product is timed on
+    // every candidate (stan_ctx::fold_probe tells the dispatch that the candidate is a FOLDED stream)
+    auto streamed = [&](void **p, size_t bytes, int32_t prec) {
+        return stan_dmalloc_streamed(ctx, p, bytes, [&, bytes, prec](const void *q, float *ms, bool self) {
+            ctx->fold_probe = q;
+            const int rc = stan_spmv_probe(ctx, K, q, bytes, prec, ms, self);
+            ctx->fold_probe = nullptr;
+            return rc;
+        });
+    };
     if (stream_kind == STAN_PREC_MIXED) {
         if (!K->d_fold_vals32 && K->d_vals32) {
-            STANCHK(stan_dmalloc(ctx, &K->d_fold_vals32, n * 9));
+            STANCHK(streamed((void **)&K->d_fold_vals32, n * 9 * 4, STAN_PREC_MIXED));
             hipLaunchKernelGGL((k_fold_fill<float, 9>), dim3(grid), dim3(256), 0, st, K->nslices, K->d_slot_ptr, K->d_fold_ptr,
-                               K->d_fold_plan, K->d_cols, K->d_vals32, oc, K->d_fold_vals32);
-            K->fold_cols_filled = true;
+                               K->d_fold_plan, K->d_cols, K->d_vals32, (int32_t *)nullptr, K->d_fold_vals32);
         }
     } else if (stream_kind == STAN_PREC_FIXED48) {
         if (!K->d_fold_vals48 && K->d_vals48) {
-            STANCHK(stan_dmalloc(ctx, &K->d_fold_vals48, n * 14));
+            STANCHK(streamed((void **)&K->d_fold_vals48, n * 14 * 4, STAN_PREC_FIXED48));
             hipLaunchKernelGGL((k_fold_fill<uint32_t, 14>), dim3(grid), dim3(256), 0, st, K->nslices, K->d_slot_ptr, K->d_fold_ptr,
-                               K->d_fold_plan, K->d_cols, K->d_vals48, oc, K->d_fold_vals48);
-            K->fold_cols_filled = true;
+                               K->d_fold_plan, K->d_cols, K->d_vals48, (int32_t *)nullptr, K->d_fold_vals48);
         }
     } else if (!K->d_fold_vals) {
-        STANCHK(stan_dmalloc(ctx, &K->d_fold_vals, n * 9));
+        STANCHK(streamed((void **)&K->d_fold_vals, n * 9 * 8, STAN_PREC_FP64));
         hipLaunchKernelGGL((k_fold_fill<double, 9>), dim3(grid), dim3(256), 0, st, K->nslices, K->d_slot_ptr, K->d_fold_ptr,
-                           K->d_fold_plan, K->d_cols, K->d_vals, oc, K->d_fold_vals);
-        K->fold_cols_filled = true;
+                           K->d_fold_plan, K->d_cols, K->d_vals, (int32_t *)nullptr, K->d_fold_vals);
     }
     HIPCHK(ctx, hipGetLastError());
-    // the folded columns get their own packed stream (16-bit offsets from a per-slot base, cg.hip colstream)
-    if (K->fold_cols_filled && ctx->cols16 && !K->d_fold_cols16 && !K->fold_pack_tried) {
-        K->fold_pack_tried = true;
-        STANCHK(stan_pack_columns(ctx, K->nslices, K->nfslots, K->d_fold_ptr, K->d_fold_cols, &K->d_fold_cols16, &K->d_fold_colbase,
-                                  &K->d_fold_pair_ptr, &K->d_fold_packed, &K->fold_slots_packed));
-    }
     return STAN_OK;
 }

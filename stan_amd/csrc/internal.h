@@ -227,6 +227,7 @@ struct stan_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     int assembly_mode = 0;     // 0 row-owner gather (default), 1 element-wave colour scatter
+    const void *fold_probe = nullptr;  // placement search: this candidate block is a FOLDED value stream (fold.hip)
     int row_folding = -1;      // STAN_OPT_ROW_FOLDING: -1 = products read the folded streams (fold.hip) when they save > 5 % of the slots; 1 always; 0 never
     int sell_sigma = 1;        // SELL-C-sigma: rows sorted by length inside windows of this many slices (1: inside each slice only)
     int placement_tries = 16;  // > 1: allocate the value stream by search (placement.hip); blocks >= 256 MB only
@@ -290,7 +291,7 @@ struct stan_matrix {
     float *d_fold_vals32 = nullptr;
     uint32_t *d_fold_vals48 = nullptr;  // [nfslots][14][64]
     int64_t nfslots = 0;
-    bool fold_cols_filled = false, fold_pack_tried = false;
+    bool fold_cols_filled = false;
     int fold_state = 0;                 // 0: not examined, 1: planned, -1: not worth it / not applicable
     int32_t *d_red = nullptr;       // [n_dof] nDOF_reduction
     uint8_t *d_fixmask = nullptr;   // [nb_glob] bit m = DOF m of the node fixed
