@@ -1540,7 +1540,14 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     // the stream the products really read (FIXED-48 falls back to fp64 when K is not SPD-scalable)
     const int vs = precision_mode == STAN_PREC_FIXED48 ? (K->d_vals48 ? STAN_PREC_FIXED48 : STAN_PREC_FP64)
                                                        : precision_mode;
-    if (!stan_small_system(ctx, K)) STANCHK(stan_matrix_make_folded(ctx, K, vs));
+    if (!stan_small_system(ctx, K)) {
+        const int rc_fold = stan_matrix_make_folded(ctx, K, vs);
+        if (rc_fold == STAN_E_ALLOC) {   // an optimisation must not fail the solve: the padded streams serve
+            stan_matrix_abandon_folding(ctx, K);
+            ctx->err.clear();
+        } else
+            STANCHK(rc_fold);
+    }
     const bool sr = ctx->cg_single_reduce;
     const bool foldr = ctx->cg_fold_reduce;
 

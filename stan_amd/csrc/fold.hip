@@ -106,6 +106,18 @@ void stan_matrix_drop_folded_values(stan_ctx *ctx, stan_matrix *K) {
     if (K->d_fold_vals48) { stan_dfree(ctx, K->d_fold_vals48); K->d_fold_vals48 = nullptr; }
 }
 
+// no memory for a second copy of the streams: give everything back, the padded streams serve
+void stan_matrix_abandon_folding(stan_ctx *ctx, stan_matrix *K) {
+    stan_matrix_drop_folded_values(ctx, K);
+    for (void **q : {(void **)&K->d_fold_ptr, (void **)&K->d_fold_meta, (void **)&K->d_fold_plan, (void **)&K->d_fold_cols,
+                     (void **)&K->d_fold_cols16, (void **)&K->d_fold_colbase, (void **)&K->d_fold_pair_ptr, (void **)&K->d_fold_packed}) {
+        stan_dfree(ctx, *q);
+        *q = nullptr;
+    }
+    K->fold_cols_filled = false;
+    K->fold_state = -1;
+}
+
 // Folded copies of the column stream and of the value stream `stream_kind`, built when STAN_OPT_ROW_FOLDING asks
 // for them (1: always; -1, the default: when the plan saves more than 5 % of the slots).  The padded streams stay: scaling,
 // export and the placement search work on them.
@@ -117,6 +129,9 @@ int stan_matrix_make_folded(stan_ctx *ctx, stan_matrix *K, int32_t stream_kind) 
         int32_t *width = nullptr;
         int64_t *ptr64 = nullptr;
         struct tmp { stan_ctx *c; int32_t **a; int64_t **b; ~tmp() { stan_dfree(c, *a); stan_dfree(c, *b); } } guard{ctx, &width, &ptr64};
+        // (an earlier attempt that ran out of memory may have left these behind)
+        stan_dfree(ctx, K->d_fold_plan); K->d_fold_plan = nullptr;
+        stan_dfree(ctx, K->d_fold_meta); K->d_fold_meta = nullptr;
         STANCHK(stan_dmalloc(ctx, &width, (size_t)K->nslices + 1));
         STANCHK(stan_dmalloc(ctx, &ptr64, (size_t)K->nslices + 2));
         STANCHK(stan_dmalloc(ctx, &K->d_fold_plan, (size_t)K->nslices * 64));

@@ -350,6 +350,7 @@ int stan_matrix_make_fp32(stan_ctx *ctx, stan_matrix *K);
 // ---- fold.hip -------------------------------------------------------------------------------
 int stan_matrix_make_folded(stan_ctx *ctx, stan_matrix *K, int32_t stream_kind);
 void stan_matrix_drop_folded_values(stan_ctx *ctx, stan_matrix *K);
+void stan_matrix_abandon_folding(stan_ctx *ctx, stan_matrix *K);
 int stan_matrix_make_fx48(stan_ctx *ctx, stan_matrix *K);
 int stan_matrix_make_cols16(stan_ctx *ctx, stan_matrix *K);
 int stan_pack_columns(stan_ctx *ctx, int32_t nslices, int64_t nslots, const int32_t *d_slot_ptr, const int32_t *d_cols,

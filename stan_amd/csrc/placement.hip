@@ -96,6 +96,8 @@ int stan_dmalloc_streamed(stan_ctx *ctx, void **p, size_t bytes,
                           const std::function<int(const void *, float *, bool)> &probe) {
     const int tries = ctx->placement_tries;
     if (tries <= 1 || bytes < ((size_t)256 << 20) || !probe) return stan_dmalloc_bytes(ctx, p, bytes);
+    // inside a peer-to-peer solve nothing may call hipFree (stan_ctx::defer_frees): no candidates to give back
+    if (ctx->defer_frees) return stan_dmalloc_bytes(ctx, p, bytes);
     // a parked block of the right size was chosen by an earlier search: take it
     for (const stan_pool::blk &b : ctx->pool.avail)
         if (b.cap >= bytes && b.cap <= bytes + bytes / 2) return stan_dmalloc_bytes(ctx, p, bytes);
