@@ -1,4 +1,6 @@
-"""Fuzz sweep of the hot path against the oracle (tests/fuzz.py): python tools/fuzz_parity.py [first] [count]"""
+"""Fuzz sweep of the hot path against the oracle (tests/fuzz.py): python tools/fuzz_parity.py [first] [count] [fold]
+fold = 1: the products of every job read the FOLDED streams (STAN_OPT_ROW_FOLDING forced on, the small-system kernel
+off: the jobs are tiny), so the sweep exercises fold.hip's plans on a few hundred ragged meshes."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,6 +12,12 @@ from tests import fuzz
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 ctx = hip.Context(0)
+fold = len(sys.argv) > 3 and int(sys.argv[3]) != 0
+if fold:
+    ctx.set_option(hip.OPT_SPMV_SMALL, 0)
+    ctx.set_option(hip.OPT_ROW_FOLDING, 1)
+    ctx.set_profiling(True)
+folded_jobs = 0
 ok = skipped = 0
 worst = {"k_err": 0.0, "u_err": 0.0, "res": 0.0, "res48": 0.0}
 for seed in range(first, first + count):
@@ -23,6 +31,8 @@ for seed in range(first, first + count):
         print("seed %d FAILED: %s" % (seed, e))
         raise
     ok += 1
+    if fold and ctx.profile()["repacked_streams"]:
+        folded_jobs += 1
     worst["k_err"] = max(worst["k_err"], out.get("k_err", 0.0))
     worst["u_err"] = max(worst["u_err"], out.get("u_err", 0.0))
     worst["res"] = max(worst["res"], out.get("res", (0.0, 0.0))[0])
@@ -30,3 +40,5 @@ for seed in range(first, first + count):
     if seed % 20 == 0:
         print("seed %d: %s" % (seed, out), flush=True)
 print("fuzz: %d jobs checked, %d disconnected meshes skipped; worst %s" % (ok, skipped, worst))
+if fold:
+    print("folded streams read in the last solve of %d jobs" % folded_jobs)
