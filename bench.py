@@ -393,6 +393,7 @@ def main():
                        # SELL-C-sigma: slots streamed per structural block - 1 (padded slots are streamed like real ones)
                        "ell_padding": info["n_slots"] * 64.0 / max(info["n_blocks"], 1) - 1.0,
                        "sell_sigma": info["sell_sigma"], "repacked_streams": "folded rows" if prof["repacked_streams"] else "none",
+                       "folded_slots_over_padded_slots": info["folded_slots_permille"] / 1000.0 if info["folded_slots_permille"] else None,
                        "parallelism": "rows sharded x%d" % world,
                        "transport": ("one rank" if world == 1 else
                                      "RCCL %s (ncclGetVersion %d), communicator of %d ranks, this = rank %d%s" %

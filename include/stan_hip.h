@@ -292,7 +292,8 @@ typedef struct stan_matrix_info {
                                      that touch its rows; summed over the devices of a group handle */
     int32_t sell_sigma;   /* sorting window (slices) the matrix was built with (STAN_OPT_SELL_SIGMA); the padding
                              of the layout is n_slots*64/n_blocks - 1 */
-    int32_t reserved0;
+    int32_t folded_slots_permille; /* 0: no folded copy (STAN_OPT_ROW_FOLDING); else 1000 * its slots / n_slots (840: a wave
+                                      walks 16 % fewer slots than in the padded layout); known after the first solve */
 } stan_matrix_info;
 int stan_hip_matrix_info(stan_matrix *K, stan_matrix_info *out);
 

@@ -453,7 +453,8 @@ int stan_hip_matrix_info(stan_matrix *K, stan_matrix_info *o) {
     o->max_row_blocks = K->max_row_blocks;
     o->n_elements_on_device = K->n_elem_scanned;
     o->sell_sigma = K->parts.empty() ? K->sigma : K->parts[0]->sigma;
-    o->reserved0 = 0;
+    const stan_matrix *P = K->parts.empty() ? K : K->parts[0];
+    o->folded_slots_permille = P->fold_state == 1 && P->nslots > 0 ? (int32_t)(1000 * P->nfslots / P->nslots) : 0;
     return STAN_OK;
 }
 

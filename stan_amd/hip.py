@@ -54,7 +54,7 @@ class MatrixInfo(C.Structure):
                 ("row_begin", C.c_int64), ("row_end", C.c_int64), ("n_halo", C.c_int64),
                 ("n_blocks", C.c_int64), ("n_slots", C.c_int64), ("bytes_matrix", C.c_int64),
                 ("scaled", C.c_int32), ("max_row_blocks", C.c_int32), ("n_elements_on_device", C.c_int64),
-                ("sell_sigma", C.c_int32), ("reserved0", C.c_int32)]
+                ("sell_sigma", C.c_int32), ("folded_slots_permille", C.c_int32)]
 
 
 class Profile(C.Structure):

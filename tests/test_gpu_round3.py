@@ -367,6 +367,9 @@ def test_folded_rows_give_the_same_product(gpu_ctx, oracle, mesh, prec):
     a, b = out[0], out[1]
     assert a[3] == 0 and b[3] == 1
     assert auto == (0 if mesh == "cube" else 1)
+    assert a[4]["folded_slots_permille"] == 0 and 0 < b[4]["folded_slots_permille"] <= 1000
+    if mesh != "cube":
+        assert b[4]["folded_slots_permille"] < 900, b[4]["folded_slots_permille"]     # > 10 % fewer slots per wave
     ymax = np.abs(a[2]).max()
     assert np.abs(b[2] - a[2]).max() <= 1e-13 * ymax, np.abs(b[2] - a[2]).max() / ymax
     same = np.mean(b[2] == a[2])
