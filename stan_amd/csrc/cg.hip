@@ -792,16 +792,24 @@ k_spmv_fold(int32_t nslices, int64_t nloc, const int32_t *__restrict__ fold_ptr,
         }
 #undef STAN_FOLD_BLOCK
     }
-    fsh[w][0][lane] = f0; fsh[w][1][lane] = f1; fsh[w][2][lane] = f2;
-    if (NRHS == 2) { fsh[w][3][lane] = g0; fsh[w][4][lane] = g1; fsh[w][5][lane] = g2; }
-    __syncthreads();
-    if (slice < nslices) {
-        const int hfirst = (int)((m >> 16) & 0xffu), nh = (int)(m >> 24);
+    // The exchange is wave-local (a slice is one wavefront): the LDS executes one wave's instructions in order, so
+    // the reads below see the writes above without a workgroup barrier -- the four slices of a workgroup do not
+    // wait for each other here; a slice without folded rows skips it altogether.
+    const int nh = (int)(m >> 24);
+    if (__any(nh > 0)) {
+        fsh[w][0][lane] = f0; fsh[w][1][lane] = f1; fsh[w][2][lane] = f2;
+        if (NRHS == 2) { fsh[w][3][lane] = g0; fsh[w][4][lane] = g1; fsh[w][5][lane] = g2; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int hfirst = (int)((m >> 16) & 0xffu);
         for (int h = 0; h < nh; h++) {   // a folded row: own part + its pieces, last lane first
             const int j = hfirst - h;
             y0 += fsh[w][0][j]; y1 += fsh[w][1][j]; yy2 += fsh[w][2][j];
             if (NRHS == 2) { z0 += fsh[w][3][j]; z1 += fsh[w][4][j]; z2 += fsh[w][5][j]; }
         }
+    }
+    if (slice < nslices) {
         if (row < nloc) {
 #if STAN_Y_NT
             __builtin_nontemporal_store(y0, y + 3 * row); __builtin_nontemporal_store(y1, y + 3 * row + 1);
