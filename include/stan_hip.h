@@ -168,7 +168,7 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
                            matrix); rows that are not folded keep their bits.  Built at the first solve next to the
                            padded streams, which the scaling, the export and the placement search keep using.  -1: when
                            the plan saves more than 5 % of the slots (a box with 40 % of its elements missing: 16 %, SpMV
-                           -9.5 ... -16 %, FIXED-48 -10 ... -19 %; the cube: 0 %, never); 1: always; 0: never. */
+                           -13 ... -19 %, +11 ... +20 % DOF/s; the cube: 0 %, never); 1: always; 0: never. */
 #define STAN_OPT_COMM_P2P 18 /* one-process multi-device handle only (stan_hip_init_multi).  0 (default): the sharded CG
                            exchanges over RCCL (2 all-reduce launches + 1 grouped send/recv per iteration).  1: peer to
                            peer -- no collective launch in the loop: the block that finishes a reduction stores this

@@ -616,8 +616,10 @@ k_spmv_small(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr
 // Two right-hand sides in ONE pass over the matrix: y = A x and y2 = A x2 (+ the x.y partial).
 // Used on the residual-refresh iterations: r = b - A(x + a p) = b - (A x + a A p), so the
 // refresh needs A x next to the A p every iteration needs -- one matrix stream instead of two.
+// 128-VGPR budget (4 waves per SIMD): with the default target the four gathers of a trip (x and x2 of two slots) were
+// issued one by one, each behind a wait for earlier data
 template <typename VT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4)))
 k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, const int32_t *__restrict__ rowof,
         const int32_t *__restrict__ cols, const VT *__restrict__ vals,
         const double *__restrict__ x, const double *__restrict__ x2, double *__restrict__ y,
@@ -712,7 +714,9 @@ k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, con
 // Two accumulators per lane; the foreign ones go through LDS and each folded row adds its helpers' sums in a
 // fixed order (descending lane).  NRHS = 1: k_spmv (DOT as there); NRHS = 2: k_spmv2.
 template <typename VT, int DOT, int NRHS>
-__global__ void __launch_bounds__(256)
+// at most 5 waves per SIMD (96 VGPRs): with the default target of 6 (80 VGPRs) the scheduler issues the gathers of a
+// trip's second slot only after the first slot's data has arrived -- one more dependent round trip per trip
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, (NRHS == 2 ? 4 : 5))))
 k_spmv_fold(int32_t nslices, int64_t nloc, const int32_t *__restrict__ fold_ptr, const int32_t *__restrict__ rowof,
             const uint32_t *__restrict__ meta, const int32_t *__restrict__ cols, const VT *__restrict__ vals,
             const double *__restrict__ x, const double *__restrict__ x2, double *__restrict__ y, double *__restrict__ y2,
@@ -741,24 +745,29 @@ k_spmv_fold(int32_t nslices, int64_t nloc, const int32_t *__restrict__ fold_ptr,
         const int32_t k0 = fold_ptr[slice], k1 = fold_ptr[slice + 1];
         const int32_t *cp = cols + (int64_t)k0 * 64 + lane;
         const VT *vp = vals + (int64_t)k0 * vstream<VT>::STRIDE + lane;
-#define STAN_FOLD_BLOCK(C, VP, KL)                                                              \
+// LOAD then MATH for both slots of a trip: with the two accumulator sets the scheduler otherwise
+// issued the gathers of a trip's SECOND slot only after the first slot's data had arrived (one more dependent round
+// trip per trip: the folded kernel was 3-6 % slower than k_spmv at equal slot counts).
+#define STAN_FOLD_LOAD(S, C, VP)                                                                \
+        double a##S[9];                                                                         \
+        load9<true, VT>(VP, a##S);                                                              \
+        double x0##S = x[3 * (C)], x1##S = x[3 * (C) + 1], x2##S = x[3 * (C) + 2];              \
+        double u0##S = 0, u1##S = 0, u2##S = 0;                                                 \
+        if (NRHS == 2) { u0##S = x2[3 * (C)]; u1##S = x2[3 * (C) + 1]; u2##S = x2[3 * (C) + 2]; }
+#define STAN_FOLD_MATH(S, KL)                                                                   \
     {                                                                                           \
-        double a[9];                                                                            \
-        load9<true, VT>(VP, a);                                                                 \
-        double x0 = x[3 * (C)], x1 = x[3 * (C) + 1], xx2 = x[3 * (C) + 2];                      \
-        if (vstream<VT>::FX) { x0 *= FX48_INV; x1 *= FX48_INV; xx2 *= FX48_INV; }               \
-        const double t0 = a[0] * x0 + a[1] * x1 + a[2] * xx2;                                   \
-        const double t1 = a[3] * x0 + a[4] * x1 + a[5] * xx2;                                   \
-        const double t2 = a[6] * x0 + a[7] * x1 + a[8] * xx2;                                   \
+        if (vstream<VT>::FX) { x0##S *= FX48_INV; x1##S *= FX48_INV; x2##S *= FX48_INV; }       \
+        const double t0 = a##S[0] * x0##S + a##S[1] * x1##S + a##S[2] * x2##S;                  \
+        const double t1 = a##S[3] * x0##S + a##S[4] * x1##S + a##S[5] * x2##S;                  \
+        const double t2 = a##S[6] * x0##S + a##S[7] * x1##S + a##S[8] * x2##S;                  \
         const bool mine = (KL) < own;                                                           \
         y0 += mine ? t0 : 0.0; y1 += mine ? t1 : 0.0; yy2 += mine ? t2 : 0.0;                   \
         f0 += mine ? 0.0 : t0; f1 += mine ? 0.0 : t1; f2 += mine ? 0.0 : t2;                    \
         if (NRHS == 2) {                                                                        \
-            double u0 = x2[3 * (C)], u1 = x2[3 * (C) + 1], u2 = x2[3 * (C) + 2];                \
-            if (vstream<VT>::FX) { u0 *= FX48_INV; u1 *= FX48_INV; u2 *= FX48_INV; }            \
-            const double s0 = a[0] * u0 + a[1] * u1 + a[2] * u2;                                \
-            const double s1 = a[3] * u0 + a[4] * u1 + a[5] * u2;                                \
-            const double s2 = a[6] * u0 + a[7] * u1 + a[8] * u2;                                \
+            if (vstream<VT>::FX) { u0##S *= FX48_INV; u1##S *= FX48_INV; u2##S *= FX48_INV; }   \
+            const double s0 = a##S[0] * u0##S + a##S[1] * u1##S + a##S[2] * u2##S;              \
+            const double s1 = a##S[3] * u0##S + a##S[4] * u1##S + a##S[5] * u2##S;              \
+            const double s2 = a##S[6] * u0##S + a##S[7] * u1##S + a##S[8] * u2##S;              \
             z0 += mine ? s0 : 0.0; z1 += mine ? s1 : 0.0; z2 += mine ? s2 : 0.0;                \
             g0 += mine ? 0.0 : s0; g1 += mine ? 0.0 : s1; g2 += mine ? 0.0 : s2;                \
         }                                                                                       \
@@ -767,30 +776,45 @@ k_spmv_fold(int32_t nslices, int64_t nloc, const int32_t *__restrict__ fold_ptr,
             const uint32_t *cq = cs.packed + (int64_t)cs.pair_ptr[slice] * 64 + lane;
             const int32_t *bp = cs.base + __builtin_amdgcn_readfirstlane(k0);
             int32_t k = k0;
+            // the packed offsets of a trip are loaded one trip ahead: both gathers of a trip can go out with its values
+            uint32_t wd = __builtin_nontemporal_load(cq);
             for (; k + 1 < k1; k += 2) {
-                const uint32_t wd = __builtin_nontemporal_load(cq);
+                const uint32_t wn = __builtin_nontemporal_load(k + 2 < k1 ? cq + 64 : cq);
                 const int64_t c = (int64_t)bp[0] + (int64_t)(wd & 0xffffu);
                 const int64_t c2 = (int64_t)bp[1] + (int64_t)(wd >> 16);
-                STAN_FOLD_BLOCK(c, vp, k - k0)
-                STAN_FOLD_BLOCK(c2, vp + vstream<VT>::STRIDE, k - k0 + 1)
+                STAN_FOLD_LOAD(A, c, vp)
+                STAN_FOLD_LOAD(B, c2, vp + vstream<VT>::STRIDE)
+                STAN_FOLD_MATH(A, k - k0)
+                STAN_FOLD_MATH(B, k - k0 + 1)
                 cq += 64;
                 bp += 2;
                 vp += 2 * vstream<VT>::STRIDE;
+                wd = wn;
             }
             if (k < k1) {
-                const int64_t c = (int64_t)bp[0] + (int64_t)(__builtin_nontemporal_load(cq) & 0xffffu);
-                STAN_FOLD_BLOCK(c, vp, k - k0)
+                const int64_t c = (int64_t)bp[0] + (int64_t)(wd & 0xffffu);
+                STAN_FOLD_LOAD(A, c, vp)
+                STAN_FOLD_MATH(A, k - k0)
             }
         } else {
-#pragma unroll 2
-            for (int32_t k = k0; k < k1; k++) {
+            int32_t k = k0;
+            for (; k + 1 < k1; k += 2) {
+                const int64_t c = __builtin_nontemporal_load(cp), c2 = __builtin_nontemporal_load(cp + 64);
+                STAN_FOLD_LOAD(A, c, vp)
+                STAN_FOLD_LOAD(B, c2, vp + vstream<VT>::STRIDE)
+                STAN_FOLD_MATH(A, k - k0)
+                STAN_FOLD_MATH(B, k - k0 + 1)
+                cp += 128;
+                vp += 2 * vstream<VT>::STRIDE;
+            }
+            if (k < k1) {
                 const int64_t c = __builtin_nontemporal_load(cp);
-                STAN_FOLD_BLOCK(c, vp, k - k0)
-                cp += 64;
-                vp += vstream<VT>::STRIDE;
+                STAN_FOLD_LOAD(A, c, vp)
+                STAN_FOLD_MATH(A, k - k0)
             }
         }
-#undef STAN_FOLD_BLOCK
+#undef STAN_FOLD_LOAD
+#undef STAN_FOLD_MATH
     }
     // The exchange is wave-local (a slice is one wavefront): the LDS executes one wave's instructions in order, so
     // the reads below see the writes above without a workgroup barrier -- the four slices of a workgroup do not
