@@ -170,6 +170,9 @@ def main():
     ap.add_argument("--placement-tries", type=int, default=32,
                     help="STAN_OPT_PLACEMENT_TRIES: candidates the allocation-by-search of K's value array may time in "
                          "the first (warm-up) assembly (library default 16; 1 = plain allocation)")
+    ap.add_argument("--placement-fraction", type=float, default=0.75,
+                    help="fraction of the free device memory the placement search may hold while it runs "
+                         "(STAN_OPT_PLACEMENT_MAX_BYTES; 0 = the library's default, a quarter)")
     ap.add_argument("--p2p", action="store_true",
                     help="STAN_OPT_COMM_P2P (N > 1): the CG's reductions and halo exchanges go peer to peer between the "
                          "rank processes (HIP IPC mappings; no RCCL launch in the loop) instead of over RCCL")
@@ -227,6 +230,13 @@ def main():
         ctx.comm_init(rank, world, bytes(uid.cpu().tolist()))
     ctx.set_option(hip.OPT_CG_MERIT_STOP, 0)
     ctx.set_option(hip.OPT_PLACEMENT_TRIES, max(1, min(64, args.placement_tries)))
+    # The library, living inside a foreign host process, lets its placement search hold a quarter of the free device
+    # memory at most (11 candidates at 148^3); this process owns its GPU: three quarters (the runs of one memory group
+    # can be 150 GB long, placement.hip).  The search runs in the first warm-up step, never in the timed region.
+    placement_budget = 0
+    if args.placement_fraction > 0 and not os.environ.get("STAN_BENCH_DEVICE"):   # (ranks sharing one GPU in the tests: default)
+        placement_budget = int(args.placement_fraction * torch.cuda.mem_get_info(dev)[0])
+        ctx.set_option(hip.OPT_PLACEMENT_MAX_BYTES, placement_budget)
     if args.single_reduce:
         ctx.set_option(hip.OPT_CG_SINGLE_REDUCE, 1)
     if args.sell_sigma > 0:
@@ -367,7 +377,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             # non-default library options this number depends on (DESIGN.md sections 3, 4)
-            "merit_stop": False, "placement_tries": args.placement_tries,
+            "merit_stop": False, "placement_tries": args.placement_tries, "placement_max_bytes": placement_budget,
             "dtype": ("f32 matrix / f64 vectors" if args.mixed else
                       "f64 (matrix streamed as 48-bit fixed point)" if args.fixed48 else "f64"),
             "data": "synthetic",
