@@ -105,7 +105,7 @@ def test_sharded_solve_peer_to_peer_between_processes(built_libs, tmp_path, worl
 def test_bench_multi_rank_code_path(built_libs):
     """bench.py --gpus 2 (gloo control plane, both ranks on GPU 0): one JSON line, converged."""
     out = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-                        "--size", "16", "--no-cpu"],
+                        "--size", "16", "--no-cpu", "--no-p2p-probe"],
                     {"STAN_BENCH_BACKEND": "gloo", "STAN_BENCH_DEVICE": "0"})
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -130,7 +130,7 @@ def test_bench_multi_rank_peer_to_peer(built_libs):
     lines = {}
     for flag in ([], ["--p2p"]):
         out = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-                            "--size", "14", "--no-cpu"] + flag,
+                            "--size", "14", "--no-cpu", "--no-p2p-probe"] + flag,
                         {"STAN_BENCH_BACKEND": "gloo", "STAN_BENCH_DEVICE": "0"})
         assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
         lines[bool(flag)] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
@@ -158,3 +158,73 @@ def test_bench_watchdog_ends_a_stuck_multi_rank_run(built_libs):
     assert d["value"] is None and "watchdog" in d["error"] and d["watchdog"]["rank"] == 0
     assert "warm-up" in d["watchdog"]["phase"] and d["n_gpus"] == 2
     assert took < 100, took     # launcher start + torch import + 12 s bound + teardown
+
+
+def _bench_no_launcher(script_args, env_extra, timeout=420):
+    """`python bench.py --gpus N ...` typed the way the driver types it: NO launcher around it."""
+    env = dict(os.environ, STAN_RCCL_LIB=FAKE, STAN_BENCH_BACKEND="gloo", STAN_BENCH_DEVICE="0", **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + script_args
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT,
+                            start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)     # (the launcher's children sit in a group of their own: it ends them)
+        out, err = proc.communicate()
+        raise AssertionError("bench.py did not end:\n" + (err or "")[-3000:])
+    return subprocess.CompletedProcess(cmd, proc.returncode, out, err)
+
+
+def test_bench_gpus_2_without_a_launcher(built_libs):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts its two rank processes itself
+    (fresh children, the parent never touches the GPU), relays ONE JSON line and the exit code; the line carries the
+    capped comparison of the two transports and says which one it would select."""
+    out = _bench_no_launcher(["--gpus", "2", "--steps", "1", "--warmup", "1", "--size", "16", "--no-cpu",
+                              "--probe-its", "40"], {})
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["converged"] and d["value"] > 0
+    assert d["config"]["parallelism"] == "rows sharded x2"
+    pr = d["config"]["p2p_probe"]
+    assert pr["capped_at_iterations"] == 40 and pr["rccl"]["iterations"] == pr["p2p"]["iterations"] == 40
+    assert pr["same_residual_bits"]                                   # rank-ordered sums on both transports
+    assert pr["rccl"]["collectives_per_iteration"] >= 2 and pr["p2p"]["collectives_per_iteration"] == 0
+    assert pr["p2p"]["stream_waits_per_iteration"] >= 2 and pr["rccl"]["stream_waits_per_iteration"] == 0
+    assert pr["rccl"]["ms_per_iteration"] > 0 and pr["p2p"]["ms_per_iteration"] > 0
+    assert d["config"]["recommended_transport"] == pr["recommended"]
+    assert pr["recommended"].split()[0] in ("rccl", "p2p")
+
+
+def test_bench_probe_that_stalls_leaves_the_line_alone(built_libs):
+    """The transport probe is an optional extra behind the measurement: rank 1 never enters its peer-to-peer leg
+    (test hook), rank 0 blocks in the collective set-up; the probe's own watchdog prints the measured line
+    unchanged and the job ends with code 0."""
+    out = _bench_no_launcher(["--gpus", "2", "--steps", "1", "--warmup", "1", "--size", "12", "--no-cpu",
+                              "--probe-its", "20", "--probe-watchdog", "8"], {"STAN_BENCH_TEST_HANG_PROBE": "1"})
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["converged"] and d["value"] > 0
+    assert "p2p_probe" not in d["config"] and "error" not in d
+
+
+def test_bench_one_process_mode(built_libs):
+    """--one-process: the handle of stan_hip_init_multi (what the reference's single process would use) timed by
+    bench.py: two ranks of ONE process on GPU 0 over the test transport, same answer as the one-rank handle."""
+    res = {}
+    for n in (1, 2):
+        out = _bench_no_launcher(["--gpus", str(n), "--one-process", "--steps", "1", "--warmup", "1", "--size", "14",
+                                  "--no-cpu"], {})
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        res[n] = json.loads(lines[0])
+        assert res[n]["n_gpus"] == n and res[n]["config"]["converged"] and res[n]["value"] > 0
+        assert "ONE process" in res[n]["config"]["process_model"]
+    assert abs(res[1]["config"]["cg_iterations"] - res[2]["config"]["cg_iterations"]) <= 1
+    assert abs(res[1]["config"]["u_max"] - res[2]["config"]["u_max"]) <= 1e-7 * res[1]["config"]["u_max"]
