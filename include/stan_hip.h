@@ -165,11 +165,22 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
                            longest row, and no row leaves its slice (the gather locality of 64 consecutive AssignDOF rows
                            stays -- SELL-C-sigma windows give that up).  A folded row is summed as own part + pieces:
                            another order than the padded layout's (deterministic; identical for a shard and the whole
-                           matrix); rows that are not folded keep their bits.  Built at the first solve next to the
+                           matrix WITH the option at 1 and STAN_OPT_SELL_SIGMA at 1: in auto mode every shard takes its own
+                           > 5 % decision and its own out-of-memory fallback, and sorting windows of sigma > 1 are aligned
+                           to the shard's first row, so a row may be folded in a shard and not in the whole matrix -- the
+                           results then agree to rounding, not to the bit); rows that are not folded keep their bits.  Built at the first solve next to the
                            padded streams, which the scaling, the export and the placement search keep using.  -1: when
                            the plan saves more than 5 % of the slots (a box with 40 % of its elements missing: 16 %, SpMV
-                           -13 ... -19 %, +11 ... +20 % DOF/s; the cube: 0 %, never); 1: always; 0: never. */
-#define STAN_OPT_COMM_P2P 18 /* one-process multi-device handle only (stan_hip_init_multi).  0 (default): the sharded CG
+                           -13 ... -19 %, +11 ... +20 % DOF/s; the cube: 0 %, never); 1: always (also for a matrix that the
+                           auto rule declined earlier); 0: never. */
+#define STAN_OPT_COMM_P2P 18 /* on a one-process multi-device handle (stan_hip_init_multi), or -- process-per-GPU form -- on
+                           the context of EVERY rank of a communicator: there the call is a COLLECTIVE (the ranks' HIP IPC
+                           handles travel over the communicator; a rank that does not make it leaves the others blocked in
+                           an all-gather), the wait kernels need one hardware queue per stream (GPU_MAX_HW_QUEUES >= 2 N + 2
+                           when N ranks share a device, as the tests do), and a rank whose stream makes no progress for
+                           STAN_P2P_STALL_S seconds (default 120: a peer died) releases its own waits and returns
+                           STAN_E_COMM from the solve; the exchange stays refused afterwards -- leave the process, never
+                           re-execute it.  0 (default): the sharded CG
                            exchanges over RCCL (2 all-reduce launches + 1 grouped send/recv per iteration).  1: peer to
                            peer -- no collective launch in the loop: the block that finishes a reduction stores this
                            rank's partial sums into every rank's mailbox and counts itself into every rank's arrival

@@ -18,7 +18,9 @@
 // bit-reproducible).  alpha, beta and every stopping decision live in device memory; the
 // host only enqueues iterations and polls a status word every CHUNK iterations, so
 // there is no host synchronisation inside an iteration.
+#include <chrono>
 #include <cmath>
+#include <thread>
 
 #include "internal.h"
 #include "p2p_device.h"
@@ -336,10 +338,19 @@ k_init(int64_t n3, int64_t dof0, const int32_t *red, const double *F, const doub
 
 // out[j] = sum_i partial[i*nv + j]: the unfolded form of the reduction (one 256-thread block, the
 // same summation order as fold_finish: both paths give the same bits)
+// st != nullptr (the loop's launches, peer to peer): once the solve has stopped -- every rank takes the same decision, but
+// not at the same moment -- this launch only COUNTS, like fold_skip: a rank that free-runs through the iterations enqueued
+// behind the stop (STAN_P2P_WAIT_MODE=2: stopped consumers do not poll) must not store stale partials into a mailbox slot
+// that a slower peer has not read yet (slot R + RING aliases slot R).
 template <int NV>
 __global__ void __launch_bounds__(256)
-k_reduce(const double *partial, int np, double *out, p2p_out po) {
+k_reduce(const double *partial, int np, double *out, p2p_out po, const int64_t *st, int64_t k) {
     __shared__ double sh[4];
+    if (st && po.pp && stopped(st, k)) {
+        if (po.signal && (int)threadIdx.x < po.pp->n)
+            __hip_atomic_fetch_add(po.pp->sig_red[threadIdx.x][po.slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     double r[NV];
     sum_partials<NV>(partial, np, sh, r);   // np == 0 (a rank that owns no rows): zeros
     publish_sums<NV>(out, po, r, sh);
@@ -1425,7 +1436,7 @@ static int ensure_scaled(stan_ctx *ctx, stan_matrix *K) {
             // separate processes, where mapping the peers' vectors delays some ranks by milliseconds: a
             // neighbour's scaling factors arrived before the fill and were overwritten with 1.0.)
             const p2p_out po{stan_p2p_table(ctx), stan_p2p_reduce_slot(ctx), 3, 1};
-            hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, ctx->stream, (const double *)nullptr, 0, (double *)nullptr, po);
+            hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, ctx->stream, (const double *)nullptr, 0, (double *)nullptr, po, (const int64_t *)nullptr, (int64_t)0);
             STANCHK(stan_p2p_reduce_wait(ctx));
         }
         STANCHK(stan_comm_halo_exchange(ctx, K, K->d_scale));
@@ -1531,6 +1542,35 @@ int stan_pack_columns(stan_ctx *ctx, int32_t nslices, int64_t nslots, const int3
 // nhalo == 0.  For nranks > 1 every rank's row count is a multiple of 64 except the last
 // rank's; the gather vectors are therefore sized 3*(max(nloc, pad) + nhalo) and the halo
 // always sits at 3*nloc.
+// Host waits of the loop.  Without peer-to-peer exchanges: the plain blocking calls.  With them the stream may sit in a
+// wait for a peer that is gone, and a blocking call would never return (the polling wavefront keeps the queue busy):
+// the host polls instead, and after stan_p2p_stall_seconds() without completion releases this rank's waits
+// (stan_p2p_release_own), lets the queue drain and reports STAN_E_COMM.  `ev` == nullptr: the whole stream.
+static int cg_wait(stan_ctx *ctx, bool p2p, hipStream_t st, hipEvent_t ev) {
+    if (!p2p) {
+        if (ev) HIPCHK(ctx, hipEventSynchronize(ev));
+        else HIPCHK(ctx, hipStreamSynchronize(st));
+        return STAN_OK;
+    }
+    const double bound = stan_p2p_stall_seconds();
+    const auto t0 = std::chrono::steady_clock::now();
+    int spins = 0;
+    for (;;) {
+        const hipError_t e = ev ? hipEventQuery(ev) : hipStreamQuery(st);
+        if (e == hipSuccess) return STAN_OK;
+        if (e != hipErrorNotReady) { ctx->err = std::string("cg: ") + hipGetErrorString(e); (void)hipGetLastError(); return STAN_E_HIP; }
+        (void)hipGetLastError();
+        if (++spins > 200) std::this_thread::sleep_for(std::chrono::microseconds(spins > 2000 ? 500 : 50));
+        if (ctx->p2p->broken.load()) break;   // somebody else (run_all, another rank's release) gave up already
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > bound) break;
+    }
+    stan_p2p_release_own(ctx);
+    (void)hipStreamSynchronize(st);   // the released waits pass: what was enqueued runs out
+    (void)hipGetLastError();
+    ctx->err = "cg: peer-to-peer exchange made no progress (a peer rank failed or never arrived); this rank's waits were released";
+    return STAN_E_COMM;
+}
+
 int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_f,
                    int32_t max_its, int32_t precision_mode, double *d_U, int32_t *term_out,
                    int32_t *iters_out, double *rel_res_out) {
@@ -1555,7 +1595,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     // peer to peer (one-process group handle, STAN_OPT_COMM_P2P): no RCCL call below this line
     const bool p2p = dist && ctx->comm_p2p && ctx->p2p != nullptr;
     // no hipFree while the peers' streams wait for this rank's future exchanges (stan_ctx::defer_frees)
-    struct free_later { stan_ctx *c; bool on; ~free_later() { if (on) stan_flush_deferred(c); } } free_guard{ctx, p2p};
+    struct free_later { stan_ctx *c; bool on; ~free_later() { if (on) { stan_flush_deferred(c); stan_p2p_ipc_trim(c); } } } free_guard{ctx, p2p};
     if (p2p) ctx->defer_frees = true;
     STANCHK(stan_cg_workspace(ctx, K));   // the context's vectors (the placement search probed with them)
     if (p2p) {
@@ -1620,10 +1660,11 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     auto fold_to = [&](int which, double *out, p2p_out po = NO_P2P) {
         return fold_args{foldr ? tick + FOLD_WORDS * which : nullptr, 0, 0, out, po};
     };
-    auto reduce_if_unfolded = [&](int np, int nv, double *out, p2p_out po = NO_P2P) {
+    auto reduce_if_unfolded = [&](int np, int nv, double *out, p2p_out po = NO_P2P, int64_t k_ = -1) {
         if (foldr || np <= 0) return;
-        if (nv == 2) hipLaunchKernelGGL(k_reduce<2>, dim3(1), dim3(256), 0, st_, partial, np, out, po);
-        else hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, np, out, po);
+        const int64_t *sk = k_ >= 1 ? stt : nullptr;   // (k_init's sum is formed before the status exists)
+        if (nv == 2) hipLaunchKernelGGL(k_reduce<2>, dim3(1), dim3(256), 0, st_, partial, np, out, po, sk, k_);
+        else hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, np, out, po, sk, k_);
     };
     // One exchange point of the sharded loop: RCCL all-reduce of `count` scalars in place, or the stream
     // wait for every rank's arrival; returns where the consumers find the sums.
@@ -1718,8 +1759,9 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         }
         if (dot && !folded) {
             if (parts > 0 || po.pp) {   // (peer to peer: a rank that owns no rows still sends its zeros)
-                if (dot == 2) hipLaunchKernelGGL(k_reduce<2>, dim3(1), dim3(256), 0, st_, partial, (int)parts, out, po);
-                else hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, (int)parts, out, po);
+                const int64_t *sk = k >= 1 ? stt : nullptr;
+                if (dot == 2) hipLaunchKernelGGL(k_reduce<2>, dim3(1), dim3(256), 0, st_, partial, (int)parts, out, po, sk, k);
+                else hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, (int)parts, out, po, sk, k);
                 n_launch++;
             } else HIPCHK(ctx, hipMemsetAsync(out, 0, 8 * dot, st_));   // a rank that owns no rows
         }
@@ -1761,7 +1803,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             if (parts == 0) folded = false;
         }
         if (!folded) {
-            if (parts > 0 || po.pp) { hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, (int)parts, out, po); n_launch++; }
+            if (parts > 0 || po.pp) { hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, (int)parts, out, po, (const int64_t *)stt, k); n_launch++; }
             else HIPCHK(ctx, hipMemsetAsync(out, 0, 8, st_));
         }
         if (ctx->profiling) hipEventRecord(spmv2_ev.back(), st_);
@@ -1781,12 +1823,12 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     int rc = STAN_OK;
     // status of "iteration 0" (initial residual test)
     HIPCHK(ctx, hipMemcpyAsync(h_st, stt, T_NSTAT * 8, hipMemcpyDeviceToHost, st_));
-    HIPCHK(ctx, hipStreamSynchronize(st_));
+    STANCHK(cg_wait(ctx, p2p, st_, nullptr));   // (peer to peer: behind the first reduction's wait)
     if (h_st[T_ITER_A] == 0) done = true;
     red_src rs_sr{nullptr, 0, nullptr, 0}, rs_vmv{nullptr, 0, nullptr, 0}, rs_r2{nullptr, 0, nullptr, 0};
     if (sr && !done) {   // w_0 = A r_0 with gamma_0, delta_0 (merit_0 = 0 sits in the zeroed scalars)
         if (p2p)         // ... or, peer to peer, is sent as this rank's zero into the slot of the first reduction
-            hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, 0, sc + S_SR_MERIT, p2p_to(2, false));
+            hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, 0, sc + S_SR_MERIT, p2p_to(2, false), (const int64_t *)nullptr, (int64_t)0);
         rc = spmv(r, w, 2, sc + S_SR_GAMMA, 0, p2p_to(0, true));
         if (rc == STAN_OK) rc = exchange_sums(sc + S_SR_GAMMA, 3, &rs_sr);
     }
@@ -1808,14 +1850,14 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
                 a.fold = vec_fold(sc + S_SR_MERIT, p2p_to(2, false));
                 hipLaunchKernelGGL(k_vec_sr, dim3(vg), dim3(VEC_T), 0, st_, a);
                 n_launch++;
-                if (!refresh) reduce_if_unfolded((int)vg, 1, sc + S_SR_MERIT, p2p_to(2, false));
+                if (!refresh) reduce_if_unfolded((int)vg, 1, sc + S_SR_MERIT, p2p_to(2, false), k);
                 else {   // r' = b^ - A^ x' (ALGLIB's periodic residual recomputation), then as usual
                     rc = spmv(xb[k & 1], v, 0, nullptr, k);
                     if (rc) break;
                     hipLaunchKernelGGL(k_refresh, dim3(vg), dim3(VEC_T), 0, st_, n3, k, (const int64_t *)stt,
                                        bh, v, xb[k & 1], r, partial, vec_fold(sc + S_SR_DELTA, p2p_to(1, false)));
                     n_launch++;
-                    reduce_if_unfolded((int)vg, 2, sc + S_SR_DELTA, p2p_to(1, false));   // [r.r (rewritten below), merit]
+                    reduce_if_unfolded((int)vg, 2, sc + S_SR_DELTA, p2p_to(1, false), k);   // [r.r (rewritten below), merit]
                 }
                 rc = spmv(r, w, 2, sc + S_SR_GAMMA, k, p2p_to(0, true));
                 if (rc) break;
@@ -1852,7 +1894,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
                                    (const int64_t *)stt, bh, v, xb[k & 1], r, partial, vec_fold(sc + S_R2NEW, po_r));
                 n_launch++;
             }
-            if (!foldr) { reduce_if_unfolded((int)vg, 2, sc + S_R2NEW, po_r); n_launch++; }
+            if (!foldr) { reduce_if_unfolded((int)vg, 2, sc + S_R2NEW, po_r, k); n_launch++; }
             rc = exchange_sums(sc + S_R2NEW, 2, &rs_r2);
             if (rc) break;
             const double *ux = a.defer_x ? a.xcur : nullptr;
@@ -1871,7 +1913,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         HIPCHK(ctx, hipMemcpyAsync(slot, stt, T_NSTAT * 8, hipMemcpyDeviceToHost, st_));
         HIPCHK(ctx, hipEventRecord(poll[chunk_id & 1], st_));
         if (chunk_id > 0) {
-            HIPCHK(ctx, hipEventSynchronize(poll[(chunk_id - 1) & 1]));
+            STANCHK(cg_wait(ctx, p2p, st_, poll[(chunk_id - 1) & 1]));
             int64_t *prev = h_st + 8 * ((chunk_id - 1) & 1);
             if (prev[T_TYPE] != 0) done = true;
         }
@@ -1881,6 +1923,10 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             rc = STAN_E_COMM;
         }
         chunk_id++;
+    }
+    if (p2p) {   // never a blocking wait on a stream that may sit in front of a peer that is gone
+        if (rc == STAN_OK) rc = cg_wait(ctx, true, st_, nullptr);
+        else stan_p2p_release_own(ctx);
     }
     hipError_t e = hipStreamSynchronize(st_);
     if (rc) return rc;

@@ -122,6 +122,8 @@ void stan_matrix_abandon_folding(stan_ctx *ctx, stan_matrix *K) {
 // for them (1: always; -1, the default: when the plan saves more than 5 % of the slots).  The padded streams stay: scaling,
 // export and the placement search work on them.
 int stan_matrix_make_folded(stan_ctx *ctx, stan_matrix *K, int32_t stream_kind) {
+    // -2 = declined by the AUTO threshold only: STAN_OPT_ROW_FOLDING = 1 ("always") set afterwards examines the matrix again
+    if (K->fold_state == -2 && ctx->row_folding == 1) K->fold_state = 0;
     if (ctx->row_folding == 0 || K->fold_state < 0 || K->nslots <= 0 || K->nslices <= 0) return STAN_OK;
     hipStream_t st = ctx->stream;
     const unsigned grid = (unsigned)((K->nslices + 3) / 4);
@@ -149,7 +151,7 @@ int stan_matrix_make_folded(stan_ctx *ctx, stan_matrix *K, int32_t stream_kind) 
         if (K->nfslots >= ((int64_t)1 << 31) || (ctx->row_folding < 0 && (double)K->nfslots > 0.95 * (double)K->nslots)) {
             stan_dfree(ctx, K->d_fold_plan); K->d_fold_plan = nullptr;
             stan_dfree(ctx, K->d_fold_meta); K->d_fold_meta = nullptr;
-            K->fold_state = -1;
+            K->fold_state = K->nfslots >= ((int64_t)1 << 31) ? -1 : -2;
             return STAN_OK;
         }
         std::vector<int32_t> h32(h.size());

@@ -11,6 +11,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/stan_hip.h"
@@ -162,6 +163,7 @@ struct stan_p2p {                   // host side, shared by the ranks of a group
     void *ipc_block = nullptr;                     // own mailbox + counters: one fine-grained allocation, one handle
     std::vector<void *> ipc_peer_block;            // mapped blocks of the peers
     std::unordered_map<std::string, void *> ipc_open;   // vectors of peers mapped so far, by handle bytes
+    std::unordered_set<std::string> ipc_live;           // ... of which the peers published these in the current solve
     // host barrier of the worker threads (abortable)
     std::mutex m;
     std::condition_variable cv;
@@ -177,9 +179,16 @@ void stan_p2p_destroy(stan_p2p *pp);
 void stan_p2p_abort(stan_p2p *pp);                 // frees every stream wait and every host barrier
 void stan_p2p_dump(stan_p2p *pp, FILE *f);         // call counts, expected and actual arrivals of every counter
 int stan_p2p_barrier(stan_p2p *pp);                // STAN_E_COMM when aborted / timed out
+// Host waits of a peer-to-peer solve are BOUNDED: a stream of this rank that makes no progress for
+// stan_p2p_stall_seconds() (a peer died or never published) gets its waits released -- the IPC form releases the
+// counters this rank waits on (its own memory), the one-process form every rank's -- the exchange is marked broken
+// and the solve returns STAN_E_COMM instead of blocking in hipStreamSynchronize with a spinning queue.
+double stan_p2p_stall_seconds();                   // STAN_P2P_STALL_S, default 120
+void stan_p2p_release_own(stan_ctx *ctx);          // RELEASE_ALL into this rank's own arrival counters + broken
 struct stan_ctx;
 int stan_p2p_ipc_setup(stan_ctx *ctx);             // collective over the context's RCCL communicator
 void stan_p2p_ipc_release(stan_ctx *ctx);
+void stan_p2p_ipc_trim(stan_ctx *ctx);             // end of a solve: close the mappings no peer published this time
 struct stan_matrix;
 int stan_p2p_reduce_slot(stan_ctx *ctx);           // mailbox slot / counter of this rank's NEXT reduction
 int stan_p2p_reduce_wait(stan_ctx *ctx, const unsigned long long **ctr = nullptr, unsigned long long *want = nullptr);   // the wait for it (advances the slot): enqueued, or (wait mode 2, ctr / want given) left to the consuming kernel
@@ -292,7 +301,7 @@ struct stan_matrix {
     uint32_t *d_fold_vals48 = nullptr;  // [nfslots][14][64]
     int64_t nfslots = 0;
     bool fold_cols_filled = false;
-    int fold_state = 0;                 // 0: not examined, 1: planned, -1: not worth it / not applicable
+    int fold_state = 0;                 // 0: not examined, 1: planned, -1: not applicable / abandoned (no memory), -2: declined by the auto threshold (> 95 % of the slots)
     int32_t *d_red = nullptr;       // [n_dof] nDOF_reduction
     uint8_t *d_fixmask = nullptr;   // [nb_glob] bit m = DOF m of the node fixed
     double *d_scale = nullptr;      // [3*(nloc+nhalo)] s_i = 1/sqrt(K_ii)

@@ -207,6 +207,8 @@ void stan_p2p_destroy(stan_p2p *pp) { delete pp; }
 void stan_p2p_abort(stan_p2p *pp) {
     if (!pp) return;
     pp->broken.store(true);
+    int dev0 = -1;   // this runs on the HOST APPLICATION's thread (multi.hip: run_all): its current device is kept
+    if (hipGetDevice(&dev0) != hipSuccess) { (void)hipGetLastError(); dev0 = -1; }
     for (stan_p2p::rank_res &r : pp->rk)
         for (int s = 0; s < STAN_P2P_RING; s++)
             for (unsigned long long *c : {r.sig_red[s], r.sig_halo[s]}) {
@@ -215,14 +217,44 @@ void stan_p2p_abort(stan_p2p *pp) {
                 (void)hipSetDevice(r.device);
                 (void)hipMemcpy(c, &v, 8, hipMemcpyHostToDevice);
             }
+    if (dev0 >= 0) (void)hipSetDevice(dev0);
     std::lock_guard<std::mutex> lk(pp->m);
     pp->cv.notify_all();
+}
+
+double stan_p2p_stall_seconds() {
+    if (const char *e = getenv("STAN_P2P_STALL_S")) {
+        const double v = atof(e);
+        if (v > 0) return v;
+    }
+    return 120.0;
+}
+
+// The process-per-GPU form has no group thread that could abort on its behalf (stan_p2p_abort belongs to
+// multi.hip's run_all): the rank releases ITSELF.  The counters a rank waits on are its own local memory, so the
+// polling wavefronts of k_wait_flag / red_get (and a hipStreamWaitValue64) see the value at once and the queue drains.
+void stan_p2p_release_own(stan_ctx *ctx) {
+    stan_p2p *pp = ctx->p2p;
+    if (!pp) return;
+    if (!pp->ipc) { stan_p2p_abort(pp); return; }   // one process: every rank's waits, as run_all would
+    pp->broken.store(true);
+    stan_p2p::rank_res &me = pp->rk[(size_t)pp->ipc_me];
+    (void)hipSetDevice(ctx->device);
+    for (int s = 0; s < STAN_P2P_RING; s++)
+        for (unsigned long long *c : {me.sig_red[s], me.sig_halo[s]}) {
+            if (!c) continue;
+            const unsigned long long v = RELEASE_ALL;
+            (void)hipMemcpy(c, &v, 8, hipMemcpyHostToDevice);   // (the context's streams are non-blocking streams)
+        }
+    (void)hipGetLastError();
 }
 
 // Where does a stalled exchange stand?  Every rank's call counts, the arrivals each of its counters must have
 // reached and the arrivals it has (read from another thread: the ranks' streams are non-blocking streams).
 void stan_p2p_dump(stan_p2p *pp, FILE *f) {
     if (!pp) return;
+    int dev0 = -1;   // caller's current device is kept (see stan_p2p_abort)
+    if (hipGetDevice(&dev0) != hipSuccess) { (void)hipGetLastError(); dev0 = -1; }
     fprintf(f, "peer-to-peer state (%d ranks, %s, wait mode %d, broken %d)\n", pp->n, pp->ipc ? "IPC" : "one process", pp->wait_mode,
             (int)pp->broken.load());
     for (int r = 0; r < pp->n; r++) {
@@ -238,6 +270,7 @@ void stan_p2p_dump(stan_p2p *pp, FILE *f) {
                     k.red_expect[s], a < k.red_expect[s] ? "  <-- waiting" : "", b, k.halo_expect[s], b < k.halo_expect[s] ? "  <-- waiting" : "");
         }
     }
+    if (dev0 >= 0) (void)hipSetDevice(dev0);
     fflush(f);
 }
 
@@ -396,6 +429,21 @@ void stan_p2p_ipc_release(stan_ctx *ctx) {
     ctx->comm_p2p = false;
 }
 
+// A peer that re-allocated its vectors (another K size, a placement search that moved them, a new d_scale per matrix:
+// bench.py assembles a fresh K every step) publishes new handles; the mappings of the old ones would pin the peer's
+// freed memory for the life of the context.  Closed at the END of a solve, where the deferred frees are released too
+// (hipIpcCloseMemHandle may wait for the device like hipFree: stan_ctx::defer_frees).
+void stan_p2p_ipc_trim(stan_ctx *ctx) {
+    stan_p2p *pp = ctx->p2p;
+    if (!pp || !pp->ipc) return;
+    for (auto it = pp->ipc_open.begin(); it != pp->ipc_open.end();) {
+        if (pp->ipc_live.count(it->first)) { ++it; continue; }
+        if (it->second) (void)hipIpcCloseMemHandle(it->second);
+        it = pp->ipc_open.erase(it);
+    }
+    (void)hipGetLastError();
+}
+
 // IPC form of the publication: handles of my five vectors + my halo plan to everybody (a collective: it
 // also is the barrier), the peers' vectors mapped (once per allocation: cached by handle)
 static int ipc_publish_vectors(stan_ctx *ctx, const stan_matrix *K, double *const vec[5]) {
@@ -413,6 +461,7 @@ static int ipc_publish_vectors(stan_ctx *ctx, const stan_matrix *K, double *cons
     for (size_t i = 0; i < K->recv_off.size() && i <= (size_t)STAN_P2P_MAXR; i++) mine.recv_off[i] = K->recv_off[i];
     std::vector<ipc_vectors> all((size_t)n);
     STANCHK(stan_comm_allgather_bytes(ctx, &mine, sizeof(mine), all.data()));
+    pp->ipc_live.clear();
     for (int q = 0; q < n; q++) {
         stan_p2p::rank_res &r = pp->rk[(size_t)q];
         const ipc_vectors &v = all[(size_t)q];
@@ -427,6 +476,7 @@ static int ipc_publish_vectors(stan_ctx *ctx, const stan_matrix *K, double *cons
             r.vec[i] = nullptr;
             if (!nbr_of_mine) continue;
             const std::string key((const char *)&v.h[i], sizeof(hipIpcMemHandle_t));
+            pp->ipc_live.insert(key);
             auto it = pp->ipc_open.find(key);
             if (it == pp->ipc_open.end()) {
                 void *m = nullptr;

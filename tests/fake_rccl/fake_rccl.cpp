@@ -20,6 +20,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -153,6 +154,19 @@ int flush_group(Comm *c) {
     }
     if (!barrier(c, "broadcast done")) return 5;
     g_ops.clear();
+    // TEST HOOK FAKE_RCCL_EXIT_AFTER_BCAST_GROUPS="rank:count": that rank's process ends (quietly, code 0) right
+    // after its count-th completed group of broadcasts -- i.e. a peer that has published what the others asked
+    // for and is then gone (tests/test_gpu_sharded.py: the survivors' peer-to-peer waits must release themselves)
+    static int n_bc_groups = 0;
+    n_bc_groups++;
+    if (const char *e = getenv("FAKE_RCCL_EXIT_AFTER_BCAST_GROUPS")) {
+        int r = -1, k = -1;
+        if (sscanf(e, "%d:%d", &r, &k) == 2 && r == c->rank && n_bc_groups == k) {
+            fprintf(stderr, "fake_rccl: rank %d leaves after broadcast group %d (test hook)\n", r, k);
+            fflush(stderr);
+            _exit(0);
+        }
+    }
     return 0;
 }
 

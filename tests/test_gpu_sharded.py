@@ -228,3 +228,18 @@ def test_bench_one_process_mode(built_libs):
         assert "ONE process" in res[n]["config"]["process_model"]
     assert abs(res[1]["config"]["cg_iterations"] - res[2]["config"]["cg_iterations"]) <= 1
     assert abs(res[1]["config"]["u_max"] - res[2]["config"]["u_max"]) <= 1e-7 * res[1]["config"]["u_max"]
+
+
+def test_peer_to_peer_survivor_releases_itself_when_its_peer_dies(built_libs):
+    """ADVICE r03 (p2p.hip:70): process-per-GPU peer to peer, the peer dies after publishing its vectors; the
+    survivor's device-side wait would spin forever.  The host loop's bounded wait releases this rank's own counters
+    after STAN_P2P_STALL_S without progress and the solve returns STAN_E_COMM (see tests/p2p_peer_dies_worker.py)."""
+    import time
+    t0 = time.time()
+    out = _torchrun(2, [os.path.join(ROOT, "tests", "p2p_peer_dies_worker.py")],
+                    {"STAN_P2P_STALL_S": "4", "FAKE_RCCL_EXIT_AFTER_BCAST_GROUPS": "1:3"})
+    took = time.time() - t0
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "SURVIVOR code -7" in out.stdout and "released" in out.stdout, out.stdout[-2000:]
+    assert "leaves after broadcast group 3" in out.stderr
+    assert took < 120, took
