@@ -50,7 +50,11 @@ typedef struct stan_matrix stan_matrix;
                                     throws ArgumentException); element via last_error and
                                     stan_hip_last_bad_element()                           */
 #define STAN_E_DOF_LAYOUT (-5)   /* Node.DOF is not {3i,3i+1,3i+2} (Node.cs:218-223)       */
-#define STAN_E_VALENCE (-6)      /* more than 64 elements share one node                  */
+#define STAN_E_VALENCE (-6)      /* (rounds 1-3: more than 64 incidences / 96 coupled nodes at one node.)  The
+                                    reference bounds neither (Database.cs:149-176, SolverFunctions.cs:143-173) and since
+                                    round 4 neither does the library: high-valence nodes take slow paths of the
+                                    symbolic and numeric kernels.  Left: 2^26 incident elements at ONE node
+                                    (int32 sort buffer) */
 #define STAN_E_COMM (-7)         /* RCCL failure                                           */
 #define STAN_E_UNSUPPORTED (-8)  /* element type / precision mode not supported           */
 

@@ -31,7 +31,7 @@
 
 namespace {
 
-constexpr int ERR_DOF_LAYOUT = 1, ERR_CONN_RANGE = 2, ERR_VALENCE = 4, ERR_ROWLEN = 8;
+constexpr int ERR_DOF_LAYOUT = 1, ERR_CONN_RANGE = 2;
 
 // ---- step 0: node permutation + fixed-DOF masks ------------------------------------------
 // (+ the coordinates in BLOCK-ROW order: the numeric phase gathers the nodes of a row's elements, which are
@@ -143,11 +143,8 @@ k_symbolic(int64_t nloc, int64_t r0, int64_t r1, const int64_t *ptr, int32_t *li
         return;
     }
     const int64_t p0 = ptr[row];
-    int deg = (int)(ptr[row + 1] - p0);
-    if (deg > STAN_MAX_INCIDENT) {
-        if (lane == 0) atomicOr((unsigned long long *)&status[SS_ERRBITS], (unsigned long long)ERR_VALENCE);
-        deg = STAN_MAX_INCIDENT;
-    }
+    const int deg = (int)(ptr[row + 1] - p0);
+    if (deg > STAN_MAX_INCIDENT) return;   // a high-valence node: k_symbolic_big (one workgroup, any number of incidences)
     // incidence entries ascending (= ascending element index, then local node)
     {
         int32_t en = lane < deg ? list[p0 + lane] : 0x7fffffff;
@@ -188,10 +185,103 @@ k_symbolic(int64_t nloc, int64_t r0, int64_t r1, const int64_t *ptr, int32_t *li
         }
         base += __popcll(m);
     }
-    if (lane == 0) {
-        rowlen[row] = base;
-        if (base > STAN_MAX_ROW_BLOCKS)
-            atomicOr((unsigned long long *)&status[SS_ERRBITS], (unsigned long long)ERR_ROWLEN);
+    if (lane == 0) rowlen[row] = base;   // (no limit: slices wider than the fast numeric kernel's LDS go to k_numeric_wide)
+}
+
+// ---- step 2, high-valence nodes.  The reference puts no bound on the elements at a node (Database.cs:149-176 builds
+// the lists, SolverFunctions.cs:143-173 scatters whatever K_e it gets): a solid of revolution meshed with collapsed
+// hexes in 5-degree sectors has 72 of them on its axis.  Rows with more than STAN_MAX_INCIDENT incidences are rare and
+// take this slow path: one 256-thread workgroup per row, the same two sorts (incidences; candidate block rows) as a
+// bitonic network over a power-of-two buffer -- in LDS when it fits the launch's allotment, otherwise in a slice of
+// global scratch claimed with a ticket (same code: one workgroup, barriers between the steps).
+__device__ inline void wg_bitonic_sort(int32_t *a, int P) {
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P; i += blockDim.x) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const int32_t x = a[i], y = a[l];
+                    const bool up = (i & k) == 0;
+                    if (up ? (x > y) : (x < y)) { a[i] = y; a[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+__global__ void __launch_bounds__(256)
+k_symbolic_big(int64_t nloc, int64_t r0, int64_t r1, const int64_t *ptr, int32_t *list, const int32_t *crow,
+               int32_t *rowlen, int32_t *refflag, int32_t *ucols, int lds_ints, int32_t *scratch, int64_t scratch_ints_per_row,
+               unsigned long long *ticket) {
+    extern __shared__ int32_t big_lds[];
+    __shared__ int32_t *sh_buf;
+    __shared__ int sh_base;
+    const int64_t row = blockIdx.x;
+    if (row >= nloc) return;
+    const int64_t p0 = ptr[row];
+    const int64_t deg = ptr[row + 1] - p0;
+    if (deg <= STAN_MAX_INCIDENT) return;   // k_symbolic did this row
+    int64_t PD = 64, PC = 64;
+    while (PD < deg) PD <<= 1;
+    while (PC < 8 * deg) PC <<= 1;
+    if (threadIdx.x == 0) {
+        if (PD + PC <= (int64_t)lds_ints) sh_buf = big_lds;
+        else sh_buf = scratch + (int64_t)atomicAdd(ticket, 1ULL) * scratch_ints_per_row;
+    }
+    __syncthreads();
+    int32_t *ent = sh_buf, *cand = sh_buf + PD;
+    for (int64_t i = threadIdx.x; i < PD; i += 256) ent[i] = i < deg ? list[p0 + i] : 0x7fffffff;
+    __syncthreads();
+    wg_bitonic_sort(ent, (int)PD);
+    for (int64_t i = threadIdx.x; i < deg; i += 256) list[p0 + i] = ent[i];
+    for (int64_t i = threadIdx.x; i < PC; i += 256)
+        cand[i] = i < 8 * deg ? crow[(int64_t)(ent[i >> 3] >> 3) * 8 + (i & 7)] : 0x7fffffff;
+    __syncthreads();
+    wg_bitonic_sort(cand, (int)PC);
+    // distinct values in ascending (global) order, 256 at a time: position = distinct values so far + those in front of me
+    __shared__ int sh_cnt[4];
+    int32_t *uc = ucols + 8 * p0;
+    if (threadIdx.x == 0) sh_base = 0;
+    __syncthreads();
+    for (int64_t i0 = 0; i0 < PC; i0 += 256) {
+        const int64_t i = i0 + threadIdx.x;
+        const int32_t c = cand[i];
+        const bool isnew = c != 0x7fffffff && (i == 0 || cand[i - 1] != c);
+        const unsigned long long m = __ballot(isnew);
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane == 0) sh_cnt[w] = __popcll(m);
+        __syncthreads();
+        int pos = sh_base + __popcll(m & ((1ull << lane) - 1ull));
+        for (int q = 0; q < w; q++) pos += sh_cnt[q];
+        if (isnew) {
+            uc[pos] = c;
+            if (refflag && (c < r0 || c >= r1)) refflag[c] = 1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) sh_base += sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) rowlen[row] = sh_base;
+}
+
+// most incidences of one owned row, and the rows whose sort buffers exceed `lds_ints` (they need global scratch)
+__global__ void k_max_incident(int64_t nrows, const int32_t *cnt, int lds_ints, int64_t *status) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int v = i < nrows ? cnt[i] : 0;
+    bool giant = false;
+    if (v > STAN_MAX_INCIDENT) {
+        int64_t PD = 64, PC = 64;
+        while (PD < v) PD <<= 1;
+        while (PC < 8 * (int64_t)v) PC <<= 1;
+        giant = PD + PC > (int64_t)lds_ints;
+    }
+    int m = v;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
+    const unsigned long long g = __ballot(giant);
+    if ((threadIdx.x & 63) == 0) {
+        if (m > STAN_MAX_INCIDENT) atomicMax((long long *)&status[SS_MAXDEG], (long long)m);
+        if (g) atomicAdd((unsigned long long *)&status[SS_NGIANT], (unsigned long long)__popcll(g));
     }
 }
 
@@ -266,32 +356,40 @@ k_window_sort(int64_t npad, int sigma, const int32_t *rowlen, int32_t *rowof, in
 __global__ void __launch_bounds__(256)
 k_fill_cols(int32_t nslices, int64_t nloc, int64_t r0, int64_t r1, const int32_t *slot_ptr,
             const int32_t *rowof, const int32_t *rowlen, const int64_t *ptr, const int32_t *ucols,
-            const int64_t *halo_rank, int32_t *cols, int32_t wmax) {
-    extern __shared__ int32_t tile_all[];   // [4 waves][64 rows][wmax | 1] (odd stride: conflict-free column reads)
+            const int64_t *halo_rank, int32_t *cols, int32_t wtile) {
+    extern __shared__ int32_t tile_all[];   // [4 waves][64 rows][wtile | 1] (odd stride: conflict-free column reads)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t slice = (int64_t)blockIdx.x * 4 + w;
     if (slice >= nslices) return;   // (no workgroup barrier below: the waves are independent)
-    const int stride = wmax | 1;
+    const int stride = wtile | 1;
     int32_t *tile = tile_all + (size_t)w * 64 * stride;
     const int64_t row = rowof[slice * 64 + lane];
     const bool live = row < nloc;   // rows >= nloc: padding of the last slice (zero values, column 0)
     const int rl = live ? rowlen[row] : 0;
     const int64_t p8 = live ? 8 * ptr[row] : 0;
-    for (int r = 0; r < 64; r++) {
-        const int rlr = __shfl(rl, r, 64);
-        const int64_t pr = __shfl(p8, r, 64);
-        for (int k = lane; k < rlr; k += 64) {
-            const int64_t g = ucols[pr + k];
-            tile[r * stride + k] = (g >= r0 && g < r1) ? (int32_t)(g - r0) : (int32_t)(nloc + halo_rank[g]);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
     const int32_t own = live ? (int32_t)row : 0;   // a row shorter than its slice is padded with its own column
-    for (int32_t k = k0; k < k1; k++)
-        cols[(int64_t)k * 64 + lane] = (k - k0 < rl) ? tile[lane * stride + (k - k0)] : own;
+    // a slice wider than the tile (a high-valence node among its rows) goes through it in chunks of wtile slots
+    for (int32_t c0 = 0; c0 < k1 - k0; c0 += wtile) {
+        for (int r = 0; r < 64; r++) {
+            const int rlr = __shfl(rl, r, 64);
+            const int64_t pr = __shfl(p8, r, 64);
+            const int hi = rlr < c0 + wtile ? rlr : c0 + wtile;
+            for (int k = c0 + lane; k < hi; k += 64) {
+                const int64_t g = ucols[pr + k];
+                tile[r * stride + (k - c0)] = (g >= r0 && g < r1) ? (int32_t)(g - r0) : (int32_t)(nloc + halo_rank[g]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int32_t kend = k1 - k0 < c0 + wtile ? k1 - k0 : c0 + wtile;
+        for (int32_t k = c0; k < kend; k++)
+            cols[((int64_t)k0 + k) * 64 + lane] = k < rl ? tile[lane * stride + (k - c0)] : own;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 }
 
 // slice width = longest row of the slice; also accumulates block count and max width
@@ -391,7 +489,8 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
     const int q = blockIdx.x & 3;
     const int64_t row_base = slice * 64 + q * 16;   // first POSITION of this workgroup
     const int32_t k0 = A.slot_ptr[slice];
-    const int sw = A.slot_ptr[slice + 1] - k0;  // this slice's width (<= wmax)
+    const int sw = A.slot_ptr[slice + 1] - k0;  // this slice's width
+    if (sw > W) return;   // wider than the LDS accumulators (a high-valence node): k_numeric_wide (workgroup-uniform)
 
     for (int i = tid; i < 16 * W * 9; i += 256) acc[i] = 0.0;
     for (int i = tid; i < 16 * sw; i += 256) {
@@ -630,6 +729,101 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
     }
 }
 
+// ---- step 3, wide slices.  A slice that holds a row of more than STAN_MAX_ROW_BLOCKS blocks (a high-valence node: the
+// axis of a revolved mesh, the centre of a fan) does not fit the LDS accumulators above.  Slow path, one WAVEFRONT per
+// row of such a slice, accumulating straight in K's values: slot k of the row belongs to lane k % 64, which zeroes it,
+// adds every contribution to it (in the order of the fast path's ordered branch: ascending element, local node, then b)
+// and applies the essential BCs -- one thread per address, so program order is all the ordering it needs.
+__global__ void __launch_bounds__(64) k_numeric_wide(numeric_args A) {
+    __shared__ double xsw[8 * 8 * 3];
+    __shared__ double gpw[8 * 8 * 10];
+    __shared__ double stage[64 * 9];
+    __shared__ int32_t posl[64];
+    const int lane = threadIdx.x;
+    const int64_t slice = blockIdx.x >> 6;
+    const int r = blockIdx.x & 63;
+    const int32_t k0 = A.slot_ptr[slice];
+    const int sw = A.slot_ptr[slice + 1] - k0;
+    if (sw <= A.wmax) return;   // k_numeric did this slice
+    const int64_t row = A.rowof[slice * 64 + r];
+    double *vrow = A.vals + (int64_t)k0 * 9 * 64 + r;          // entry (k, comp) of this row: vrow[(k * 9 + comp) * 64]
+    const int32_t *crow_cols = A.cols + (int64_t)k0 * 64 + r;  // local column of slot k: crow_cols[k * 64]
+    for (int k = lane; k < sw; k += 64)
+#pragma unroll
+        for (int j = 0; j < 9; j++) vrow[(int64_t)(k * 9 + j) * 64] = 0.0;
+    if (row >= A.nloc) return;   // padding row of the last slice
+    const int64_t p0 = A.ptr[row];
+    const int64_t deg = A.ptr[row + 1] - p0;
+    const int rl = A.rowlen[row];
+    auto gcol = [&](int k) -> int32_t {
+        const int32_t lc = crow_cols[(int64_t)k * 64];
+        return lc < A.nloc ? (int32_t)(A.r0 + lc) : A.halo_glob[lc - A.nloc];
+    };
+    const int s = lane >> 3, b = lane & 7;
+    for (int64_t c0 = 0; c0 < deg; c0 += 8) {
+        const bool valid = c0 + s < deg;
+        int32_t e = 0, a = 0, type = STAN_HEX8_G2, colg = 0;
+        double lam = 0, G = 0;
+        if (valid) {
+            const int32_t en = A.list[p0 + c0 + s];
+            e = en >> 3;
+            a = en & 7;
+            colg = A.crow[(int64_t)e * 8 + b];
+            type = A.elem_type[e];
+            const int32_t m = A.elem_mat[e];
+            lam = A.mat_lamG[2 * m];
+            G = A.mat_lamG[2 * m + 1];
+            xsw[(s * 8 + b) * 3 + 0] = A.xrow[3 * (int64_t)colg + 0];
+            xsw[(s * 8 + b) * 3 + 1] = A.xrow[3 * (int64_t)colg + 1];
+            xsw[(s * 8 + b) * 3 + 2] = A.xrow[3 * (int64_t)colg + 2];
+        }
+        __syncthreads();
+        if (valid) {   // this lane = Gauss point b of incidence s
+            double o[10];
+            const double det = hex8_gp_setup(xsw + s * 24, type, b, o);
+            if (det == 0.0 && hex8_gauss_weight(type, b) != 0.0) atomicMin(A.bad_elem, (long long)e);
+#pragma unroll
+            for (int j = 0; j < 10; j++) gpw[(b * 8 + s) * 10 + j] = o[j];
+        }
+        __syncthreads();
+        int pos = -1;
+        if (valid) {   // block (a, b) of element e and its slot in the row (columns ascend in global index)
+            double kb[9];
+            hex8_block_ab(gpw + s * 10, 8 * 10, type, a, b, lam, G, kb);
+            int lo = 0, hi = rl;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (gcol(mid) < colg) lo = mid + 1; else hi = mid;
+            }
+            pos = (lo < rl && gcol(lo) == colg) ? lo : -1;
+#pragma unroll
+            for (int j = 0; j < 9; j++) stage[lane * 9 + j] = kb[j];
+        }
+        posl[lane] = pos;
+        __syncthreads();
+        for (int l = 0; l < 64; l++) {
+            const int p = posl[l];
+            if (p >= 0 && (p & 63) == lane) {
+#pragma unroll
+                for (int j = 0; j < 9; j++) vrow[(int64_t)(p * 9 + j) * 64] += stage[l * 9 + j];
+            }
+        }
+        __syncthreads();
+    }
+    const int rfix = A.fixmask[A.r0 + row];
+    const int32_t grow = (int32_t)(A.r0 + row);
+    for (int k = lane; k < rl; k += 64) {
+        const int32_t g = gcol(k);
+        const int cf = A.fixmask[g];
+        if (!rfix && !cf) continue;
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+#pragma unroll
+            for (int n = 0; n < 3; n++)
+                if (((rfix >> m) & 1) || ((cf >> n) & 1)) vrow[(int64_t)(k * 9 + 3 * m + n) * 64] = (g == grow && m == n) ? 1.0 : 0.0;
+    }
+}
+
 // slice class: 1 if any row of the slice references a halo column (local index >= nloc)
 __global__ void __launch_bounds__(64)
 k_slice_class(int64_t nloc, const int32_t *rowlen, const int32_t *rowof, const int32_t *slot_ptr,
@@ -776,7 +970,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     const int64_t nrows_pad = (int64_t)K->nslices * 64;
 
     int64_t *d_status = ctx->d_status;
-    HIPCHK(ctx, hipMemsetAsync(d_status, 0, 8 * 8, st));
+    HIPCHK(ctx, hipMemsetAsync(d_status, 0, 16 * 8, st));
     {
         long long init = 0x7fffffffffffffffLL;
         HIPCHK(ctx, hipMemcpyAsync(d_status + SS_BAD_ELEM, &init, 8, hipMemcpyHostToDevice, st));
@@ -805,9 +999,13 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     if (n_elem > 0)
         hipLaunchKernelGGL(k_count_incident, dim3(nblk(n_elem * 8, 256)), dim3(256), 0, st, n_elem,
                            n_nodes, d_conn, d_perm, r0, r1, d_cnt, d_crow, d_status);
+    constexpr int BIG_LDS_INTS = 32768;   // 128 KB of the CU's 160 KB for k_symbolic_big's two sort buffers (up to 3640 incidences)
+    if (nrows_pad > 0)
+        hipLaunchKernelGGL(k_max_incident, dim3(nblk(nrows_pad, 256)), dim3(256), 0, st, nrows_pad, d_cnt, BIG_LDS_INTS, d_status);
     STANCHK(stan_scan_exclusive(ctx, d_cnt, d_ptr, nrows_pad));
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_ERRBITS, d_status + SS_ERRBITS, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_H_NINC, d_ptr + nrows_pad, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_MAXDEG, d_status + SS_MAXDEG, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     if (ctx->h_status[SS_ERRBITS] & ERR_DOF_LAYOUT) {
         ctx->err = "assemble: Node.DOF is not {3i,3i+1,3i+2} with 3i < n_dof (Node.cs:218-223)";
@@ -837,6 +1035,24 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     if (nrows_pad > 0)
         hipLaunchKernelGGL(k_symbolic, dim3((unsigned)nrows_pad), dim3(64), 0, st, nloc, r0, r1, d_ptr,
                            d_list, d_crow, K->d_rowlen, d_refflag, d_ucols, d_status);
+    if (ctx->h_status[SS_MAXDEG] > STAN_MAX_INCIDENT && nrows_pad > 0) {   // high-valence nodes: the slow symbolic path
+        int64_t PD = 64, PC = 64;
+        while (PD < ctx->h_status[SS_MAXDEG]) PD <<= 1;
+        while (PC < 8 * ctx->h_status[SS_MAXDEG]) PC <<= 1;
+        if (PC >= (int64_t)1 << 30) { ctx->err = "assemble: a node with more than 2^26 incident elements"; return STAN_E_VALENCE; }
+        const int64_t lds_ints = PD + PC < BIG_LDS_INTS ? PD + PC : BIG_LDS_INTS;
+        int32_t *d_scratch = nullptr;
+        if (ctx->h_status[SS_NGIANT] > 0) {
+            STANCHK(stan_dmalloc(ctx, &d_scratch, (size_t)(ctx->h_status[SS_NGIANT] * (PD + PC))));
+            tmp.own(d_scratch);
+        }
+        HIPCHK(ctx, hipMemsetAsync(d_status + SS_COUNTER, 0, 8, st));   // scratch tickets
+        if (lds_ints * 4 > 64 * 1024)
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)k_symbolic_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_ints * 4)));
+        hipLaunchKernelGGL(k_symbolic_big, dim3((unsigned)nrows_pad), dim3(256), (size_t)lds_ints * 4, st, nloc, r0, r1, d_ptr, d_list,
+                           d_crow, K->d_rowlen, d_refflag, d_ucols, (int)lds_ints, d_scratch, PD + PC,
+                           (unsigned long long *)(d_status + SS_COUNTER));
+    }
     // SELL-C-sigma: positions of the rows inside the sliced layout
     K->sigma = ctx->sell_sigma < 1 ? 1 : ctx->sell_sigma > 32 ? 32 : ctx->sell_sigma;
     STANCHK(stan_dmalloc(ctx, &K->d_rowof, (size_t)(nrows_pad > 0 ? nrows_pad : 1)));
@@ -870,11 +1086,6 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_H_NSLOTS, d_sp64 + K->nslices, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_H_NBLOCKS, d_status + SS_WIDTH_SUM, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
-    if (ctx->h_status[SS_ERRBITS] & (ERR_VALENCE | ERR_ROWLEN)) {
-        ctx->err = "assemble: a node is shared by more than 64 (element, local node) pairs or "
-                   "couples to more than " + std::to_string(STAN_MAX_ROW_BLOCKS) + " nodes";
-        return STAN_E_VALENCE;
-    }
     K->nslots = ctx->h_status[SS_H_NSLOTS];
     K->nblocks = ctx->h_status[SS_H_NBLOCKS];
     K->max_row_blocks = (int32_t)(ctx->h_status[SS_H_MAXROW] & 0xffffffff);
@@ -885,7 +1096,8 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     }
     STANCHK(stan_dmalloc(ctx, &K->d_cols, (size_t)K->nslots * 64));
     if (K->nslices > 0) {
-        const int32_t wmax = K->max_row_blocks > 0 ? K->max_row_blocks : 1;
+        int32_t wmax = K->max_row_blocks > 0 ? K->max_row_blocks : 1;
+        if (wmax > STAN_MAX_ROW_BLOCKS) wmax = STAN_MAX_ROW_BLOCKS;         // wider slices pass through the tile in chunks
         const size_t lds = (size_t)4 * 64 * (wmax | 1) * sizeof(int32_t);   // <= 4 * 64 * 97 * 4 = 99 KB
         if (lds > 64 * 1024)
             HIPCHK(ctx, hipFuncSetAttribute((const void *)k_fill_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -915,6 +1127,8 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         A.rowlen = K->d_rowlen; A.rowof = K->d_rowof; A.slot_ptr = K->d_slot_ptr; A.cols = K->d_cols; A.vals = K->d_vals;
         A.bad_elem = (long long *)(d_status + SS_BAD_ELEM);
         A.wmax = K->max_row_blocks > 0 ? K->max_row_blocks : 1;
+        const bool wide = A.wmax > STAN_MAX_ROW_BLOCKS;   // some slice holds a high-valence row: it goes to k_numeric_wide
+        if (wide) A.wmax = STAN_MAX_ROW_BLOCKS;
         const size_t lds = (size_t)16 * A.wmax * 9 * 8 + (size_t)4 * 8 * 8 * 3 * 8 +
                            (size_t)4 * 8 * 8 * 10 * 8 + (size_t)2 * 16 * A.wmax * 4;
         if (lds > 64 * 1024)
@@ -922,6 +1136,10 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (K->nslices > 0)
             hipLaunchKernelGGL(k_numeric, dim3((unsigned)K->nslices * 4), dim3(256), lds, st, A);
+        if (wide) {
+            if ((int64_t)K->nslices * 64 >= (int64_t)1 << 31) { ctx->err = "assemble: too many slices for the wide-row kernel's grid"; return STAN_E_ARG; }
+            hipLaunchKernelGGL(k_numeric_wide, dim3((unsigned)K->nslices * 64), dim3(64), 0, st, A);
+        }
     }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemsetAsync(d_status + SS_AUX, 0, 8, st));

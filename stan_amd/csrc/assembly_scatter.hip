@@ -21,22 +21,26 @@ __device__ __forceinline__ unsigned prio(int32_t e) {
     return x;
 }
 
-// tentative colour = smallest colour no already-coloured neighbour uses
+// tentative colour = smallest colour no already-coloured neighbour uses.  Colours are examined in windows of 64 (one
+// mask word): a structured mesh needs 8-18, the elements around a high-valence node (72 collapsed hexes on the axis
+// of a revolved mesh) one each -- the window moves on until a free colour turns up, so there is no limit.
 __global__ void k_col_tentative(int64_t n_elem, const int32_t *conn, const int32_t *perm,
                                 const int64_t *ptr, const int32_t *list, const int32_t *colour,
-                                int32_t *tent, int64_t *status) {
+                                int32_t *tent) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_elem || colour[e] >= 0) return;
-    unsigned long long forbid = 0;
-    for (int a = 0; a < 8; a++) {
-        const int64_t row = perm[conn[e * 8 + a]];
-        for (int64_t q = ptr[row]; q < ptr[row + 1]; q++) {
-            const int32_t e2 = list[q] >> 3;
-            if (e2 != e && colour[e2] >= 0) forbid |= 1ull << colour[e2];
+    for (int32_t base = 0;; base += 64) {
+        unsigned long long forbid = 0;
+        for (int a = 0; a < 8; a++) {
+            const int64_t row = perm[conn[e * 8 + a]];
+            for (int64_t q = ptr[row]; q < ptr[row + 1]; q++) {
+                const int32_t e2 = list[q] >> 3;
+                const int32_t c2 = colour[e2];
+                if (e2 != e && c2 >= base && c2 < base + 64) forbid |= 1ull << (c2 - base);
+            }
         }
+        if (~forbid != 0ull) { tent[e] = base + __ffsll((long long)~forbid) - 1; return; }
     }
-    if (~forbid == 0ull) { atomicOr((unsigned long long *)&status[SS_ERRBITS], 16ull); tent[e] = 63; return; }
-    tent[e] = __ffsll((long long)~forbid) - 1;
 }
 
 // keep the tentative colour unless an uncoloured neighbour with higher priority wants it too
@@ -62,6 +66,13 @@ __global__ void k_col_resolve(int64_t n_elem, const int32_t *conn, const int32_t
     if (lose) atomicAdd(remaining, 1ull);
 }
 
+__global__ void k_col_max(int64_t n_elem, const int32_t *colour, int32_t *out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int v = e < n_elem ? colour[e] : -1;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+    if ((threadIdx.x & 63) == 0 && v >= 0) atomicMax(out, v);
+}
 __global__ void k_col_count(int64_t n_elem, const int32_t *colour, int32_t *cnt) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < n_elem) atomicAdd(&cnt[colour[e]], 1);
@@ -187,42 +198,47 @@ int stan_assemble_colour_scatter(stan_ctx *ctx, stan_matrix *K, int64_t n_elem, 
     HIPCHK(ctx, hipMemsetAsync(K->d_vals, 0, (size_t)K->nslots * 9 * 64 * 8, st));
     ctx->prof_colours = 0;
     if (n_elem > 0) {
-        int32_t *d_col[2], *d_tent, *d_cnt, *d_order;
+        int32_t *d_col[2], *d_tent, *d_cnt = nullptr, *d_order, *d_maxc;
         unsigned long long *d_rem;
         std::vector<void *> owned;
         auto A = [&](auto **p, size_t n) { int rc = stan_dmalloc(ctx, p, n); if (!rc) owned.push_back((void *)*p); return rc; };
         struct F { stan_ctx *c; std::vector<void *> &v; ~F() { for (void *q : v) stan_dfree(c, q); } } fr{ctx, owned};
         STANCHK(A(&d_col[0], (size_t)n_elem)); STANCHK(A(&d_col[1], (size_t)n_elem));
-        STANCHK(A(&d_tent, (size_t)n_elem)); STANCHK(A(&d_cnt, 192)); STANCHK(A(&d_order, (size_t)n_elem));
+        STANCHK(A(&d_tent, (size_t)n_elem)); STANCHK(A(&d_maxc, 2)); STANCHK(A(&d_order, (size_t)n_elem));
         STANCHK(A(&d_rem, 1));
         HIPCHK(ctx, hipMemsetAsync(d_col[0], 0xff, (size_t)n_elem * 4, st));  // -1 = uncoloured
         int cur = 0;
         for (int round = 0; round < 4096; round++) {
             HIPCHK(ctx, hipMemsetAsync(d_rem, 0, 8, st));
             hipLaunchKernelGGL(k_col_tentative, dim3(nblk(n_elem, 256)), dim3(256), 0, st, n_elem, d_conn,
-                               d_perm, d_ptr, d_list, d_col[cur], d_tent, ctx->d_status);
+                               d_perm, d_ptr, d_list, d_col[cur], d_tent);
             hipLaunchKernelGGL(k_col_resolve, dim3(nblk(n_elem, 256)), dim3(256), 0, st, n_elem, d_conn,
                                d_perm, d_ptr, d_list, d_col[cur], d_tent, d_col[cur ^ 1], d_rem);
             cur ^= 1;
             HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_COUNTER, d_rem, 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_H_ERRCOPY, ctx->d_status + SS_ERRBITS, 8, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
-            if (ctx->h_status[SS_H_ERRCOPY] & 16) { ctx->err = "colouring needs more than 64 colours"; return STAN_E_VALENCE; }
             if (ctx->h_status[SS_COUNTER] == 0) break;
         }
         if (ctx->h_status[SS_COUNTER] != 0) { ctx->err = "element colouring did not converge"; return STAN_E_HIP; }
-        // elements grouped by colour
-        HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 192 * 4, st));
+        // elements grouped by colour (as many colours as the mesh needed)
+        HIPCHK(ctx, hipMemsetAsync(d_maxc, 0xff, 4, st));
+        hipLaunchKernelGGL(k_col_max, dim3(nblk(n_elem, 256)), dim3(256), 0, st, n_elem, d_col[cur], d_maxc);
+        int32_t maxc = -1;
+        HIPCHK(ctx, hipMemcpyAsync(&maxc, d_maxc, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        const int32_t nc = maxc + 1;
+        STANCHK(A(&d_cnt, (size_t)3 * nc));
+        HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, (size_t)3 * nc * 4, st));
         hipLaunchKernelGGL(k_col_count, dim3(nblk(n_elem, 256)), dim3(256), 0, st, n_elem, d_col[cur], d_cnt);
-        int32_t cnt[64], off[64];
-        HIPCHK(ctx, hipMemcpyAsync(cnt, d_cnt, 64 * 4, hipMemcpyDeviceToHost, st));
+        std::vector<int32_t> cnt((size_t)nc), off((size_t)nc);
+        HIPCHK(ctx, hipMemcpyAsync(cnt.data(), d_cnt, (size_t)nc * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         int32_t run = 0, ncol = 0;
-        for (int c = 0; c < 64; c++) { off[c] = run; run += cnt[c]; if (cnt[c]) ncol = c + 1; }
-        HIPCHK(ctx, hipMemcpyAsync(d_cnt + 64, off, 64 * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(ctx, hipMemsetAsync(d_cnt + 128, 0, 64 * 4, st));
+        for (int c = 0; c < nc; c++) { off[(size_t)c] = run; run += cnt[(size_t)c]; if (cnt[(size_t)c]) ncol = c + 1; }
+        HIPCHK(ctx, hipMemcpyAsync(d_cnt + nc, off.data(), (size_t)nc * 4, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_col_fill, dim3(nblk(n_elem, 256)), dim3(256), 0, st, n_elem, d_col[cur],
-                           d_cnt + 64, d_cnt + 128, d_order);
+                           d_cnt + nc, d_cnt + 2 * nc, d_order);
+        HIPCHK(ctx, hipStreamSynchronize(st));   // off[] must outlive the copy
         ctx->prof_colours = ncol;
         // colour passes, in colour order
         for (int c = 0; c < ncol; c++)

@@ -17,8 +17,8 @@
 #include "../../include/stan_hip.h"
 
 #define STAN_SLICE 64      // block rows per ELL slice == wavefront width
-#define STAN_MAX_INCIDENT 64  // (element,local node) pairs per node the symbolic kernels accept
-#define STAN_MAX_ROW_BLOCKS 96
+#define STAN_MAX_INCIDENT 64  // (element,local node) pairs per node of the FAST symbolic kernel (one lane each); more: k_symbolic_big
+#define STAN_MAX_ROW_BLOCKS 96 // slice width (blocks per row) of the FAST numeric kernel's LDS accumulators; wider slices: k_numeric_wide
 
 // HIP call guard: records the error on the context and returns STAN_E_HIP.
 #define HIPCHK(ctx, call)                                                              \
@@ -105,6 +105,8 @@ enum stan_status_slot {
     SS_AUX = 9,          // fixed-DOF count (assembly) / first HEX8_G1 element (recovery)
     SS_COUNTER = 10,     // FIXED-48 overflow count; colouring: elements still uncoloured (host)
     SS_H_ERRCOPY = 11,   // host: copy of SS_ERRBITS during the colouring rounds
+    SS_MAXDEG = 12,      // device + host: most (element, local node) incidences of one owned row when > STAN_MAX_INCIDENT, else 0
+    SS_NGIANT = 13,      // device + host: rows whose symbolic sort does not fit the LDS allotment (global scratch)
     SS_WIDTH_SUM = 16,   // device: sum of row lengths, followed by
     SS_WIDTH_MAX = 17,   //         the longest row (k_slice_width)
     SS_H_CG_STATUS = 16, // host: two 8-word copies of the CG status words (chunk polling)

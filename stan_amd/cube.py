@@ -113,3 +113,33 @@ def perforated_mesh(n, frac, seed=7):
     new = np.full(xyz.shape[0], -1, dtype=np.int64)
     new[used] = np.arange(used.shape[0])
     return xyz[used], new[conn].astype(np.int32)
+
+
+def revolved_mesh(sectors=72, rings=2, layers=3, r0=1.0, h=1.0):
+    """A solid of revolution meshed the way pre-processors do it: `sectors` wedge-shaped COLLAPSED hexes around
+    the axis (CHEXA with node 4 = node 1 and node 8 = node 5: the axis node is listed twice), `rings` - 1 rings of
+    ordinary hexes outside them, `layers` layers in z.  An interior axis node belongs to 2 * sectors elements with
+    2 incidences each (72 sectors: 288 (element, local node) pairs) and couples to 3 * (sectors + 1) nodes -- the
+    reference accepts any of it (Node.RemoveElemDuplicates, Node.cs:202-205; Database.cs:149-176 puts no bound on
+    the elements at a node).  Returns xyz [n,3] float64 and conn [e,8] int32 (det J > 0 at every Gauss point)."""
+    ang = 2.0 * np.pi * np.arange(sectors) / sectors
+    per_layer = 1 + sectors * rings      # axis node, then ring 1 .. rings (sector fastest)
+    xyz = []
+    for z in range(layers + 1):
+        xyz.append((0.0, 0.0, z * h))
+        for r in range(1, rings + 1):
+            for s in range(sectors):
+                xyz.append((r0 * r * np.cos(ang[s]), r0 * r * np.sin(ang[s]), z * h))
+
+    def nid(z, r, s):   # r = 0: the axis
+        return z * per_layer + (0 if r == 0 else 1 + (r - 1) * sectors + s % sectors)
+
+    conn = []
+    for z in range(layers):
+        for s in range(sectors):
+            a0, a1 = nid(z, 0, 0), nid(z + 1, 0, 0)
+            conn.append([a0, nid(z, 1, s), nid(z, 1, s + 1), a0, a1, nid(z + 1, 1, s), nid(z + 1, 1, s + 1), a1])
+            for r in range(1, rings):
+                conn.append([nid(z, r, s), nid(z, r + 1, s), nid(z, r + 1, s + 1), nid(z, r, s + 1),
+                             nid(z + 1, r, s), nid(z + 1, r + 1, s), nid(z + 1, r + 1, s + 1), nid(z + 1, r, s + 1)])
+    return np.array(xyz, dtype=np.float64), np.array(conn, dtype=np.int32)

@@ -7,7 +7,10 @@ import numpy as np
 from stan_amd import host, problem
 
 
-def random_job(seed):
+def random_job(seed, collapse=0.0):
+    """collapse > 0: that fraction of the elements becomes a wedge-shaped COLLAPSED hex (node 4 := node 1, node 8 :=
+    node 5, as pre-processors write wedges into CHEXA cards): the element lists two nodes twice, which the reference
+    accepts (Node.RemoveElemDuplicates, Node.cs:202-205) and scatters like any other K_e (SolverFunctions.cs:143-173)."""
     rng = np.random.default_rng(seed)
     nx, ny, nz = (int(v) for v in rng.integers(1, 8, 3))
     mx, my, mz = nx + 1, ny + 1, nz + 1
@@ -35,6 +38,13 @@ def random_job(seed):
     xyz2[perm] = xyz[used]
     conn = new_of_old[conn].astype(np.int32)
     n_nodes = used.shape[0]
+    if collapse > 0:
+        rc = np.random.default_rng(seed + 100003)     # (its own stream: collapse = 0 keeps every earlier job as it was)
+        for e in np.nonzero(rc.random(conn.shape[0]) < collapse)[0]:
+            old = conn[e].copy()
+            conn[e, 3], conn[e, 7] = conn[e, 0], conn[e, 4]
+            if np.unique(conn).shape[0] != n_nodes:   # would leave a node without an element: keep the hex
+                conn[e] = old
     try:
         host.assign_dof(n_nodes, conn)
     except Exception:

@@ -600,18 +600,8 @@ def test_unstructured_mesh_parity(gpu_ctx, oracle, k, rings):
     K.free()
 
 
-def test_valence_limits_are_errors(gpu_ctx):
-    from stan_amd import hip
-    job = _star_job(20, rings=1)      # centre row couples to 123 nodes > 96
-    with pytest.raises(hip.StanHipError) as ei:
-        gpu_ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type,
-                              job.mat_E_nu, job.red)
-    assert ei.value.code == hip.E_VALENCE
-    job = _star_job(33, rings=1)      # 66 > 64 incidences on the centre line
-    with pytest.raises(hip.StanHipError) as ei:
-        gpu_ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type,
-                              job.mat_E_nu, job.red)
-    assert ei.value.code == hip.E_VALENCE
+# (test_valence_limits_are_errors lived here until round 4: the limits it pinned -- 64 incidences, 96 blocks per row --
+#  are gone; tests/test_gpu_round4.py assembles the same jobs and larger ones against the oracle)
 
 
 def test_edge_cases_empty_and_fully_fixed(gpu_ctx, oracle):
