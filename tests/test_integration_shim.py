@@ -1,0 +1,184 @@
+"""The C# side of the drop-in (integration/*.cs) checked MECHANICALLY against include/stan_hip.h: no .NET toolchain
+exists in this image, so nothing compiles those files; this test is what keeps them from drifting.
+  * every function the header declares has exactly one [DllImport] and vice versa (nothing invented);
+  * same arity, and every managed argument type is the blittable image of the C type;
+  * the [StructLayout(Sequential)] records have the header's fields in the header's order and widths;
+  * the constants the shim uses (error codes, element types, precision modes, options) equal the #defines;
+  * the library really exports every one of those names."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "stan_hip.h")
+SHIM = os.path.join(ROOT, "integration", "StanHip.cs")
+SHIM2 = os.path.join(ROOT, "integration", "SolverFunctions.Hip.cs")
+
+
+def _strip_c_comments(t):
+    t = re.sub(r"/\*.*?\*/", " ", t, flags=re.S)
+    return re.sub(r"//[^\n]*", " ", t)
+
+
+def _c_kind(decl):
+    """C parameter declaration -> (kind, pointee): kind in scalar | ptr | handle | out_handle | struct."""
+    d = re.sub(r"\bconst\b", " ", decl).strip()
+    arr = re.search(r"\[\s*\d*\s*\]\s*$", d)
+    if arr:
+        d = d[:arr.start()].strip()
+    stars = d.count("*")
+    d = d.replace("*", " ")
+    toks = d.split()
+    base = toks[0] if toks[0] != "struct" else toks[1]
+    nptr = stars + (1 if arr else 0)
+    if base in ("stan_ctx", "stan_matrix", "void"):
+        return ("out_handle" if nptr == 2 else "handle", base)
+    if base in ("stan_matrix_info", "stan_profile"):
+        assert nptr == 1
+        return ("struct", base)
+    norm = {"int": "int32", "int32_t": "int32", "int64_t": "int64", "double": "double", "float": "float",
+            "uint8_t": "uint8", "char": "uint8"}[base]
+    return ("scalar" if nptr == 0 else "ptr", norm)
+
+
+def c_prototypes():
+    t = _strip_c_comments(open(HEADER).read())
+    t = t[t.index('extern "C"'):]
+    t = re.sub(r"^\s*#.*$", " ", t, flags=re.M)                                   # preprocessor lines
+    t = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", " ", t, flags=re.S)   # the two records
+    t = re.sub(r"typedef[^;]*;", " ", t)
+    protos = {}
+    for stmt in t.split(";"):
+        m = re.search(r"((?:const\s+)?[A-Za-z_]\w*[\s\*]+)(stan_hip_\w+)\s*\((.*)\)\s*$", stmt.strip(), flags=re.S)
+        if not m:
+            continue
+        ret, name, params = m.group(1).strip(), m.group(2), m.group(3)
+        ret_kind = {"int": "int32", "void": "void", "int64_t": "int64", "const char *": "handle"}[re.sub(r"\s+", " ", ret)]
+        plist = [p.strip() for p in params.replace("\n", " ").split(",") if p.strip() and p.strip() != "void"]
+        assert name not in protos, name
+        protos[name] = (ret_kind, [_c_kind(p) for p in plist])
+    return protos
+
+
+CS_SCALAR = {"int": "int32", "long": "int64", "double": "double", "float": "float", "byte": "uint8"}
+
+
+def _cs_kind(decl):
+    d = re.sub(r"\[(Out|In|In, Out)\]", " ", decl).strip()
+    toks = d.split()
+    mod = toks[0] if toks[0] in ("out", "ref") else None
+    typ = toks[1] if mod else toks[0]
+    if typ == "IntPtr":
+        return ("out_handle" if mod else "handle", None)
+    if typ in ("StanMatrixInfo", "StanProfile"):
+        assert mod in ("out", "ref")
+        return ("struct", {"StanMatrixInfo": "stan_matrix_info", "StanProfile": "stan_profile"}[typ])
+    if typ.endswith("[]"):
+        return ("ptr", CS_SCALAR[typ[:-2]])
+    return (("ptr" if mod else "scalar"), CS_SCALAR[typ])
+
+
+def cs_imports():
+    t = _strip_c_comments(open(SHIM).read())
+    out = {}
+    for m in re.finditer(r"\[DllImport\(Lib\)\]\s*internal\s+static\s+extern\s+(\w+)\s+(stan_hip_\w+)\s*\(([^;]*?)\)\s*;", t, flags=re.S):
+        ret, name, params = m.group(1), m.group(2), m.group(3)
+        assert name not in out, "declared twice: " + name
+        ret_kind = {"int": "int32", "void": "void", "long": "int64", "IntPtr": "handle"}[ret]
+        plist = [p.strip() for p in params.replace("\n", " ").split(",") if p.strip()]
+        out[name] = (ret_kind, [_cs_kind(p) for p in plist])
+    return out
+
+
+def test_every_header_function_has_one_matching_dllimport():
+    c, cs = c_prototypes(), cs_imports()
+    assert len(c) >= 29, sorted(c)
+    assert sorted(c) == sorted(cs), (sorted(set(c) - set(cs)), sorted(set(cs) - set(c)))
+    for name, (ret, params) in c.items():
+        cret, cparams = cs[name]
+        assert ret == cret, (name, ret, cret)
+        assert len(params) == len(cparams), (name, len(params), len(cparams))
+        for i, ((k, b), (ck, cb)) in enumerate(zip(params, cparams)):
+            if ck == "handle" and k in ("handle", "ptr"):     # IntPtr: an opaque handle or a device / raw pointer
+                continue
+            assert (k, b) == (ck, cb) or (k == ck == "out_handle"), (name, i, (k, b), (ck, cb))
+
+
+def _c_struct(name):
+    t = _strip_c_comments(open(HEADER).read())
+    body = re.search(r"typedef\s+struct\s+%s\s*\{(.*?)\}\s*%s\s*;" % (name, name), t, flags=re.S).group(1)
+    fields = []
+    for stmt in body.split(";"):
+        stmt = stmt.strip()
+        if not stmt:
+            continue
+        typ, names = stmt.split(None, 1)
+        for n in names.split(","):
+            fields.append((n.strip(), {"int64_t": "int64", "int32_t": "int32", "double": "double", "float": "float"}[typ]))
+    return fields
+
+
+def _cs_struct(name):
+    t = _strip_c_comments(open(SHIM).read())
+    m = re.search(r"\[StructLayout\(LayoutKind\.Sequential\)\]\s*public\s+struct\s+%s\s*\{(.*?)\}" % name, t, flags=re.S)
+    return [(n, CS_SCALAR[ty]) for ty, n in re.findall(r"public\s+(\w+)\s+(\w+)\s*;", m.group(1))]
+
+
+def test_struct_records_match_the_header_field_by_field():
+    assert _cs_struct("StanMatrixInfo") == _c_struct("stan_matrix_info")
+    assert _cs_struct("StanProfile") == _c_struct("stan_profile")
+    # ... and the ctypes mirror the Python tests use
+    from stan_amd import hip
+    cmap = {ctypes.c_int64: "int64", ctypes.c_int32: "int32", ctypes.c_double: "double", ctypes.c_float: "float"}
+    assert [(n, cmap[t]) for n, t in hip.MatrixInfo._fields_] == _c_struct("stan_matrix_info")
+    assert [(n, cmap[t]) for n, t in hip.Profile._fields_] == _c_struct("stan_profile")
+
+
+def test_constants_of_the_shim_are_the_header_defines():
+    h = open(HEADER).read()
+    defs = {m.group(1): int(m.group(2).strip("()")) for m in re.finditer(r"#define\s+(STAN_\w+)\s+(\(?-?\d+\)?)", h)}
+    t = _strip_c_comments(open(SHIM).read())
+    used = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(STAN_[A-Z0-9_]+)\s*=\s*(-?\d+)", t)}
+    assert len(used) >= 30
+    for k, v in used.items():
+        assert defs.get(k) == v, (k, v, defs.get(k))
+    # every option the header defines is available to the managed side
+    assert {k for k in defs if k.startswith("STAN_OPT_")} <= set(used)
+
+
+def test_the_library_exports_every_imported_name(built_libs):
+    lib = ctypes.CDLL(os.path.join(ROOT, "stan_amd", "lib", "libstan_hip.so"))
+    for name in cs_imports():
+        assert hasattr(lib, name), name
+
+
+def test_replacement_methods_call_only_declared_imports_with_declared_arity():
+    """integration/SolverFunctions.Hip.cs: every StanHipNative.<f>(...) call names a declared import and passes as many
+    arguments as it takes (the write-back of the 8x6 blocks into dE / dS is there, in front of Update_StrainStress)."""
+    cs = cs_imports()
+    t = _strip_c_comments(open(SHIM2).read())
+    calls = 0
+    for m in re.finditer(r"StanHipNative\.(stan_hip_\w+)\s*\(", t):
+        name = m.group(1)
+        assert name in cs, name
+        depth, i, args, cur = 1, m.end(), [], ""
+        while depth:
+            ch = t[i]
+            if ch in "([":
+                depth += 1
+            elif ch in ")]":
+                depth -= 1
+                if depth == 0:
+                    break
+            if ch == "," and depth == 1:
+                args.append(cur); cur = ""
+            else:
+                cur += ch
+            i += 1
+        if cur.strip():
+            args.append(cur)
+        assert len(args) == len(cs[name][1]), (name, len(args), len(cs[name][1]))
+        calls += 1
+    assert calls >= 6
+    assert re.search(r"e\.dE\[a\]\.SetFast\(c, 0, strain\[48 \* i \+ 6 \* a \+ c\]\)", t)
+    assert re.search(r"e\.dS\[a\]\.SetFast\(c, 0, stress\[48 \* i \+ 6 \* a \+ c\]\)", t)
