@@ -276,33 +276,79 @@ k_to_fx48(int64_t nslots, const double *vals, uint32_t *out, unsigned long long 
     if (nbad) atomicAdd(bad, (unsigned long long)nbad);
 }
 
-// packed column stream (struct colstream): one wavefront per slice
+// packed column stream (struct colstream): one wavefront per slice.  Mode of a slice (ok[slice]):
+//   1  every slot's 64 columns (padding entries = the row's own column included) lie within 2^16 of the slot's smallest:
+//      one base per slot (round 2);
+//   2  (round 4) the slice mixes rows of different length -- the k-th neighbour of a short row (a node on the surface
+//      of the mesh) plays another part than the k-th neighbour of its 27-neighbour slice mates and, once a breadth-first
+//      level is wider than 2^16 rows (200^3: 120 k), lies further away than an offset reaches.  Two bases per slot: A
+//      for the rows of the slice's full width, B for the shorter ones (cmask[slice]: one bit per lane); a padding
+//      entry (zero values) takes offset 0 from its class's base.  63.9 % -> 99.8 % of the slots at 200^3 / 400^3,
+//      98.4 % -> 99.9 % at 148^3 (tools: /profiles/r04/packed_columns_two_bases.txt);
+//   0  neither: the slice keeps the int32 stream.
+// rowof == nullptr (the folded copy's stream, whose lanes carry foreign pieces): modes 0 / 1 only.
 __global__ void __launch_bounds__(256)
-k_pack_cols(int32_t nslices, const int32_t *slot_ptr, const int32_t *cols, const int32_t *pair_ptr,
-            uint32_t *packed, int32_t *base, uint8_t *ok) {
+k_pack_cols(int32_t nslices, int64_t nloc, const int32_t *slot_ptr, const int32_t *cols, const int32_t *rowof, const int32_t *rowlen,
+            const int32_t *pair_ptr, uint32_t *packed, int32_t *base, int32_t *base2, unsigned long long *cmask, uint8_t *ok) {
     const int lane = threadIdx.x & 63;
     const int64_t slice = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slice >= nslices) return;
     const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
+    int32_t len = k1 - k0;   // without row lengths every entry counts as live and every lane as class A
+    if (rowof) {
+        const int64_t row = rowof[slice * 64 + lane];
+        len = row < nloc ? rowlen[row] : 0;
+    }
+    const bool cls_b = len < k1 - k0;
+    const int32_t BIG = 0x7fffffff;
+    auto wmin = [](int32_t v) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
+        return v;
+    };
+    auto wmax = [](int32_t v) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+        return v;
+    };
+    bool fits1 = true, fits2 = rowof != nullptr;
+    for (int32_t k = k0; k < k1; k++) {
+        const int32_t c = cols[(int64_t)k * 64 + lane];
+        const bool live = k - k0 < len;
+        fits1 = fits1 && (wmax(c) - wmin(c)) < 65536;
+        if (fits2) {
+            const int32_t mna = wmin(live && !cls_b ? c : BIG), mxa = wmax(live && !cls_b ? c : -1);
+            const int32_t mnb = wmin(live && cls_b ? c : BIG), mxb = wmax(live && cls_b ? c : -1);
+            fits2 = (mxa < 0 || mxa - mna < 65536) && (mxb < 0 || mxb - mnb < 65536);
+        }
+    }
+    const int mode = fits1 ? 1 : fits2 ? 2 : 0;
     uint32_t *out = packed + (int64_t)pair_ptr[slice] * 64 + lane;
-    bool fits = true;
     uint32_t lo = 0;
     for (int32_t k = k0; k < k1; k++) {
         const int32_t c = cols[(int64_t)k * 64 + lane];
-        int32_t mn = c, mx = c;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            mn = min(mn, __shfl_xor(mn, d, 64));
-            mx = max(mx, __shfl_xor(mx, d, 64));
+        uint32_t dlt;
+        if (mode == 2) {
+            const bool live = k - k0 < len;
+            const int32_t mna = wmin(live && !cls_b ? c : BIG);   // (never BIG: the rows of full width are live in every slot)
+            int32_t mnb = wmin(live && cls_b ? c : BIG);
+            if (mnb == BIG) mnb = mna;                            // no short row reaches this slot: its padding points at A's base
+            if (lane == 0) { base[k] = mna; base2[k] = mnb; }
+            dlt = live ? (uint32_t)(c - (cls_b ? mnb : mna)) & 0xffffu : 0u;
+        } else {
+            const int32_t mn = wmin(c);
+            if (lane == 0) { base[k] = mn; base2[k] = mn; }
+            dlt = (uint32_t)(c - mn) & 0xffffu;
         }
-        if (lane == 0) base[k] = mn;
-        fits = fits && (mx - mn) < 65536;
-        const uint32_t dlt = (uint32_t)(c - mn) & 0xffffu;
         if (((k - k0) & 1) == 0) lo = dlt;
         else { *out = lo | (dlt << 16); out += 64; }
     }
     if ((k1 - k0) & 1) *out = lo;
-    if (lane == 0) ok[slice] = fits ? 1 : 0;
+    const unsigned long long mb = __ballot(cls_b);
+    if (lane == 0) {
+        ok[slice] = (uint8_t)mode;
+        cmask[slice] = mode == 2 ? mb : 0ULL;
+    }
 }
 __global__ void k_pair_counts(int32_t nslices, const int32_t *slot_ptr, int32_t *cnt) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -310,7 +356,8 @@ __global__ void k_pair_counts(int32_t nslices, const int32_t *slot_ptr, int32_t 
 }
 __global__ void k_count_ok(int32_t nslices, const uint8_t *ok, const int32_t *slot_ptr, unsigned long long *out) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < nslices && ok[s]) atomicAdd(out, (unsigned long long)(slot_ptr[s + 1] - slot_ptr[s]));
+    if (s < nslices && ok[s]) atomicAdd(out, (unsigned long long)(slot_ptr[s + 1] - slot_ptr[s]));           // packed slots
+    if (s < nslices && ok[s] == 2) atomicAdd(out + 1, (unsigned long long)(slot_ptr[s + 1] - slot_ptr[s]));  // ... with two bases
 }
 
 // b^[i] = s_i * F[d - red[d]] on free DOFs, 0 on fixed ones; also x0 = 0, r = p = b^ and
@@ -440,8 +487,16 @@ struct colstream {
     const uint32_t *packed;   // [pair][64]: offset of slot 2j in the low half, of slot 2j+1 in the high half
     const int32_t *base;      // [slot] smallest column of the slot
     const int32_t *pair_ptr;  // [nslices + 1] first pair of every slice
-    const uint8_t *ok;        // [nslices] 1 = this slice is in the packed stream
+    const uint8_t *ok;        // [nslices] 0 = int32 columns, 1 = packed, one base per slot, 2 = packed, two bases (k_pack_cols)
+    const int32_t *base2;     // [slot] mode 2: the base of the slice's SHORTER rows (base: of its full-width rows)
+    const unsigned long long *cmask;   // [nslices] mode 2: bit l = lane l holds a shorter row
 };
+constexpr colstream NO_COLSTREAM = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+// the arrays behind `base` (one allocation, stan_pack_columns): [nslots] base, [nslots] base2, [nslices] cmask
+inline colstream make_colstream(const uint32_t *packed, const int32_t *base, const int32_t *pair_ptr, const uint8_t *ok, int64_t nslots) {
+    const int64_t n = nslots > 0 ? nslots : 1;
+    return colstream{packed, base, pair_ptr, ok, base + n, (const unsigned long long *)(base + 2 * n)};
+}
 
 #define STAN_SPMV_BLOCK(C, VP)                                                        \
     {                                                                                 \
@@ -494,26 +549,31 @@ k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, cons
         const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
         const int32_t *cp = cols + (int64_t)k0 * 64 + lane;
         const VT *vp = vals + (int64_t)k0 * vstream<VT>::STRIDE + lane;
+        const int pmode = cs.packed ? (int)cs.ok[slice] : 0;   // wave-uniform: 0 int32 columns, 1 / 2 packed (k_pack_cols)
 #ifdef STAN_LAB
 #include "lab/spmv_variants_lab.inc"   // lab-only kernel variants (VAR 8, 14-16)
 #endif
-        if (cs.packed && cs.ok[slice]) {   // wave-uniform: a slice is packed or not
+        if (pmode != 0) {   // one loop for both packed modes: a one-base slice has cmask 0 and base2 = base
+            // two bases per slot: the lane's class picks (a select between two scalars)
             const uint32_t *cq = cs.packed + (int64_t)cs.pair_ptr[slice] * 64 + lane;
-            const int32_t *bp = cs.base + __builtin_amdgcn_readfirstlane(k0);   // scalar loads
+            const int32_t *bp = cs.base + __builtin_amdgcn_readfirstlane(k0);
+            const int32_t *bq = cs.base2 + __builtin_amdgcn_readfirstlane(k0);
+            const bool cb = (cs.cmask[slice] >> lane) & 1ull;
             int32_t k = k0;
 #pragma unroll UNR2
             for (; k + 1 < k1; k += 2) {
                 const uint32_t wd = ld_stream<NT>(cq);
-                const int64_t c = (int64_t)bp[0] + (int64_t)(wd & 0xffffu);
-                const int64_t c2 = (int64_t)bp[1] + (int64_t)(wd >> 16);
+                const int64_t c = (int64_t)(cb ? bq[0] : bp[0]) + (int64_t)(wd & 0xffffu);
+                const int64_t c2 = (int64_t)(cb ? bq[1] : bp[1]) + (int64_t)(wd >> 16);
                 STAN_SPMV_BLOCK(c, vp)
                 STAN_SPMV_BLOCK(c2, vp + vstream<VT>::STRIDE)
                 cq += 64;
                 bp += 2;
+                bq += 2;
                 vp += 2 * vstream<VT>::STRIDE;
             }
             if (k < k1) {
-                const int64_t c = (int64_t)bp[0] + (int64_t)(ld_stream<NT>(cq) & 0xffffu);
+                const int64_t c = (int64_t)(cb ? bq[0] : bp[0]) + (int64_t)(ld_stream<NT>(cq) & 0xffffu);
                 STAN_SPMV_BLOCK(c, vp)
             }
         } else {
@@ -582,7 +642,7 @@ k_spmv_small(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr
     const int64_t row = slice < nslices ? (int64_t)rowof[slice * 64 + lane] : nloc;   // SELL-C-sigma: position -> block row
     if (slice < nslices) {
         const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
-        const bool packed = cs.packed && cs.ok[slice];
+        const bool packed = cs.packed && cs.ok[slice] == 1;   // (two-base slices read the int32 columns here)
         const int64_t pp = packed ? (int64_t)cs.pair_ptr[slice] : 0;
         for (int32_t k = k0 + w; k < k1; k += 4) {
             int64_t c;
@@ -671,7 +731,7 @@ k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, con
         z1 += a[3] * u0 + a[4] * u1 + a[5] * u2;                                      \
         z2 += a[6] * u0 + a[7] * u1 + a[8] * u2;                                      \
     }
-        if (cs.packed && cs.ok[slice]) {
+        if (cs.packed && cs.ok[slice] == 1) {   // (two-base slices read the int32 columns here)
             const uint32_t *cq = cs.packed + (int64_t)cs.pair_ptr[slice] * 64 + lane;
             const int32_t *bp = cs.base + __builtin_amdgcn_readfirstlane(k0);
             int32_t k = k0;
@@ -783,7 +843,7 @@ k_spmv_fold(int32_t nslices, int64_t nloc, const int32_t *__restrict__ fold_ptr,
             g0 += mine ? 0.0 : s0; g1 += mine ? 0.0 : s1; g2 += mine ? 0.0 : s2;                \
         }                                                                                       \
     }
-        if (cs.packed && cs.ok[slice]) {   // wave-uniform: the folded copy has its own packed column stream
+        if (cs.packed && cs.ok[slice] == 1) {   // wave-uniform: the folded copy has its own packed column stream (modes 0 / 1)
             const uint32_t *cq = cs.packed + (int64_t)cs.pair_ptr[slice] * 64 + lane;
             const int32_t *bp = cs.base + __builtin_amdgcn_readfirstlane(k0);
             int32_t k = k0;
@@ -1250,8 +1310,8 @@ template <> const uint32_t *fold_vals<uint32_t>(const stan_ctx *ctx, const stan_
     return ctx->row_folding != 0 && vals == K->d_vals48 ? K->d_fold_vals48 : nullptr;
 }
 inline colstream fold_cols_of(const stan_ctx *ctx, const stan_matrix *K) {
-    return ctx->cols16 && K->d_fold_cols16 ? colstream{K->d_fold_cols16, K->d_fold_colbase, K->d_fold_pair_ptr, K->d_fold_packed}
-                                           : colstream{nullptr, nullptr, nullptr, nullptr};
+    return ctx->cols16 && K->d_fold_cols16 ? make_colstream(K->d_fold_cols16, K->d_fold_colbase, K->d_fold_pair_ptr, K->d_fold_packed, K->nfslots)
+                                           : NO_COLSTREAM;
 }
 // which: 0 = all slices, 1 = interior list, 2 = boundary list (partials offset by the
 // interior launch's block count).  Returns the number of partial slots this launch writes.
@@ -1265,8 +1325,8 @@ unsigned launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double
     if (!stream) stream = ctx->stream;
     const int32_t *slist = which == 1 ? K->d_sl_int : which == 2 ? K->d_sl_bnd : nullptr;
     const int32_t nlist = which == 1 ? K->n_sl_int : which == 2 ? K->n_sl_bnd : K->nslices;
-    const colstream cs = ctx->cols16 && K->d_cols16 ? colstream{K->d_cols16, K->d_colbase, K->d_pair_ptr, K->d_slice_packed}
-                                                    : colstream{nullptr, nullptr, nullptr, nullptr};
+    const colstream cs = ctx->cols16 && K->d_cols16 ? make_colstream(K->d_cols16, K->d_colbase, K->d_pair_ptr, K->d_slice_packed, K->nslots)
+                                                    : NO_COLSTREAM;
     if (stan_small_system(ctx, K)) {   // one workgroup per slice (k_spmv_small); partials per slice
         const int32_t poff_s = which == 2 ? K->n_sl_int : 0;
         const unsigned grid_s = (unsigned)nlist;
@@ -1331,8 +1391,8 @@ unsigned launch_spmv2(stan_ctx *ctx, stan_matrix *K, const VT *vals, const doubl
                            fold_cols_of(ctx, K));
         return grid;
     }
-    const colstream cs = ctx->cols16 && K->d_cols16 ? colstream{K->d_cols16, K->d_colbase, K->d_pair_ptr, K->d_slice_packed}
-                                                    : colstream{nullptr, nullptr, nullptr, nullptr};
+    const colstream cs = ctx->cols16 && K->d_cols16 ? make_colstream(K->d_cols16, K->d_colbase, K->d_pair_ptr, K->d_slice_packed, K->nslots)
+                                                    : NO_COLSTREAM;
     hipLaunchKernelGGL((k_spmv2<VT>), dim3(grid), dim3(256), 0, stream, K->nslices, K->nloc, K->d_slot_ptr,
                        K->d_rowof, K->d_cols, vals, x, x2, y, y2, partial, st, k, slist, nlist, poff, fold, cs);
     return grid;
@@ -1495,12 +1555,13 @@ int stan_matrix_make_fx48(stan_ctx *ctx, stan_matrix *K) {
 int stan_matrix_make_cols16(stan_ctx *ctx, stan_matrix *K) {
     if (K->d_cols16 || K->nslices <= 0) return STAN_OK;
     return stan_pack_columns(ctx, K->nslices, K->nslots, K->d_slot_ptr, K->d_cols, &K->d_cols16, &K->d_colbase, &K->d_pair_ptr,
-                             &K->d_slice_packed, &K->slots_packed);
+                             &K->d_slice_packed, &K->slots_packed, K->nloc, K->d_rowof, K->d_rowlen, &K->slots_packed2);
 }
 // the same for any sliced column stream (the folded copy of fold.hip has its own); *packed stays nullptr when the
 // pair index would not fit an int32
 int stan_pack_columns(stan_ctx *ctx, int32_t nslices, int64_t nslots, const int32_t *d_slot_ptr, const int32_t *d_cols,
-                      uint32_t **packed_out, int32_t **base_out, int32_t **pair_ptr_out, uint8_t **ok_out, int64_t *slots_packed) {
+                      uint32_t **packed_out, int32_t **base_out, int32_t **pair_ptr_out, uint8_t **ok_out, int64_t *slots_packed,
+                      int64_t nloc, const int32_t *d_rowof, const int32_t *d_rowlen, int64_t *slots_packed2) {
     hipStream_t st_ = ctx->stream;
     dev_bufs bufs;
     int32_t *cnt; int64_t *ptr64;
@@ -1516,20 +1577,26 @@ int stan_pack_columns(stan_ctx *ctx, int32_t nslices, int64_t nslots, const int3
     std::vector<int32_t> h32(h.size());
     for (size_t i = 0; i < h.size(); i++) h32[i] = (int32_t)h[i];
     STANCHK(stan_dmalloc(ctx, pair_ptr_out, h32.size()));
-    STANCHK(stan_dmalloc(ctx, base_out, (size_t)(nslots > 0 ? nslots : 1)));
+    // one allocation: [n] base, [n] base2, [nslices] cmask (64-bit words), n = max(nslots, 1): make_colstream
+    const size_t nb_ = (size_t)(nslots > 0 ? nslots : 1);
+    STANCHK(stan_dmalloc(ctx, base_out, 2 * nb_ + 2 * (size_t)nslices + 2));
     STANCHK(stan_dmalloc(ctx, ok_out, (size_t)nslices));
     uint32_t *packed;
     STANCHK(stan_dmalloc(ctx, &packed, (size_t)(npairs > 0 ? npairs : 1) * 64));
     HIPCHK(ctx, hipMemcpyAsync(*pair_ptr_out, h32.data(), h32.size() * 4, hipMemcpyHostToDevice, st_));
-    hipLaunchKernelGGL(k_pack_cols, dim3(nblk(nslices, 4)), dim3(256), 0, st_, nslices, d_slot_ptr, d_cols, *pair_ptr_out, packed,
-                       *base_out, *ok_out);
-    unsigned long long *d_cnt = (unsigned long long *)(ctx->d_status + SS_COUNTER);
-    HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 8, st_));
+    int32_t *b2_ = *base_out + nb_;
+    unsigned long long *cm_ = (unsigned long long *)(*base_out + 2 * nb_);
+    if (((uintptr_t)cm_ & 7) != 0) cm_ = (unsigned long long *)((uintptr_t)cm_ + 4);   // (never: 2 n ints from an aligned block)
+    hipLaunchKernelGGL(k_pack_cols, dim3(nblk(nslices, 4)), dim3(256), 0, st_, nslices, nloc, d_slot_ptr, d_cols, d_rowof, d_rowlen,
+                       *pair_ptr_out, packed, *base_out, b2_, cm_, *ok_out);
+    unsigned long long *d_cnt = (unsigned long long *)(ctx->d_status + SS_COUNTER);   // two words: SS_COUNTER, SS_H_ERRCOPY
+    HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 16, st_));
     hipLaunchKernelGGL(k_count_ok, dim3(nblk(nslices, 256)), dim3(256), 0, st_, nslices, *ok_out, d_slot_ptr, d_cnt);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_COUNTER, d_cnt, 8, hipMemcpyDeviceToHost, st_));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_COUNTER, d_cnt, 16, hipMemcpyDeviceToHost, st_));
     HIPCHK(ctx, hipStreamSynchronize(st_));   // h32 must outlive the copy
     *slots_packed = ctx->h_status[SS_COUNTER];
+    if (slots_packed2) *slots_packed2 = ctx->h_status[SS_COUNTER + 1];
     *packed_out = packed;
     return STAN_OK;
 }
@@ -1998,7 +2065,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         const bool packed = ctx->cols16 && K->d_cols16;
         const double packed_frac = packed && K->nslots > 0 ? (double)K->slots_packed / (double)K->nslots : 0.0;
         ctx->prof.spmv_bytes = K->nblocks * blk_bytes + 3 * K->nloc * 16 + K->nloc * 4
-                               - (int64_t)(packed_frac * (double)K->nblocks * 2.0) + (packed ? K->slots_packed * 4 : 0);
+                               - (int64_t)(packed_frac * (double)K->nblocks * 2.0) + (packed ? (K->slots_packed + K->slots_packed2) * 4 : 0);
         const bool folded = ctx->row_folding != 0 && (vs == STAN_PREC_FIXED48 ? K->d_fold_vals48 != nullptr : vs == STAN_PREC_MIXED ? K->d_fold_vals32 != nullptr
                                                                                                                                     : K->d_fold_vals != nullptr);
         if (folded) {   // its own packed column stream, 4 B of plan per row

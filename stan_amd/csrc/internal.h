@@ -282,7 +282,8 @@ struct stan_matrix {
     int32_t *d_colbase = nullptr;   //   [nslots] smallest column of each slot
     int32_t *d_pair_ptr = nullptr;  //   [nslices+1]
     uint8_t *d_slice_packed = nullptr;  // [nslices] 1 = slice is in the packed stream
-    int64_t slots_packed = 0;
+    int64_t slots_packed = 0;       // ELL slots of packed slices (modes 1 and 2 of k_pack_cols) ...
+    int64_t slots_packed2 = 0;      // ... of which in two-base slices (4 B more per slot: the second base)
     double *d_vals = nullptr;       // [nslots][9][64]
     float *d_vals32 = nullptr;      // same layout, fp32 copy (mixed precision)
     uint32_t *d_vals48 = nullptr;   // FIXED-48 stream of the scaled values, [slot][14][64] dwords
@@ -365,7 +366,8 @@ void stan_matrix_abandon_folding(stan_ctx *ctx, stan_matrix *K);
 int stan_matrix_make_fx48(stan_ctx *ctx, stan_matrix *K);
 int stan_matrix_make_cols16(stan_ctx *ctx, stan_matrix *K);
 int stan_pack_columns(stan_ctx *ctx, int32_t nslices, int64_t nslots, const int32_t *d_slot_ptr, const int32_t *d_cols,
-                      uint32_t **packed_out, int32_t **base_out, int32_t **pair_ptr_out, uint8_t **ok_out, int64_t *slots_packed);
+                      uint32_t **packed_out, int32_t **base_out, int32_t **pair_ptr_out, uint8_t **ok_out, int64_t *slots_packed,
+                      int64_t nloc = 0, const int32_t *d_rowof = nullptr, const int32_t *d_rowlen = nullptr, int64_t *slots_packed2 = nullptr);
 int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K);
 int stan_cg_workspace(stan_ctx *ctx, const stan_matrix *K);  // (re)allocates ctx->ws for K's sizes
 void stan_cg_workspace_free(stan_ctx *ctx);

@@ -132,3 +132,34 @@ def test_shards_of_the_revolved_mesh(built_libs):
     from tests import fuzz
     xyz, conn = revolved_mesh(72, 2, 3)
     fuzz.check_shards(lambda: hip.Context(0), _job(xyz, conn), 3)
+
+
+def test_two_base_packed_columns_at_a_size_with_wide_bfs_levels(gpu_ctx):
+    """once a breadth-first level is wider than 2^16 rows, the slices that mix surface rows with
+    27-neighbour rows no longer fit ONE 16-bit base per slot (63.9 % of the slots packed at 200^3, 98.4 % at 148^3);
+    with a second base for the slice's shorter rows (k_pack_cols mode 2) practically all do.  160^3: levels up to 77 k
+    rows wide.  Lossless: U, the iteration count and a plain product keep the bits of the int32 stream."""
+    from stan_amd import hip
+    job = problem.cube_job(160)
+    K = gpu_ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+    gpu_ctx.set_profiling(True)
+    gpu_ctx.set_option(hip.OPT_CG_MERIT_STOP, 0)
+    out = {}
+    try:
+        for packed in (1, 0):
+            gpu_ctx.set_option(hip.OPT_PACKED_COLUMNS, packed)
+            U, rep = K.cg_solve(job.F, 1e-8)
+            pr = gpu_ctx.profile()
+            x = np.random.default_rng(5).standard_normal(job.n_red)
+            out[packed] = (U, rep, pr["col_slots_packed"], pr["spmv_bytes"], K.spmv(x))
+    finally:
+        gpu_ctx.set_option(hip.OPT_PACKED_COLUMNS, 1)
+        gpu_ctx.set_option(hip.OPT_CG_MERIT_STOP, 1)
+        gpu_ctx.set_profiling(False)
+    info = K.info()
+    (Ua, ra, na, ba, ya), (Ub, rb, nb_, bb, yb) = out[1], out[0]
+    assert ra == rb and ra["terminationtype"] == 1
+    assert np.array_equal(Ua, Ub) and np.array_equal(ya, yb)
+    assert nb_ == 0 and na >= 0.99 * info["n_slots"], (na, info["n_slots"])      # one base alone: ~0.93 here
+    assert ba < bb
+    K.free()
