@@ -13,7 +13,7 @@ from stan_amd import hip, problem  # noqa: E402
 
 spec, nranks, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 if spec.startswith("perf:"):
-    from tests.perforated import perforated_job
+    from stan_amd.problem import perforated_job
     _, n, frac = spec.split(":")
     job = perforated_job(int(n), float(frac))
 else:

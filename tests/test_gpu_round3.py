@@ -28,7 +28,7 @@ def test_sell_c_sigma_on_a_perforated_box(gpu_ctx, oracle, frac):
     from 8 % / 26 % to <= 3 % (memory; the default stays 1 because the sort costs the gather its locality:
     profiles/r03/SELL_C_SIGMA.md).  The permutation is internal: the CRS export, every product and the
     oracle's K are unchanged, bit for bit, for every window."""
-    from tests.perforated import perforated_job
+    from stan_amd.problem import perforated_job
     job = perforated_job(24, frac)
     args = (job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
     rng = np.random.default_rng(5)
@@ -337,7 +337,7 @@ def test_folded_rows_give_the_same_product(gpu_ctx, oracle, mesh, prec):
     A folded row is summed as own part + pieces (another order): the product agrees with the padded layout's to
     rounding, rows that are not folded keep their bits, the solve meets the oracle.  star12: rows of 75 blocks
     (the centre line of a 12-sector star) among rows of 10-30: several helper lanes for one row."""
-    from tests.perforated import perforated_job
+    from stan_amd.problem import perforated_job
     job = perforated_job(18, 0.4) if mesh == "perforated" else _star_job(12, rings=1) if mesh == "star12" else problem.cube_job(9, jitter=0.05)
     args = (job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
     x = np.random.default_rng(3).standard_normal(job.n_red)
@@ -391,7 +391,7 @@ def test_folded_rows_in_a_sharded_solve(built_libs):
     code = r'''
 import numpy as np
 from stan_amd import hip
-from tests.perforated import perforated_job
+from stan_amd.problem import perforated_job
 job = perforated_job(14, 0.35)
 args = (job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
 ctx = hip.Context(devices=[0, 0, 0])

@@ -273,7 +273,7 @@ def test_irregular_meshes_vs_independent_assembly_and_direct_solver(oracle, mesh
     import scipy.sparse.linalg as spla
     from stan_amd.cube import star_mesh
     if mesh == "perforated":
-        from tests.perforated import perforated_job
+        from stan_amd.problem import perforated_job
         job = perforated_job(6, 0.4)
     else:
         xyz, conn = star_mesh(int(mesh[4:]), 3, 1)
