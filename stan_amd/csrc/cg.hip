@@ -193,1079 +193,11 @@ __device__ __forceinline__ bool stopped(const int64_t *st, int64_t k) {
     return st[T_ITER_A] < k || st[T_ITER_B] < k;
 }
 
-// ---- setup kernels ---------------------------------------------------------------------------
-// s_i = 1/sqrt(K_ii) if K_ii > 0 else 1 (lincgsolvesparse); one lane per block row
-__global__ void k_diag_scale(int64_t nloc, const int32_t *rowlen, const int32_t *posof, const int32_t *slot_ptr,
-                             const int32_t *cols, const double *vals, double *s) {
-    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= nloc) return;
-    const int64_t pos = posof[row];   // SELL-C-sigma: where the row sits in the sliced layout
-    const int64_t slice = pos >> 6;
-    const int lane = (int)(pos & 63);
-    const int32_t k0 = slot_ptr[slice];
-    double d0 = 0, d1 = 0, d2 = 0;
-    for (int k = 0; k < rowlen[row]; k++)
-        if (cols[((int64_t)k0 + k) * 64 + lane] == (int32_t)row) {
-            const double *v = vals + ((int64_t)k0 + k) * 9 * 64 + lane;
-            d0 = v[0 * 64]; d1 = v[4 * 64]; d2 = v[8 * 64];
-            break;
-        }
-    s[3 * row + 0] = d0 > 0 ? 1.0 / sqrt(d0) : 1.0;
-    s[3 * row + 1] = d1 > 0 ? 1.0 / sqrt(d1) : 1.0;
-    s[3 * row + 2] = d2 > 0 ? 1.0 / sqrt(d2) : 1.0;
-}
+#include "cg_setup_kernels.inc"   // scaling (k_diag_scale, k_scale_matrix), value-stream copies (fp32, FIXED-48), the packed column stream (k_pack_cols), k_init / k_reduce / k_init_scalars
 
-// vals[slot][3m+n][lane] *= s[3 row + m] * s[3 col + n]   (inverse=1: divide)
-__global__ void __launch_bounds__(256)
-k_scale_matrix(int32_t nslices, const int32_t *slot_ptr, const int32_t *rowof, const int32_t *cols, double *vals,
-               const double *s, int inverse) {
-    const int lane = threadIdx.x & 63;
-    const int64_t slice = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (slice >= nslices) return;
-    const int64_t row = rowof[slice * 64 + lane];
-    double sr[3] = {s[3 * row], s[3 * row + 1], s[3 * row + 2]};  // s is padded to slices
-    if (inverse) { sr[0] = 1.0 / sr[0]; sr[1] = 1.0 / sr[1]; sr[2] = 1.0 / sr[2]; }
-    for (int32_t k = slot_ptr[slice]; k < slot_ptr[slice + 1]; k++) {
-        const int32_t c = cols[(int64_t)k * 64 + lane];
-        double sc[3] = {s[3 * (int64_t)c], s[3 * (int64_t)c + 1], s[3 * (int64_t)c + 2]};
-        if (inverse) { sc[0] = 1.0 / sc[0]; sc[1] = 1.0 / sc[1]; sc[2] = 1.0 / sc[2]; }
-        double *v = vals + (int64_t)k * 9 * 64 + lane;
-#pragma unroll
-        for (int m = 0; m < 3; m++)
-#pragma unroll
-            for (int n = 0; n < 3; n++) v[(3 * m + n) * 64] *= sr[m] * sc[n];
-    }
-}
+#include "spmv_kernels.inc"   // the products: k_spmv (one wavefront per slice), k_spmv_small (one workgroup per slice), k_spmv2 (two right-hand sides), k_spmv_fold (folded rows)
 
-__global__ void k_to_fp32(const double *in, float *out, int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) out[i] = (float)in[i];
-}
-
-constexpr double FX48_ONE = 70368744177664.0;                          // 2^46
-constexpr double FX48_INV = 1.0 / 70368744177664.0;                    // 2^-46
-constexpr double FX48_BIAS = 4503599627370496.0 + 140737488355328.0;   // 2^52 + 2^47
-
-// scaled fp64 values -> FIXED-48 stream (see vstream<uint32_t>); *bad counts the entries
-// with |a| >= 2 (not representable: the matrix was not SPD-scalable)
-__global__ void __launch_bounds__(256)
-k_to_fx48(int64_t nslots, const double *vals, uint32_t *out, unsigned long long *bad) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t slot = t >> 6;
-    const int lane = (int)(t & 63);
-    if (slot >= nslots) return;
-    const double *v = vals + slot * 9 * 64 + lane;
-    uint32_t *o = out + slot * 14 * 64 + lane;
-    uint32_t hi[10];
-    int nbad = 0;
-#pragma unroll
-    for (int j = 0; j < 9; j++) {
-        const double a = v[j * 64] * FX48_ONE;
-        long long q = 0;
-        if (!(fabs(a) < 140737488355328.0)) nbad++;  // also catches NaN
-        else q = __double2ll_rn(a);
-        if (q >= 140737488355328LL) { q = 0; nbad++; }
-        const unsigned long long u = (unsigned long long)(q + 140737488355328LL);
-        o[j * 64] = (uint32_t)u;
-        hi[j] = (uint32_t)(u >> 32);
-    }
-    hi[9] = 0;
-#pragma unroll
-    for (int m = 0; m < 5; m++) o[(9 + m) * 64] = hi[2 * m] | (hi[2 * m + 1] << 16);
-    if (nbad) atomicAdd(bad, (unsigned long long)nbad);
-}
-
-// packed column stream (struct colstream): one wavefront per slice.  Mode of a slice (ok[slice]):
-//   1  every slot's 64 columns (padding entries = the row's own column included) lie within 2^16 of the slot's smallest:
-//      one base per slot (round 2);
-//   2  (round 4) the slice mixes rows of different length -- the k-th neighbour of a short row (a node on the surface
-//      of the mesh) plays another part than the k-th neighbour of its 27-neighbour slice mates and, once a breadth-first
-//      level is wider than 2^16 rows (200^3: 120 k), lies further away than an offset reaches.  Two bases per slot: A
-//      for the rows of the slice's full width, B for the shorter ones (cmask[slice]: one bit per lane); a padding
-//      entry (zero values) takes offset 0 from its class's base.  63.9 % -> 99.8 % of the slots at 200^3 / 400^3,
-//      98.4 % -> 99.9 % at 148^3 (tools: /profiles/r04/packed_columns_two_bases.txt);
-//   0  neither: the slice keeps the int32 stream.
-// rowof == nullptr (the folded copy's stream, whose lanes carry foreign pieces): modes 0 / 1 only.
-__global__ void __launch_bounds__(256)
-k_pack_cols(int32_t nslices, int64_t nloc, const int32_t *slot_ptr, const int32_t *cols, const int32_t *rowof, const int32_t *rowlen,
-            const int32_t *pair_ptr, uint32_t *packed, int32_t *base, int32_t *base2, unsigned long long *cmask, uint8_t *ok) {
-    const int lane = threadIdx.x & 63;
-    const int64_t slice = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (slice >= nslices) return;
-    const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
-    int32_t len = k1 - k0;   // without row lengths every entry counts as live and every lane as class A
-    if (rowof) {
-        const int64_t row = rowof[slice * 64 + lane];
-        len = row < nloc ? rowlen[row] : 0;
-    }
-    const bool cls_b = len < k1 - k0;
-    const int32_t BIG = 0x7fffffff;
-    auto wmin = [](int32_t v) {
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
-        return v;
-    };
-    auto wmax = [](int32_t v) {
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
-        return v;
-    };
-    bool fits1 = true, fits2 = rowof != nullptr;
-    for (int32_t k = k0; k < k1; k++) {
-        const int32_t c = cols[(int64_t)k * 64 + lane];
-        const bool live = k - k0 < len;
-        fits1 = fits1 && (wmax(c) - wmin(c)) < 65536;
-        if (fits2) {
-            const int32_t mna = wmin(live && !cls_b ? c : BIG), mxa = wmax(live && !cls_b ? c : -1);
-            const int32_t mnb = wmin(live && cls_b ? c : BIG), mxb = wmax(live && cls_b ? c : -1);
-            fits2 = (mxa < 0 || mxa - mna < 65536) && (mxb < 0 || mxb - mnb < 65536);
-        }
-    }
-    const int mode = fits1 ? 1 : fits2 ? 2 : 0;
-    uint32_t *out = packed + (int64_t)pair_ptr[slice] * 64 + lane;
-    uint32_t lo = 0;
-    for (int32_t k = k0; k < k1; k++) {
-        const int32_t c = cols[(int64_t)k * 64 + lane];
-        uint32_t dlt;
-        if (mode == 2) {
-            const bool live = k - k0 < len;
-            const int32_t mna = wmin(live && !cls_b ? c : BIG);   // (never BIG: the rows of full width are live in every slot)
-            int32_t mnb = wmin(live && cls_b ? c : BIG);
-            if (mnb == BIG) mnb = mna;                            // no short row reaches this slot: its padding points at A's base
-            if (lane == 0) { base[k] = mna; base2[k] = mnb; }
-            dlt = live ? (uint32_t)(c - (cls_b ? mnb : mna)) & 0xffffu : 0u;
-        } else {
-            const int32_t mn = wmin(c);
-            if (lane == 0) { base[k] = mn; base2[k] = mn; }
-            dlt = (uint32_t)(c - mn) & 0xffffu;
-        }
-        if (((k - k0) & 1) == 0) lo = dlt;
-        else { *out = lo | (dlt << 16); out += 64; }
-    }
-    if ((k1 - k0) & 1) *out = lo;
-    const unsigned long long mb = __ballot(cls_b);
-    if (lane == 0) {
-        ok[slice] = (uint8_t)mode;
-        cmask[slice] = mode == 2 ? mb : 0ULL;
-    }
-}
-__global__ void k_pair_counts(int32_t nslices, const int32_t *slot_ptr, int32_t *cnt) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < nslices) cnt[s] = (slot_ptr[s + 1] - slot_ptr[s] + 1) >> 1;
-}
-__global__ void k_count_ok(int32_t nslices, const uint8_t *ok, const int32_t *slot_ptr, unsigned long long *out) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < nslices && ok[s]) atomicAdd(out, (unsigned long long)(slot_ptr[s + 1] - slot_ptr[s]));           // packed slots
-    if (s < nslices && ok[s] == 2) atomicAdd(out + 1, (unsigned long long)(slot_ptr[s + 1] - slot_ptr[s]));  // ... with two bases
-}
-
-// b^[i] = s_i * F[d - red[d]] on free DOFs, 0 on fixed ones; also x0 = 0, r = p = b^ and
-// partial sums of b^.b^ (x0 = 0 => r0 = b^, merit0 = 0).
-__global__ void __launch_bounds__(VEC_T)
-k_init(int64_t n3, int64_t dof0, const int32_t *red, const double *F, const double *s,
-       double *bh, double *x0, double *r, double *p, double *partial, fold_args fold) {
-    __shared__ double sh[4];
-    __shared__ int sh_last;
-    double acc = 0;
-    const int64_t stride = (int64_t)gridDim.x * VEC_T;
-    for (int64_t i = (int64_t)blockIdx.x * VEC_T + threadIdx.x; i < n3; i += stride) {
-        const int32_t rd = red[dof0 + i];
-        const double b = rd == -1 ? 0.0 : s[i] * F[dof0 + i - rd];
-        bh[i] = b;
-        x0[i] = 0.0;
-        r[i] = b;
-        p[i] = b;
-        acc += b * b;
-    }
-    const double t = block_sum(acc, sh);
-    if (threadIdx.x == 0) st_agent(partial + blockIdx.x, t);
-    if (fold.counter && fold_arrive(fold, &sh_last)) fold_finish<1>(fold, partial, sh);
-}
-
-// out[j] = sum_i partial[i*nv + j]: the unfolded form of the reduction (one 256-thread block, the
-// same summation order as fold_finish: both paths give the same bits)
-// st != nullptr (the loop's launches, peer to peer): once the solve has stopped -- every rank takes the same decision, but
-// not at the same moment -- this launch only COUNTS, like fold_skip: a rank that free-runs through the iterations enqueued
-// behind the stop (STAN_P2P_WAIT_MODE=2: stopped consumers do not poll) must not store stale partials into a mailbox slot
-// that a slower peer has not read yet (slot R + RING aliases slot R).
-template <int NV>
-__global__ void __launch_bounds__(256)
-k_reduce(const double *partial, int np, double *out, p2p_out po, const int64_t *st, int64_t k) {
-    __shared__ double sh[4];
-    if (st && po.pp && stopped(st, k)) {
-        if (po.signal && (int)threadIdx.x < po.pp->n)
-            __hip_atomic_fetch_add(po.pp->sig_red[threadIdx.x][po.slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
-    }
-    double r[NV];
-    sum_partials<NV>(partial, np, sh, r);   // np == 0 (a rank that owns no rows): zeros
-    publish_sums<NV>(out, po, r, sh);
-}
-
-// after the b^.b^ reduction: bnorm, first residual test, rho, prevmf
-__global__ void __launch_bounds__(64) k_init_scalars(double *sc, int64_t *st, double epsf, red_src rs) {
-    __shared__ double sh[4];
-    double t[1];
-    red_get<1>(sc + S_VMV, rs, t, sh);   // b^.b^ (all ranks' partials when sharded peer to peer)
-    if (threadIdx.x != 0) return;
-    const double r2 = t[0];
-    sc[S_BNORM] = sqrt(r2);
-    sc[S_RHO0] = r2; sc[S_RHO1] = r2;  // iteration 1 reads slot 1
-    sc[S_PMF0] = 0.0; sc[S_PMF1] = 0.0;
-    sc[S_R2OUT] = r2;
-    st[T_ITER_A] = 0x7fffffffffffffffLL;
-    st[T_ITER_B] = 0x7fffffffffffffffLL;
-    st[T_TYPE] = 0; st[T_ITERS] = 0; st[T_XSEL] = 0;
-    if (!isfinite(r2)) { st[T_TYPE] = -4; st[T_ITER_A] = 0; }
-    else if (sqrt(r2) <= epsf * sqrt(r2)) { st[T_TYPE] = 1; st[T_ITER_A] = 0; }
-}
-
-// ---- SpMV --------------------------------------------------------------------------------------
-// y = A x over BSELL-64.  One wavefront per slice, one lane per block row: every load of
-// the value stream is a contiguous 512-B (fp64) / 256-B (fp32) wave access; x is gathered
-// (24 B per block, L2 / Infinity-Cache resident: neighbouring rows share columns).
-// DOT = 1: also the per-block partial of x_own . y  (p.Ap of the CG); DOT = 2: the partials of
-// x_own . x_own and x_own . y (r.r and r.Ar of the single-reduction CG); the block that finishes
-// last adds the partials up (fold_args).
-// VAR selects the kernel variant.  The product library carries three:
-//   0   plain loads, identity workgroup mapping (reference point of the A/B runs)
-//   9   non-temporal loads for the once-read matrix stream (keeps x in L2 / MALL) + XCD-chunked
-//       workgroup mapping (below)                                   -- default for fp64 / fp32
-//   12  = 9 with the block loop unrolled by 4                       -- default for FIXED-48
-// A lab build (make lab: -DSTAN_LAB, build_lab/libstan_hip_lab.so, never shipped) adds the other
-// A/B variants of round 1 (1-8, 10, 11, 13; 8 is a timing-only kernel whose results are wrong).
-// NT must be a compile-time choice: with a run-time flag, `nt ? __builtin_nontemporal_load(p) : *p`
-// is two loads of one address that the optimiser merges into ONE plain load inside this helper,
-// before it is inlined anywhere -- the non-temporal hint never reached the ISA (no `nt` bit on any
-// global_load of the first builds; found by reading the disassembly).
-template <bool NT, typename T>
-__device__ __forceinline__ T ld_stream(const T *p) {
-    if constexpr (NT) return __builtin_nontemporal_load(p);
-    else return *p;
-}
-
-// Value streams of the matrix.  double / float: vals[slot][9][64].
-// uint32_t = FIXED-48 (STAN_PREC_FIXED48): after the Jacobi scaling every entry of an SPD matrix
-// satisfies |a_ij| <= sqrt(a_ii a_jj) = 1, so no exponent is needed: q = rint(a * 2^46) as a
-// signed 48-bit integer (absolute error <= 2^-47 = 7.1e-15 of the unit diagonal), stored
-// offset-binary u = q + 2^47 as vals48[slot][14][64] dwords: rows 0..8 the low 32 bits of the
-// nine entries, rows 9..13 the high 16 bits packed two per dword.  60 B per block instead of
-// 76 B.  Decoding is one integer op and one exact fp64 subtraction per entry: the bits
-// 0x43300000'00000000 | u are the double 2^52 + u.  The 2^-46 is applied to the three
-// gathered x values instead of the nine entries (powers of two commute with rounding), so
-// the arithmetic is the fp64 product with the quantised matrix.
-template <typename VT> struct vstream { static constexpr int STRIDE = 9 * 64; static constexpr bool FX = false; };
-template <> struct vstream<uint32_t> { static constexpr int STRIDE = 14 * 64; static constexpr bool FX = true; };
-
-template <bool NT, typename VT>
-__device__ __forceinline__ void load9(const VT *vp, double a[9]) {
-    if constexpr (vstream<VT>::FX) {
-        uint32_t lo[9], hw[5];
-#pragma unroll
-        for (int j = 0; j < 9; j++) lo[j] = ld_stream<NT>(vp + j * 64);
-#pragma unroll
-        for (int m = 0; m < 5; m++) hw[m] = ld_stream<NT>(vp + (9 + m) * 64);
-#pragma unroll
-        for (int j = 0; j < 9; j++) {
-            const uint32_t h = (j & 1) ? (hw[j >> 1] >> 16) : (hw[j >> 1] & 0xffffu);
-            a[j] = __hiloint2double((int)(0x43300000u | h), (int)lo[j]) - FX48_BIAS;
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 9; j++) a[j] = (double)ld_stream<NT>(vp + j * 64);
-    }
-}
-
-// Packed column stream (round 2): the block-column indices of a slot are, in reference (BFS) DOF
-// order, within a few thousand of each other across the 64 rows of a slice, so a slot stores its
-// smallest column once (a wave-uniform scalar) and every lane a 16-bit offset, two slots per
-// dword: 2 B per block instead of 4 (74 B instead of 76 with fp64 values: -2.6 % of the SpMV's
-// bytes, lossless, same products in the same order -> same bits).  Slices whose offsets do not fit
-// (the ragged last slice, rows coupling owned and halo columns far apart) keep the int32 stream.
-struct colstream {
-    const uint32_t *packed;   // [pair][64]: offset of slot 2j in the low half, of slot 2j+1 in the high half
-    const int32_t *base;      // [slot] smallest column of the slot
-    const int32_t *pair_ptr;  // [nslices + 1] first pair of every slice
-    const uint8_t *ok;        // [nslices] 0 = int32 columns, 1 = packed, one base per slot, 2 = packed, two bases (k_pack_cols)
-    const int32_t *base2;     // [slot] mode 2: the base of the slice's SHORTER rows (base: of its full-width rows)
-    const unsigned long long *cmask;   // [nslices] mode 2: bit l = lane l holds a shorter row
-};
-constexpr colstream NO_COLSTREAM = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-// the arrays behind `base` (one allocation, stan_pack_columns): [nslots] base, [nslots] base2, [nslices] cmask
-inline colstream make_colstream(const uint32_t *packed, const int32_t *base, const int32_t *pair_ptr, const uint8_t *ok, int64_t nslots) {
-    const int64_t n = nslots > 0 ? nslots : 1;
-    return colstream{packed, base, pair_ptr, ok, base + n, (const unsigned long long *)(base + 2 * n)};
-}
-
-#define STAN_SPMV_BLOCK(C, VP)                                                        \
-    {                                                                                 \
-        double a[9];                                                                  \
-        load9<NT, VT>(VP, a);                                                         \
-        double x0 = x[3 * (C)], x1 = x[3 * (C) + 1], x2 = x[3 * (C) + 2];             \
-        if (vstream<VT>::FX) { x0 *= FX48_INV; x1 *= FX48_INV; x2 *= FX48_INV; }      \
-        y0 += a[0] * x0 + a[1] * x1 + a[2] * x2;                                      \
-        y1 += a[3] * x0 + a[4] * x1 + a[5] * x2;                                      \
-        y2 += a[6] * x0 + a[7] * x1 + a[8] * x2;                                      \
-    }
-
-template <typename VT, int DOT, int VAR>
-// lab 17 / 18: capped at 68 / 62 VGPRs for 7 / 8 waves per SIMD instead of 78 / 6: in-CG SpMV 1.071 /
-// 1.072 ms against 1.032 ms (profiles/r02/fold_ab_incg_n148_box9_register_caps.txt): more waves do not help
-__global__ void __launch_bounds__(256, (VAR == 17 ? 7 : VAR == 18 ? 8 : 1))
-k_spmv(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, const int32_t *__restrict__ rowof,
-       const int32_t *__restrict__ cols, const VT *__restrict__ vals,
-       const double *__restrict__ x, double *__restrict__ y, double *partial,
-       const int64_t *st, int64_t kiter, const int32_t *__restrict__ slist, int32_t nlist,
-       int32_t poff, fold_args fold, colstream cs) {
-    __shared__ double sh[4];
-    __shared__ int sh_last;
-    if (stopped(st, kiter)) { fold_skip(fold); return; }
-    constexpr bool NT = ((VAR & 1) != 0 && VAR < 8) || (VAR >= 9 && VAR != 13);  // 13 = 9 without the hint; 14-16 lab
-    constexpr bool XCD = (VAR & 2) != 0 && VAR < 8;
-    constexpr int UNR = (((VAR & 4) != 0 && VAR < 8) || VAR == 12) ? 4 : 2;
-    constexpr int UNR2 = 1;         // the packed-column loop handles two slots per trip (unrolling it further costs 40 VGPRs)
-    // VAR 9/10/11: XCD-chunked mapping.  Workgroups go round-robin to the 8 XCDs; here every
-    // window of 8*C consecutive workgroups is dealt so that each XCD gets C CONSECUTIVE ones
-    // (C = 32 / 8 / 128): an XCD's L2 then holds the x window of one contiguous run of rows
-    // while the chip as a whole still sweeps the matrix front to back.
-    constexpr int CH = (VAR == 9 || VAR == 12 || VAR >= 13) ? 32 :   /* 17, 18: = 9 with a register cap */ VAR == 10 ? 8 : VAR == 11 ? 128 : 0;  // 12 = 9 + unroll 4
-    const int lane = threadIdx.x & 63;
-    int64_t bid = blockIdx.x;
-    if (XCD) {
-        const int64_t g = gridDim.x, cpx = g >> 3, rem = g & 7, xcd = bid & 7;
-        bid = xcd * cpx + (xcd < rem ? xcd : rem) + (bid >> 3);
-    }
-    if (CH > 0) {
-        const int64_t win = 8 * CH, grp = bid / win, within = bid - grp * win;
-        if ((grp + 1) * win <= (int64_t)gridDim.x)   // the ragged tail keeps the identity mapping
-            bid = grp * win + (within & 7) * CH + (within >> 3);
-    }
-    int64_t slice = bid * 4 + (threadIdx.x >> 6);
-    if (slist) slice = slice < nlist ? (int64_t)slist[slice] : (int64_t)nslices;  // interior / boundary list
-    double y0 = 0, y1 = 0, y2 = 0;
-    const int64_t row = slice < nslices ? (int64_t)rowof[slice * 64 + lane] : nloc;   // SELL-C-sigma: position -> block row
-    if (slice < nslices) {
-        const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
-        const int32_t *cp = cols + (int64_t)k0 * 64 + lane;
-        const VT *vp = vals + (int64_t)k0 * vstream<VT>::STRIDE + lane;
-        const int pmode = cs.packed ? (int)cs.ok[slice] : 0;   // wave-uniform: 0 int32 columns, 1 / 2 packed (k_pack_cols)
-#ifdef STAN_LAB
-#include "lab/spmv_variants_lab.inc"   // lab-only kernel variants (VAR 8, 14-16)
-#endif
-        if (pmode != 0) {   // one loop for both packed modes: a one-base slice has cmask 0 and base2 = base
-            // two bases per slot: the lane's class picks (a select between two scalars)
-            const uint32_t *cq = cs.packed + (int64_t)cs.pair_ptr[slice] * 64 + lane;
-            const int32_t *bp = cs.base + __builtin_amdgcn_readfirstlane(k0);
-            const int32_t *bq = cs.base2 + __builtin_amdgcn_readfirstlane(k0);
-            const bool cb = (cs.cmask[slice] >> lane) & 1ull;
-            int32_t k = k0;
-#pragma unroll UNR2
-            for (; k + 1 < k1; k += 2) {
-                const uint32_t wd = ld_stream<NT>(cq);
-                const int64_t c = (int64_t)(cb ? bq[0] : bp[0]) + (int64_t)(wd & 0xffffu);
-                const int64_t c2 = (int64_t)(cb ? bq[1] : bp[1]) + (int64_t)(wd >> 16);
-                STAN_SPMV_BLOCK(c, vp)
-                STAN_SPMV_BLOCK(c2, vp + vstream<VT>::STRIDE)
-                cq += 64;
-                bp += 2;
-                bq += 2;
-                vp += 2 * vstream<VT>::STRIDE;
-            }
-            if (k < k1) {
-                const int64_t c = (int64_t)(cb ? bq[0] : bp[0]) + (int64_t)(ld_stream<NT>(cq) & 0xffffu);
-                STAN_SPMV_BLOCK(c, vp)
-            }
-        } else {
-#pragma unroll UNR
-            for (int32_t k = k0; k < k1; k++) {
-                const int64_t c = ld_stream<NT>(cp);
-                STAN_SPMV_BLOCK(c, vp)
-                cp += 64;
-                vp += vstream<VT>::STRIDE;
-            }
-        }
-        if (row < nloc) {
-#if STAN_Y_NT  // A p is read exactly once, by k_step
-            if (NT) {
-                __builtin_nontemporal_store(y0, y + 3 * row); __builtin_nontemporal_store(y1, y + 3 * row + 1);
-                __builtin_nontemporal_store(y2, y + 3 * row + 2);
-            } else
-#endif
-            { y[3 * row] = y0; y[3 * row + 1] = y1; y[3 * row + 2] = y2; }
-        }
-    }
-    if (DOT) {
-        double d = 0, e = 0;
-        if (slice < nslices && row < nloc) {
-            const double x0 = x[3 * row], x1 = x[3 * row + 1], x2 = x[3 * row + 2];
-            d = y0 * x0 + y1 * x1 + y2 * x2;
-            if (DOT == 2) e = x0 * x0 + x1 * x1 + x2 * x2;
-        }
-        const double t = block_sum(d, sh);
-        if (DOT == 2) {
-            const double u = block_sum(e, sh);
-            if (threadIdx.x == 0) {
-                st_agent(partial + 2 * (int64_t)(blockIdx.x + poff), u);
-                st_agent(partial + 2 * (int64_t)(blockIdx.x + poff) + 1, t);
-            }
-        } else if (threadIdx.x == 0) st_agent(partial + blockIdx.x + poff, t);
-        if (fold.counter && fold_arrive(fold, &sh_last)) fold_finish<(DOT == 2 ? 2 : 1)>(fold, partial, sh);
-    }
-}
-
-// ---- SpMV for SMALL systems -----------------------------------------------------------------------
-// Below ~150 k block rows the chip is not filled by one wavefront per slice (46 875 DOF: 245 slices
-// on 1024 SIMDs), and a wavefront walking its 27 slots is a chain of dependent memory round trips:
-// k_spmv takes 19 us there, two thirds of an iteration (rocprofv3, tools/small_sizes.py).  Here a
-// slice belongs to a WORKGROUP: its four wavefronts take every fourth slot, the four partial rows are
-// added through LDS in a fixed order (wave 0 + 1 + 2 + 3: deterministic; another order than k_spmv's,
-// so the choice between the two depends on the GLOBAL row count only -- every shard of a sharded
-// matrix and the unsharded matrix use the same kernel and keep producing the same bits).  Plain
-// loads: a matrix of this size stays in the L2s / the memory-side cache from one product to the next.
-template <typename VT, int DOT>
-__global__ void __launch_bounds__(256)
-k_spmv_small(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, const int32_t *__restrict__ rowof,
-             const int32_t *__restrict__ cols, const VT *__restrict__ vals,
-             const double *__restrict__ x, double *__restrict__ y, double *partial,
-             const int64_t *st, int64_t kiter, const int32_t *__restrict__ slist, int32_t nlist,
-             int32_t poff, fold_args fold, colstream cs) {
-    __shared__ double sh[4];
-    __shared__ int sh_last;
-    __shared__ double acc[3][4][64];
-    if (stopped(st, kiter)) { fold_skip(fold); return; }
-    constexpr bool NT = false;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int64_t slice = blockIdx.x;
-    if (slist) slice = slice < nlist ? (int64_t)slist[slice] : (int64_t)nslices;
-    double y0 = 0, y1 = 0, y2 = 0;
-    const int64_t row = slice < nslices ? (int64_t)rowof[slice * 64 + lane] : nloc;   // SELL-C-sigma: position -> block row
-    if (slice < nslices) {
-        const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
-        const bool packed = cs.packed && cs.ok[slice] == 1;   // (two-base slices read the int32 columns here)
-        const int64_t pp = packed ? (int64_t)cs.pair_ptr[slice] : 0;
-        for (int32_t k = k0 + w; k < k1; k += 4) {
-            int64_t c;
-            if (packed) {
-                const uint32_t wd = cs.packed[(pp + ((k - k0) >> 1)) * 64 + lane];
-                c = (int64_t)cs.base[k] + (int64_t)(((k - k0) & 1) ? (wd >> 16) : (wd & 0xffffu));
-            } else
-                c = cols[(int64_t)k * 64 + lane];
-            const VT *vp = vals + (int64_t)k * vstream<VT>::STRIDE + lane;
-            STAN_SPMV_BLOCK(c, vp)
-        }
-    }
-    acc[0][w][lane] = y0; acc[1][w][lane] = y1; acc[2][w][lane] = y2;
-    __syncthreads();
-    double d = 0, e = 0;
-    if (w == 0) {
-        y0 = ((acc[0][0][lane] + acc[0][1][lane]) + acc[0][2][lane]) + acc[0][3][lane];
-        y1 = ((acc[1][0][lane] + acc[1][1][lane]) + acc[1][2][lane]) + acc[1][3][lane];
-        y2 = ((acc[2][0][lane] + acc[2][1][lane]) + acc[2][2][lane]) + acc[2][3][lane];
-        if (slice < nslices && row < nloc) {
-            y[3 * row] = y0; y[3 * row + 1] = y1; y[3 * row + 2] = y2;
-            if (DOT) {
-                const double x0 = x[3 * row], x1 = x[3 * row + 1], x2 = x[3 * row + 2];
-                d = y0 * x0 + y1 * x1 + y2 * x2;
-                if (DOT == 2) e = x0 * x0 + x1 * x1 + x2 * x2;
-            }
-        }
-    }
-    if (DOT) {
-        const double t = block_sum(d, sh);
-        if (DOT == 2) {
-            const double u = block_sum(e, sh);
-            if (threadIdx.x == 0) {
-                st_agent(partial + 2 * (int64_t)(blockIdx.x + poff), u);
-                st_agent(partial + 2 * (int64_t)(blockIdx.x + poff) + 1, t);
-            }
-        } else if (threadIdx.x == 0) st_agent(partial + blockIdx.x + poff, t);
-        if (fold.counter && fold_arrive(fold, &sh_last)) fold_finish<(DOT == 2 ? 2 : 1)>(fold, partial, sh);
-    }
-}
-
-// Two right-hand sides in ONE pass over the matrix: y = A x and y2 = A x2 (+ the x.y partial).
-// Used on the residual-refresh iterations: r = b - A(x + a p) = b - (A x + a A p), so the
-// refresh needs A x next to the A p every iteration needs -- one matrix stream instead of two.
-// 128-VGPR budget (4 waves per SIMD): with the default target the four gathers of a trip (x and x2 of two slots) were
-// issued one by one, each behind a wait for earlier data
-template <typename VT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4)))
-k_spmv2(int32_t nslices, int64_t nloc, const int32_t *__restrict__ slot_ptr, const int32_t *__restrict__ rowof,
-        const int32_t *__restrict__ cols, const VT *__restrict__ vals,
-        const double *__restrict__ x, const double *__restrict__ x2, double *__restrict__ y,
-        double *__restrict__ y2, double *partial, const int64_t *st, int64_t kiter,
-        const int32_t *__restrict__ slist, int32_t nlist, int32_t poff, fold_args fold, colstream cs) {
-    __shared__ double sh[4];
-    __shared__ int sh_last;
-    if (stopped(st, kiter)) { fold_skip(fold); return; }
-    const int lane = threadIdx.x & 63;
-    int64_t bid = blockIdx.x;
-    {   // XCD-chunked workgroup mapping, as in k_spmv (variant 9)
-        constexpr int CH = 32;
-        const int64_t win = 8 * CH, grp = bid / win, within = bid - grp * win;
-        if ((grp + 1) * win <= (int64_t)gridDim.x) bid = grp * win + (within & 7) * CH + (within >> 3);
-    }
-    int64_t slice = bid * 4 + (threadIdx.x >> 6);
-    if (slist) slice = slice < nlist ? (int64_t)slist[slice] : (int64_t)nslices;
-    double y0 = 0, y1 = 0, yy2 = 0, z0 = 0, z1 = 0, z2 = 0;
-    const int64_t row = slice < nslices ? (int64_t)rowof[slice * 64 + lane] : nloc;   // SELL-C-sigma: position -> block row
-    if (slice < nslices) {
-        const int32_t k0 = slot_ptr[slice], k1 = slot_ptr[slice + 1];
-        const int32_t *cp = cols + (int64_t)k0 * 64 + lane;
-        const VT *vp = vals + (int64_t)k0 * vstream<VT>::STRIDE + lane;
-#define STAN_SPMV2_BLOCK(C, VP)                                                       \
-    {                                                                                 \
-        double a[9];                                                                  \
-        load9<true, VT>(VP, a);                                                       \
-        double x0 = x[3 * (C)], x1 = x[3 * (C) + 1], xx2 = x[3 * (C) + 2];            \
-        double u0 = x2[3 * (C)], u1 = x2[3 * (C) + 1], u2 = x2[3 * (C) + 2];          \
-        if (vstream<VT>::FX) {                                                        \
-            x0 *= FX48_INV; x1 *= FX48_INV; xx2 *= FX48_INV;                          \
-            u0 *= FX48_INV; u1 *= FX48_INV; u2 *= FX48_INV;                           \
-        }                                                                             \
-        y0 += a[0] * x0 + a[1] * x1 + a[2] * xx2;                                     \
-        y1 += a[3] * x0 + a[4] * x1 + a[5] * xx2;                                     \
-        yy2 += a[6] * x0 + a[7] * x1 + a[8] * xx2;                                    \
-        z0 += a[0] * u0 + a[1] * u1 + a[2] * u2;                                      \
-        z1 += a[3] * u0 + a[4] * u1 + a[5] * u2;                                      \
-        z2 += a[6] * u0 + a[7] * u1 + a[8] * u2;                                      \
-    }
-        if (cs.packed && cs.ok[slice] == 1) {   // (two-base slices read the int32 columns here)
-            const uint32_t *cq = cs.packed + (int64_t)cs.pair_ptr[slice] * 64 + lane;
-            const int32_t *bp = cs.base + __builtin_amdgcn_readfirstlane(k0);
-            int32_t k = k0;
-            for (; k + 1 < k1; k += 2) {
-                const uint32_t wd = ld_stream<true>(cq);
-                const int64_t c = (int64_t)bp[0] + (int64_t)(wd & 0xffffu);
-                const int64_t c2 = (int64_t)bp[1] + (int64_t)(wd >> 16);
-                STAN_SPMV2_BLOCK(c, vp)
-                STAN_SPMV2_BLOCK(c2, vp + vstream<VT>::STRIDE)
-                cq += 64;
-                bp += 2;
-                vp += 2 * vstream<VT>::STRIDE;
-            }
-            if (k < k1) {
-                const int64_t c = (int64_t)bp[0] + (int64_t)(ld_stream<true>(cq) & 0xffffu);
-                STAN_SPMV2_BLOCK(c, vp)
-            }
-        } else {
-#pragma unroll 2
-            for (int32_t k = k0; k < k1; k++) {
-                const int64_t c = ld_stream<true>(cp);
-                STAN_SPMV2_BLOCK(c, vp)
-                cp += 64;
-                vp += vstream<VT>::STRIDE;
-            }
-        }
-#undef STAN_SPMV2_BLOCK
-        if (row < nloc) {
-#if STAN_Y_NT  // both products are read exactly once, by k_step
-            __builtin_nontemporal_store(y0, y + 3 * row); __builtin_nontemporal_store(y1, y + 3 * row + 1);
-            __builtin_nontemporal_store(yy2, y + 3 * row + 2);
-            __builtin_nontemporal_store(z0, y2 + 3 * row); __builtin_nontemporal_store(z1, y2 + 3 * row + 1);
-            __builtin_nontemporal_store(z2, y2 + 3 * row + 2);
-#else
-            y[3 * row] = y0; y[3 * row + 1] = y1; y[3 * row + 2] = yy2;
-            y2[3 * row] = z0; y2[3 * row + 1] = z1; y2[3 * row + 2] = z2;
-#endif
-        }
-    }
-    double d = 0;
-    if (slice < nslices && row < nloc) d = y0 * x[3 * row] + y1 * x[3 * row + 1] + yy2 * x[3 * row + 2];
-    const double t = block_sum(d, sh);
-    if (threadIdx.x == 0) st_agent(partial + blockIdx.x + poff, t);
-    if (fold.counter && fold_arrive(fold, &sh_last)) fold_finish<1>(fold, partial, sh);
-}
-
-
-// ---- folded rows (STAN_OPT_ROW_FOLDING, fold.hip) ---------------------------------------------------------
-// The streams of fold.hip: padded-slot layout ([slot][ROWS][64]) with W ~ blocks/64 slots per slice; slots
-// < own[lane] hold the lane's own row, the slots behind them a piece of ONE longer row of the slice (or zeros).
-// Two accumulators per lane; the foreign ones go through LDS and each folded row adds its helpers' sums in a
-// fixed order (descending lane).  NRHS = 1: k_spmv (DOT as there); NRHS = 2: k_spmv2.
-template <typename VT, int DOT, int NRHS>
-// at most 5 waves per SIMD (96 VGPRs): with the default target of 6 (80 VGPRs) the scheduler issues the gathers of a
-// trip's second slot only after the first slot's data has arrived -- one more dependent round trip per trip
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, (NRHS == 2 ? 4 : 5))))
-k_spmv_fold(int32_t nslices, int64_t nloc, const int32_t *__restrict__ fold_ptr, const int32_t *__restrict__ rowof,
-            const uint32_t *__restrict__ meta, const int32_t *__restrict__ cols, const VT *__restrict__ vals,
-            const double *__restrict__ x, const double *__restrict__ x2, double *__restrict__ y, double *__restrict__ y2,
-            double *partial, const int64_t *st, int64_t kiter, const int32_t *__restrict__ slist, int32_t nlist,
-            int32_t poff, fold_args fold, colstream cs) {
-    __shared__ double sh[4];
-    __shared__ int sh_last;
-    __shared__ double fsh[4][3 * NRHS][64];
-    if (stopped(st, kiter)) { fold_skip(fold); return; }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int64_t bid = blockIdx.x;
-    {   // XCD-chunked workgroup mapping, as in k_spmv (variant 9)
-        constexpr int CH = 32;
-        const int64_t win = 8 * CH, grp = bid / win, within = bid - grp * win;
-        if ((grp + 1) * win <= (int64_t)gridDim.x) bid = grp * win + (within & 7) * CH + (within >> 3);
-    }
-    int64_t slice = bid * 4 + w;
-    if (slist) slice = slice < nlist ? (int64_t)slist[slice] : (int64_t)nslices;
-    double y0 = 0, y1 = 0, yy2 = 0, z0 = 0, z1 = 0, z2 = 0;     // own row
-    double f0 = 0, f1 = 0, f2 = 0, g0 = 0, g1 = 0, g2 = 0;      // the piece of a longer row this lane carries
-    const int64_t row = slice < nslices ? (int64_t)rowof[slice * 64 + lane] : nloc;
-    uint32_t m = 0;
-    if (slice < nslices) {
-        m = meta[slice * 64 + lane];
-        const int32_t own = (int32_t)(m & 0xffffu);
-        const int32_t k0 = fold_ptr[slice], k1 = fold_ptr[slice + 1];
-        const int32_t *cp = cols + (int64_t)k0 * 64 + lane;
-        const VT *vp = vals + (int64_t)k0 * vstream<VT>::STRIDE + lane;
-// LOAD then MATH for both slots of a trip: with the two accumulator sets the scheduler otherwise
-// issued the gathers of a trip's SECOND slot only after the first slot's data had arrived (one more dependent round
-// trip per trip: the folded kernel was 3-6 % slower than k_spmv at equal slot counts).
-#define STAN_FOLD_LOAD(S, C, VP)                                                                \
-        double a##S[9];                                                                         \
-        load9<true, VT>(VP, a##S);                                                              \
-        double x0##S = x[3 * (C)], x1##S = x[3 * (C) + 1], x2##S = x[3 * (C) + 2];              \
-        double u0##S = 0, u1##S = 0, u2##S = 0;                                                 \
-        if (NRHS == 2) { u0##S = x2[3 * (C)]; u1##S = x2[3 * (C) + 1]; u2##S = x2[3 * (C) + 2]; }
-#define STAN_FOLD_MATH(S, KL)                                                                   \
-    {                                                                                           \
-        if (vstream<VT>::FX) { x0##S *= FX48_INV; x1##S *= FX48_INV; x2##S *= FX48_INV; }       \
-        const double t0 = a##S[0] * x0##S + a##S[1] * x1##S + a##S[2] * x2##S;                  \
-        const double t1 = a##S[3] * x0##S + a##S[4] * x1##S + a##S[5] * x2##S;                  \
-        const double t2 = a##S[6] * x0##S + a##S[7] * x1##S + a##S[8] * x2##S;                  \
-        const bool mine = (KL) < own;                                                           \
-        y0 += mine ? t0 : 0.0; y1 += mine ? t1 : 0.0; yy2 += mine ? t2 : 0.0;                   \
-        f0 += mine ? 0.0 : t0; f1 += mine ? 0.0 : t1; f2 += mine ? 0.0 : t2;                    \
-        if (NRHS == 2) {                                                                        \
-            if (vstream<VT>::FX) { u0##S *= FX48_INV; u1##S *= FX48_INV; u2##S *= FX48_INV; }   \
-            const double s0 = a##S[0] * u0##S + a##S[1] * u1##S + a##S[2] * u2##S;              \
-            const double s1 = a##S[3] * u0##S + a##S[4] * u1##S + a##S[5] * u2##S;              \
-            const double s2 = a##S[6] * u0##S + a##S[7] * u1##S + a##S[8] * u2##S;              \
-            z0 += mine ? s0 : 0.0; z1 += mine ? s1 : 0.0; z2 += mine ? s2 : 0.0;                \
-            g0 += mine ? 0.0 : s0; g1 += mine ? 0.0 : s1; g2 += mine ? 0.0 : s2;                \
-        }                                                                                       \
-    }
-        if (cs.packed && cs.ok[slice] == 1) {   // wave-uniform: the folded copy has its own packed column stream (modes 0 / 1)
-            const uint32_t *cq = cs.packed + (int64_t)cs.pair_ptr[slice] * 64 + lane;
-            const int32_t *bp = cs.base + __builtin_amdgcn_readfirstlane(k0);
-            int32_t k = k0;
-            // the packed offsets of a trip are loaded one trip ahead: both gathers of a trip can go out with its values
-            uint32_t wd = __builtin_nontemporal_load(cq);
-            for (; k + 1 < k1; k += 2) {
-                const uint32_t wn = __builtin_nontemporal_load(k + 2 < k1 ? cq + 64 : cq);
-                const int64_t c = (int64_t)bp[0] + (int64_t)(wd & 0xffffu);
-                const int64_t c2 = (int64_t)bp[1] + (int64_t)(wd >> 16);
-                STAN_FOLD_LOAD(A, c, vp)
-                STAN_FOLD_LOAD(B, c2, vp + vstream<VT>::STRIDE)
-                STAN_FOLD_MATH(A, k - k0)
-                STAN_FOLD_MATH(B, k - k0 + 1)
-                cq += 64;
-                bp += 2;
-                vp += 2 * vstream<VT>::STRIDE;
-                wd = wn;
-            }
-            if (k < k1) {
-                const int64_t c = (int64_t)bp[0] + (int64_t)(wd & 0xffffu);
-                STAN_FOLD_LOAD(A, c, vp)
-                STAN_FOLD_MATH(A, k - k0)
-            }
-        } else {
-            int32_t k = k0;
-            for (; k + 1 < k1; k += 2) {
-                const int64_t c = __builtin_nontemporal_load(cp), c2 = __builtin_nontemporal_load(cp + 64);
-                STAN_FOLD_LOAD(A, c, vp)
-                STAN_FOLD_LOAD(B, c2, vp + vstream<VT>::STRIDE)
-                STAN_FOLD_MATH(A, k - k0)
-                STAN_FOLD_MATH(B, k - k0 + 1)
-                cp += 128;
-                vp += 2 * vstream<VT>::STRIDE;
-            }
-            if (k < k1) {
-                const int64_t c = __builtin_nontemporal_load(cp);
-                STAN_FOLD_LOAD(A, c, vp)
-                STAN_FOLD_MATH(A, k - k0)
-            }
-        }
-#undef STAN_FOLD_LOAD
-#undef STAN_FOLD_MATH
-    }
-    // The exchange is wave-local (a slice is one wavefront): the LDS executes one wave's instructions in order, so
-    // the reads below see the writes above without a workgroup barrier -- the four slices of a workgroup do not
-    // wait for each other here; a slice without folded rows skips it altogether.
-    const int nh = (int)(m >> 24);
-    if (__any(nh > 0)) {
-        fsh[w][0][lane] = f0; fsh[w][1][lane] = f1; fsh[w][2][lane] = f2;
-        if (NRHS == 2) { fsh[w][3][lane] = g0; fsh[w][4][lane] = g1; fsh[w][5][lane] = g2; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int hfirst = (int)((m >> 16) & 0xffu);
-        for (int h = 0; h < nh; h++) {   // a folded row: own part + its pieces, last lane first
-            const int j = hfirst - h;
-            y0 += fsh[w][0][j]; y1 += fsh[w][1][j]; yy2 += fsh[w][2][j];
-            if (NRHS == 2) { z0 += fsh[w][3][j]; z1 += fsh[w][4][j]; z2 += fsh[w][5][j]; }
-        }
-    }
-    if (slice < nslices) {
-        if (row < nloc) {
-#if STAN_Y_NT
-            __builtin_nontemporal_store(y0, y + 3 * row); __builtin_nontemporal_store(y1, y + 3 * row + 1);
-            __builtin_nontemporal_store(yy2, y + 3 * row + 2);
-            if (NRHS == 2) {
-                __builtin_nontemporal_store(z0, y2 + 3 * row); __builtin_nontemporal_store(z1, y2 + 3 * row + 1);
-                __builtin_nontemporal_store(z2, y2 + 3 * row + 2);
-            }
-#else
-            y[3 * row] = y0; y[3 * row + 1] = y1; y[3 * row + 2] = yy2;
-            if (NRHS == 2) { y2[3 * row] = z0; y2[3 * row + 1] = z1; y2[3 * row + 2] = z2; }
-#endif
-        }
-    }
-    if (DOT) {
-        double d = 0, e = 0;
-        if (slice < nslices && row < nloc) {
-            const double x0 = x[3 * row], x1 = x[3 * row + 1], xx2 = x[3 * row + 2];
-            d = y0 * x0 + y1 * x1 + yy2 * xx2;
-            if (DOT == 2) e = x0 * x0 + x1 * x1 + xx2 * xx2;
-        }
-        const double t = block_sum(d, sh);
-        if (DOT == 2) {
-            const double u = block_sum(e, sh);
-            if (threadIdx.x == 0) {
-                st_agent(partial + 2 * (int64_t)(blockIdx.x + poff), u);
-                st_agent(partial + 2 * (int64_t)(blockIdx.x + poff) + 1, t);
-            }
-        } else if (threadIdx.x == 0) st_agent(partial + blockIdx.x + poff, t);
-        if (fold.counter && fold_arrive(fold, &sh_last)) fold_finish<(DOT == 2 ? 2 : 1)>(fold, partial, sh);
-    }
-}
-
-// ---- CG step kernels ----------------------------------------------------------------------------
-
-struct step_args {
-    int64_t n3;           // 3 * owned block rows
-    int64_t k;            // iteration number (1-based)
-    double *sc;           // scalars
-    int64_t *st;          // status
-    const double *xcur;   // rx
-    double *xnext;        // cx
-    double *r;            // r (in), cr (out)
-    const double *p;
-    const double *v;      // A^ p
-    const double *bh;
-    double *partial;      // [blocks][2]: r2, merit
-    const double *w;      // A^ x (fused refresh)
-    int merit;            // 0: the merit-function stop is off, skip its sum (and the b^ read)
-    int refresh;          // 0: r -= a v; 1: only cx is formed here (r from a second SpMV);
-                          // 2: fused refresh, r = b^ - (w + a v) with w = A^ x from the same pass
-    int defer_x;          // 1: x' = x + a p is formed by k_update (one read of p for both updates); only
-                          //    when the merit sum is off and the iteration needs no x' before k_update
-    fold_args fold;       // r.r and the merit sum are added up by the last block (-> sc[S_R2NEW..])
-    red_src rs_vmv;       // where p.Ap is found (p2p_device.h)
-};
-
-template <bool RNT>
-__global__ void __launch_bounds__(VEC_T) k_step(step_args a) {
-    __shared__ double sh[4];
-    __shared__ int sh_last;
-    if (stopped(a.st, a.k)) { if (a.refresh != 1) fold_skip(a.fold); return; }
-    double vmv_[1];
-    red_get<1>(a.sc + S_VMV, a.rs_vmv, vmv_, sh);
-    const double vmv = vmv_[0];
-    const double rho = a.sc[S_RHO0 + (a.k & 1)];
-    int bad = 0;
-    if (!isfinite(vmv) || vmv <= 0) bad = isfinite(vmv) ? -5 : -4;
-    const double alpha = rho / vmv;
-    if (!bad && !isfinite(alpha)) bad = -4;
-    if (bad) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            a.st[T_TYPE] = bad;
-            a.st[T_ITERS] = a.k;
-            a.st[T_XSEL] = (a.k - 1) & 1;  // rx of the previous iteration
-            a.st[T_ITER_B] = a.k;
-        }
-        if (a.refresh != 1) fold_skip(a.fold);
-        return;
-    }
-    double s_r2 = 0, s_mf = 0;
-    const int64_t stride = (int64_t)gridDim.x * VEC_T;
-    for (int64_t i = (int64_t)blockIdx.x * VEC_T + threadIdx.x; i < a.n3; i += stride) {
-        double cx = 0;
-        if (!a.defer_x) {
-#if STAN_VEC_NT  // the iterate vectors pass through once per kernel: keep them out of the caches p lives in
-            const double pi = __builtin_nontemporal_load(a.p + i);
-            cx = __builtin_nontemporal_load(a.xcur + i) + alpha * pi;
-            __builtin_nontemporal_store(cx, a.xnext + i);
-#else
-            const double pi = a.p[i];
-            cx = a.xcur[i] + alpha * pi;
-            a.xnext[i] = cx;
-#endif
-        }
-        if (a.refresh == 0) {
-#if STAN_VEC_NT
-            const double cr = __builtin_nontemporal_load(a.r + i) - alpha * __builtin_nontemporal_load(a.v + i);
-#else
-            const double cr = a.r[i] - alpha * a.v[i];
-#endif
-            if (RNT) __builtin_nontemporal_store(cr, a.r + i);
-            else a.r[i] = cr;
-            s_r2 += cr * cr;
-            if (a.merit) s_mf -= (cr + a.bh[i]) * cx;
-        } else if (a.refresh == 2) {
-            const double b = a.bh[i];
-            const double mv = a.w[i] + alpha * a.v[i];  // A^ (x + a p)
-            const double cr = b - mv;
-            if (RNT) __builtin_nontemporal_store(cr, a.r + i);
-            else a.r[i] = cr;
-            s_r2 += cr * cr;
-            if (a.merit) s_mf += (mv - 2 * b) * cx;
-        }
-    }
-    if (a.refresh != 1) {
-        const double t0 = block_sum(s_r2, sh);
-        const double t1 = block_sum(s_mf, sh);
-        if (threadIdx.x == 0) {
-            st_agent(a.partial + 2 * blockIdx.x, t0);
-            st_agent(a.partial + 2 * blockIdx.x + 1, t1);
-        }
-        if (a.fold.counter && fold_arrive(a.fold, &sh_last)) fold_finish<2>(a.fold, a.partial, sh);
-    }
-}
-
-// refresh iterations: r = b^ - A^ cx, merit = sum (mv - 2 b^) cx
-__global__ void __launch_bounds__(VEC_T)
-k_refresh(int64_t n3, int64_t k, const int64_t *st, const double *bh, const double *mv,
-          const double *cx, double *r, double *partial, fold_args fold) {
-    __shared__ double sh[4];
-    __shared__ int sh_last;
-    if (st[T_ITER_A] < k || st[T_ITER_B] <= k) { fold_skip(fold); return; }
-    double s_r2 = 0, s_mf = 0;
-    const int64_t stride = (int64_t)gridDim.x * VEC_T;
-    for (int64_t i = (int64_t)blockIdx.x * VEC_T + threadIdx.x; i < n3; i += stride) {
-        const double b = bh[i], m = mv[i];
-        const double cr = b - m;
-#if STAN_R_NT
-        __builtin_nontemporal_store(cr, r + i);
-#else
-        r[i] = cr;
-#endif
-        s_r2 += cr * cr;
-        s_mf += (m - 2 * b) * cx[i];
-    }
-    const double t0 = block_sum(s_r2, sh);
-    const double t1 = block_sum(s_mf, sh);
-    if (threadIdx.x == 0) {
-        st_agent(partial + 2 * blockIdx.x, t0);
-        st_agent(partial + 2 * blockIdx.x + 1, t1);
-    }
-    if (fold.counter && fold_arrive(fold, &sh_last)) fold_finish<2>(fold, partial, sh);
-}
-
-// decisions of the iteration + p = r + beta p
-template <bool PNT>
-__global__ void __launch_bounds__(VEC_T)
-k_update(int64_t n3, int64_t k, double *sc, int64_t *st, double epsf, int64_t maxits,
-         int64_t its_before_restart, int merit_stop, const double *r, double *p,
-         const double *xcur, double *xnext /* non-null: the deferred x' = x + a p of this iteration */,
-         red_src rs_r2, red_src rs_vmv) {
-    __shared__ double sh[4];
-    if (st[T_ITER_A] < k || st[T_ITER_B] <= k) return;
-    double t2[2];
-    red_get<2>(sc + S_R2NEW, rs_r2, t2, sh);   // r.r, merit sum
-    const double r2 = t2[0], merit = t2[1];
-    const double rho = sc[S_RHO0 + (k & 1)], prevmf = sc[S_PMF0 + (k & 1)];
-    const double bnorm = sc[S_BNORM];
-    int type = 0;
-    int64_t xsel = k & 1;  // cx lives in buffer k&1
-    if (sqrt(r2) <= epsf * bnorm) type = 1;
-    else if (k >= maxits && maxits > 0) type = 5;
-    else if (merit_stop && merit >= prevmf) { type = 7; xsel = (k - 1) & 1; }
-    double beta = 0;
-    const bool restart = (k % its_before_restart) == 0;
-    if (!type && !restart) {
-        beta = r2 / rho;
-        if (!isfinite(beta)) { type = -4; }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        sc[S_R2OUT] = r2;
-        if (type) {
-            st[T_TYPE] = type;
-            st[T_ITERS] = k;
-            st[T_XSEL] = xsel;
-            st[T_ITER_A] = k;
-        } else {
-            sc[S_RHO0 + ((k + 1) & 1)] = r2;
-            sc[S_PMF0 + ((k + 1) & 1)] = merit;
-        }
-    }
-    const int64_t stride = (int64_t)gridDim.x * VEC_T;
-    // alpha of this iteration, as k_step formed it (same operands, same bits)
-    double alpha = 0.0;
-    if (xnext) {   // block-uniform
-        double v1[1];
-        red_get<1>(sc + S_VMV, rs_vmv, v1, sh);
-        alpha = rho / v1[0];
-    }
-    if (type) {
-        // the iteration that stops (types 1, 5, -4 select x' = buffer k & 1) still owes its x'
-        if (xnext && xsel == (k & 1))
-            for (int64_t i = (int64_t)blockIdx.x * VEC_T + threadIdx.x; i < n3; i += stride)
-                __builtin_nontemporal_store(__builtin_nontemporal_load(xcur + i) + alpha * __builtin_nontemporal_load(p + i), xnext + i);
-        return;
-    }
-    for (int64_t i = (int64_t)blockIdx.x * VEC_T + threadIdx.x; i < n3; i += stride)
-    {
-        // PNT: p is read, rewritten and not touched again until the next product gathers it: take it
-        // past the caches both ways (a non-temporal store to a line a plain load has just brought
-        // into L2 only dirties that line: lab modes 9-12 of tools/fold_ab.py)
-        const double po = PNT ? __builtin_nontemporal_load(p + i) : p[i];
-        const double pn = (PNT ? __builtin_nontemporal_load(r + i) : r[i]) + beta * po;
-        if (PNT) __builtin_nontemporal_store(pn, p + i);
-        else p[i] = pn;
-        if (xnext) __builtin_nontemporal_store(__builtin_nontemporal_load(xcur + i) + alpha * po, xnext + i);
-    }
-}
-
-// ---- single-reduction CG (Chronopoulos-Gear), STAN_OPT_CG_SINGLE_REDUCE --------------------------
-// Same iterates as the classic loop in exact arithmetic, ONE reduction point per iteration:
-//   w_k = A r_k,  gamma_k = r_k.r_k,  delta_k = r_k.w_k          (the SpMV, both sums in its epilogue)
-//   beta_k = gamma_k / gamma_{k-1},   p_k.A p_k = delta_k - beta_k gamma_k / alpha_{k-1},
-//   alpha_k = gamma_k / p_k.A p_k
-//   p = r + beta p,  s = w + beta s (= A p),  x' = x + alpha p,  r' = r - alpha s
-// Per iteration: this kernel + one SpMV (+ ONE all-reduce of 3 doubles when sharded) instead of
-// SpMV, all-reduce, step, all-reduce, update.  Iteration k's kernel first takes the decisions of
-// iteration k-1 (its residual norm and merit value arrived with the last reduction), with the
-// codes and the "previous point on type 7" rule of the classic loop.  Rounding differs from the
-// classic recurrences (alpha comes from a three-term formula), so iteration counts may differ by
-// a few: the default stays the classic loop, which is the oracle's.
-struct sr_args {
-    int64_t n3, k;
-    double *sc;
-    int64_t *st;
-    double epsf;
-    int64_t maxits, its_before_restart;
-    int merit_stop;
-    int refresh;          // 1: r' comes from b^ - A x' (k_refresh), only p, s, x' are formed here
-    const double *xcur;
-    double *xnext;
-    double *r, *p, *s;
-    const double *w, *bh;
-    double *partial;      // [blocks] merit partials
-    fold_args fold;       // -> sc[S_SR_MERIT]
-    red_src rs;           // where gamma, delta, merit of the last reduction are found
-};
-
-__global__ void __launch_bounds__(VEC_T) k_vec_sr(sr_args a) {
-    __shared__ double sh[4];
-    __shared__ int sh_last;
-    const int64_t k = a.k;
-    if (a.st[T_ITER_A] < k) return;   // stopped by an earlier iteration's decisions
-    double t3[3];
-    red_get<3>(a.sc + S_SR_GAMMA, a.rs, t3, sh);
-    const double gamma = t3[0], delta = t3[1], merit = t3[2];
-    const double bnorm = a.sc[S_BNORM];
-    int type = 0;
-    int64_t its = k - 1, xsel = (k - 1) & 1;
-    if (!isfinite(gamma)) type = -4;
-    else if (k > 1) {   // decisions of iteration k-1 (x_{k-1} lives in buffer (k-1)&1)
-        if (sqrt(gamma) <= a.epsf * bnorm) type = 1;
-        else if (k - 1 >= a.maxits && a.maxits > 0) type = 5;
-        else if (a.merit_stop && merit >= a.sc[S_PMF0 + ((k - 1) & 1)]) { type = 7; xsel = (k - 2) & 1; }
-    }
-    double alpha = 0, beta = 0;
-    if (!type) {
-        const bool restart = k == 1 || ((k - 1) % a.its_before_restart) == 0;
-        double pap = delta;
-        if (!restart) {
-            beta = gamma / a.sc[S_SR_GP0 + ((k - 1) & 1)];
-            pap = delta - beta * gamma / a.sc[S_SR_AP0 + ((k - 1) & 1)];
-        }
-        if (!isfinite(pap) || !isfinite(beta)) type = -4;
-        else if (pap <= 0) type = -5;
-        else { alpha = gamma / pap; if (!isfinite(alpha)) type = -4; }
-        if (type) { its = k; xsel = (k - 1) & 1; }   // as k_step: the previous point, this iteration's number
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        a.sc[S_R2OUT] = gamma;
-        if (type) {
-            a.st[T_TYPE] = type;
-            a.st[T_ITERS] = its;
-            a.st[T_XSEL] = xsel;
-            a.st[T_ITER_A] = k - 1;   // this iteration's product and everything later return at once
-        } else {
-            a.sc[S_SR_GP0 + (k & 1)] = gamma;
-            a.sc[S_SR_AP0 + (k & 1)] = alpha;
-            a.sc[S_PMF0 + (k & 1)] = merit;
-        }
-    }
-    if (type) return;
-    double s_mf = 0;
-    const int64_t stride = (int64_t)gridDim.x * VEC_T;
-    for (int64_t i = (int64_t)blockIdx.x * VEC_T + threadIdx.x; i < a.n3; i += stride) {
-        const double ri = a.r[i];
-        const double pi = ri + beta * a.p[i];
-        const double si = __builtin_nontemporal_load(a.w + i) + beta * a.s[i];
-        const double cx = __builtin_nontemporal_load(a.xcur + i) + alpha * pi;
-        __builtin_nontemporal_store(pi, a.p + i);
-        __builtin_nontemporal_store(si, a.s + i);
-        __builtin_nontemporal_store(cx, a.xnext + i);
-        if (!a.refresh) {
-            const double cr = ri - alpha * si;
-            __builtin_nontemporal_store(cr, a.r + i);   // gathered by the product that follows (see STAN_P_NT)
-            if (a.merit_stop) s_mf -= (cr + a.bh[i]) * cx;
-        }
-    }
-    if (!a.refresh) {
-        const double t = block_sum(s_mf, sh);
-        if (threadIdx.x == 0) st_agent(a.partial + blockIdx.x, t);
-        if (a.fold.counter && fold_arrive(a.fold, &sh_last)) fold_finish<1>(a.fold, a.partial, sh);
-    }
-}
-
-// U[d - red[d]] = s_d * x^_d on free DOFs (SolverFunctions.cs:305 lincgresults + un-scaling)
-__global__ void k_result(int64_t n3, int64_t dof0, const int32_t *red, const double *s,
-                         const double *x, double *U) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += stride) {
-        const int32_t rd = red[dof0 + i];
-        if (rd != -1) U[dof0 + i - rd] = s[i] * x[i];
-    }
-}
-// multi-rank: scaled solution into the global block vector, compressed after the all-gather
-__global__ void k_result_full(int64_t n3, const double *s, const double *x, double *full) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += stride)
-        full[i] = s[i] * x[i];
-}
-__global__ void k_compress(int64_t n_dof, const int32_t *red, const double *full, double *U) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_dof; i += stride) {
-        const int32_t rd = red[i];
-        if (rd != -1) U[i - rd] = full[i];
-    }
-}
-// reduced host-order vector <-> full local vector (for stan_hip_spmv)
-__global__ void k_expand(int64_t n3, int64_t dof0, const int32_t *red, const double *in,
-                         const double *div, double *out) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += stride) {
-        const int32_t rd = red[dof0 + i];
-        double v = rd == -1 ? 0.0 : in[dof0 + i - rd];
-        if (div) v /= div[i];
-        out[i] = v;
-    }
-}
-__global__ void k_compress_div(int64_t n3, const int32_t *red, const double *s, const double *y,
-                               double *out) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += stride) {
-        const int32_t rd = red[i];
-        if (rd != -1) out[i - rd] = s ? y[i] / s[i] : y[i];
-    }
-}
-__global__ void k_fill(double *p, int64_t n, double v) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
-}
+#include "cg_vector_kernels.inc"   // the vector kernels of the CG loop: k_step, k_refresh, k_update, k_vec_sr (single-reduction form), result / expand / compress
 
 inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
 inline unsigned vec_grid(int64_t n) {
