@@ -88,7 +88,28 @@ int64_t stan_hip_last_bad_element(stan_ctx *ctx);
 /* Use an existing hipStream_t (e.g. torch's current stream) for all work; NULL = own stream. */
 int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
 
-/* Solver options (defaults reproduce alglib.lincg as the reference uses it).
+/* Solver options (defaults reproduce alglib.lincg as the reference uses it).  The numbers are ABI and stay as they were
+ * handed out over the rounds; in numerical order:
+ *    1 STAN_OPT_CG_MERIT_STOP        1     alglib's merit-function stop (termination type 7)
+ *    2 STAN_OPT_CG_RUPDATE           10    residual recomputed every n iterations (ItsBeforeRUpdate)
+ *    3 STAN_OPT_SPMV_VARIANT         -1    SpMV kernel variant (auto)
+ *    4 STAN_OPT_OVERLAP_HALO         1     sharded SpMV: interior slices behind the halo exchange
+ *    5 STAN_OPT_ASSEMBLY_MODE        0     0 row-owner gather, 1 element wave + colour scatter
+ *    6 STAN_OPT_CG_FUSED_REFRESH     1     A x and A p from one matrix pass on refresh iterations
+ *    7 STAN_OPT_POOL                 1     freed device blocks stay with the context
+ *    8 STAN_OPT_PLACEMENT_TRIES      16    allocation of K's values by search (1 = plain)
+ *    9 STAN_OPT_POOL_MAX_BYTES       half the device   byte budget of the parked blocks
+ *   10 STAN_OPT_CG_SINGLE_REDUCE     0     Chronopoulos-Gear loop (one reduction point per iteration)
+ *   11 STAN_OPT_CG_FOLD_REDUCE       1     reductions finished by the producing kernel's last block
+ *   12 STAN_OPT_VEC_STORE_NT         3     non-temporal stores of p (bit 0) and r (bit 1)
+ *   13 STAN_OPT_PACKED_COLUMNS       1     16-bit column offsets from per-slot bases
+ *   14 STAN_OPT_CG_DEFER_X           1     x' formed next to p' when the merit stop is off
+ *   15 STAN_OPT_SPMV_SMALL           1     one workgroup per slice below 150 000 block rows
+ *   16 STAN_OPT_PLACEMENT_MAX_BYTES  0     byte budget of the placement search (0 = a quarter of free memory)
+ *   17 STAN_OPT_SELL_SIGMA           1     SELL-C-sigma sorting window in slices
+ *   18 STAN_OPT_COMM_P2P             0     sharded CG exchanges peer to peer instead of over RCCL
+ *   19 STAN_OPT_ROW_FOLDING          -1    folded rows on irregular meshes (auto)
+ * The descriptions follow in the order the options were added.
  *   STAN_OPT_CG_MERIT_STOP  1 (default): stop with type 7 when the merit function x'Ax-2b'x
  *                           no longer decreases (rounding floor, ~1e-7 relative residual on
  *                           large meshes); 0: iterate until eps_f / max_its only.
