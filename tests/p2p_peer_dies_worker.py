@@ -22,12 +22,12 @@ dist.broadcast_object_list(box, 0)
 ctx.comm_init(rank, world, box[0])
 ctx.set_option(hip.OPT_COMM_P2P, 1)        # broadcast group 1: the ranks' mailbox handles
 K = ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
-U, rep = K.cg_solve(job.F, 1e-6)           # group 2: the vectors of solve 1; both ranks finish it
+U, rep = K.cg_solve(job.F, 1e-6)           # group 2: the vectors of solve 1; group 3: its result rows; both ranks finish it
 assert rep["terminationtype"] in (1, 7), rep
 print("rank %d: first solve done (%d its)" % (rank, rep["iterations"]), flush=True)
 t0 = time.time()
 try:
-    K.cg_solve(job.F, 1e-6)                # group 3: rank 1 publishes and is gone
+    K.cg_solve(job.F, 1e-6)                # group 4: rank 1 publishes its vectors and is gone
     print("rank %d: SECOND SOLVE RETURNED NORMALLY" % rank, flush=True)
     os._exit(7)
 except hip.StanHipError as e:

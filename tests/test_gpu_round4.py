@@ -53,10 +53,13 @@ def test_wedge_collapsed_hex(gpu_ctx, oracle, mode):
     """A hex that lists a node twice (CHEXA wedge: node 4 := node 1, node 8 := node 5) in the middle of a 3^3 cube and
     on its corner: k_numeric's duplicate-node branch (assembly.hip) and k_scatter's (assembly_scatter.hip), which no
     GPU test fed before.  The reference accepts such elements (Node.cs:202-205)."""
+    from stan_amd.cube import cube_bcs
     xyz, conn = cube_mesh(3, jitter=0.05)
     for e in (13, 0, 26):
         conn[e, 3], conn[e, 7] = conn[e, 0], conn[e, 4]
-    info, _ = _check_against_oracle(gpu_ctx, oracle, _job(xyz, conn), mode)
+    spc, ld, f = cube_bcs(3)                 # (from the grid indices: the jittered coordinates have no exact planes)
+    job = problem.make_job(xyz, conn, spc, np.ones((len(spc), 3)), ld, np.tile(f, (len(ld), 1)))
+    info, _ = _check_against_oracle(gpu_ctx, oracle, job, mode)
     assert info["n_blocks"] > 0
 
 

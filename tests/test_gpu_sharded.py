@@ -237,9 +237,9 @@ def test_peer_to_peer_survivor_releases_itself_when_its_peer_dies(built_libs):
     import time
     t0 = time.time()
     out = _torchrun(2, [os.path.join(ROOT, "tests", "p2p_peer_dies_worker.py")],
-                    {"STAN_P2P_STALL_S": "4", "FAKE_RCCL_EXIT_AFTER_BCAST_GROUPS": "1:3"})
+                    {"STAN_P2P_STALL_S": "4", "FAKE_RCCL_EXIT_AFTER_BCAST_GROUPS": "1:4"})
     took = time.time() - t0
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "SURVIVOR code -7" in out.stdout and "released" in out.stdout, out.stdout[-2000:]
-    assert "leaves after broadcast group 3" in out.stderr
+    assert "leaves after broadcast group 4" in out.stderr
     assert took < 120, took
