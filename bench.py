@@ -630,8 +630,8 @@ def main():
                        "termination_type": rep["terminationtype"],
                        "rel_residual": rep["rel_residual"], "converged": bool(ok),
                        "assemble_ms": asm_ms / args.steps, "cg_ms": cg_ms / args.steps,
-                       "matrix_format": "BSELL-64 3x3 blocks (%s values + block cols as 16-bit offsets from a "
-                                        "per-slot base in %.1f %% of the slots, int32 in the rest)" %
+                       "matrix_format": "BSELL-64 3x3 blocks (%s values + block cols as 16-bit offsets from per-slot "
+                                        "bases -- one, or two where a slice mixes row lengths -- in %.1f %% of the slots, int32 in the rest)" %
                                         ("fp32" if args.mixed else "48-bit fixed-point" if args.fixed48
                                          else "fp64", 100.0 * prof["col_slots_packed"] / max(info["n_slots"], 1)),
                        # SELL-C-sigma: slots streamed per structural block - 1 (padded slots are streamed like real ones)

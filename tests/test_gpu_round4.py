@@ -306,3 +306,26 @@ def test_config5_at_size_400_cubed(gpu_ctx, oracle):
     assert np.isfinite(r_true) and r_true <= 1e-2
     assert 2000 <= rep["iterations"] <= 6000
     K.free()
+
+
+def test_row_folding_always_reexamines_a_matrix_the_auto_rule_declined(gpu_ctx):
+    """auto mode declines the cube (the plan saves nothing) and used to leave the matrix marked for
+    good; STAN_OPT_ROW_FOLDING = 1 ("always") set afterwards must build the folded streams for that same matrix."""
+    from stan_amd import hip
+    job = problem.cube_job(20, jitter=0.05)
+    gpu_ctx.set_option(hip.OPT_SPMV_SMALL, 0)          # (small systems never fold: take the large-system kernels)
+    gpu_ctx.set_profiling(True)
+    try:
+        K = gpu_ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+        U0, rep0 = K.cg_solve(job.F, 1e-10)
+        assert gpu_ctx.profile()["repacked_streams"] == 0
+        gpu_ctx.set_option(hip.OPT_ROW_FOLDING, 1)
+        U1, rep1 = K.cg_solve(job.F, 1e-10)
+        assert gpu_ctx.profile()["repacked_streams"] == 1 and K.info()["folded_slots_permille"] > 0
+        assert rep0["terminationtype"] == rep1["terminationtype"] and abs(rep0["iterations"] - rep1["iterations"]) <= 2
+        assert np.abs(U1 - U0).max() <= 1e-8 * np.abs(U0).max()
+        K.free()
+    finally:
+        gpu_ctx.set_option(hip.OPT_ROW_FOLDING, -1)
+        gpu_ctx.set_option(hip.OPT_SPMV_SMALL, 1)
+        gpu_ctx.set_profiling(False)
