@@ -595,6 +595,10 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     const bool p2p = dist && ctx->comm_p2p && ctx->p2p != nullptr;
     // no hipFree while the peers' streams wait for this rank's future exchanges (stan_ctx::defer_frees)
     struct free_later { stan_ctx *c; bool on; ~free_later() { if (on) { stan_flush_deferred(c); stan_p2p_ipc_trim(c); } } } free_guard{ctx, p2p};
+    if (p2p && ctx->p2p->broken.load()) {   // refused at once: not another collective with a peer that is gone
+        ctx->err = "cg: the peer-to-peer exchange of this context is broken (a peer rank failed earlier); start a fresh process";
+        return STAN_E_COMM;
+    }
     if (p2p) ctx->defer_frees = true;
     STANCHK(stan_cg_workspace(ctx, K));   // the context's vectors (the placement search probed with them)
     if (p2p) {
