@@ -745,181 +745,6 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
     }
 }
 
-// ---- step 3, register form (round 4, STAN_NUMERIC_VARIANT=1): the same arithmetic with NO accumulator in LDS.  k_numeric keeps
-// acc[16 rows][W][9] (31 KB at W = 27) only to turn 16 rows into full 128-B lines at the end; that buffer is what holds a CU
-// to two workgroups (2 waves per SIMD), and the kernel's phases are chains of dependent LDS / memory round trips that
-// nothing hides at that occupancy.  Here lane k of the wave that owns a row keeps slot k's block in registers over the
-// row's incidence chunks (a slice of up to 64 slots: one per lane), applies the BCs there and stores its nine values
-// itself -- 8-byte stores 4.6 KB apart, merged into lines by the write-back L2 (the other 15 rows of a line are written
-// by this workgroup within microseconds).  LDS: 7.4 KB per wave (Gauss-point scratch, coordinates / slot map, the
-// row's columns) -> 4 waves per SIMD with the 128-VGPR budget.  Same summation order as k_numeric's gather form.
-template <int WV>
-__global__ void __launch_bounds__(256, WV) k_numeric_reg(numeric_args A) {
-    extern __shared__ double lds[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    double *gpw = lds + w * 928;                 // [8 gp][8 inc][10] = 640 doubles; aliased: stage [64][9] = 576
-    double *xsw = gpw + 640;                     // [8 inc][8 nodes][3] = 192 doubles; aliased: map [8][64] int32 = 256 doubles
-    int32_t *colsl = (int32_t *)(xsw + 256);     // [64] global block column of slot k (ascending along the row)
-    const int64_t bid = STAN_NUM_CH > 0 ? xcd_chunked(blockIdx.x, gridDim.x, STAN_NUM_CH) : (int64_t)blockIdx.x;
-    const int64_t slice = bid >> 2;
-    const int q = (int)(bid & 3);
-    const int32_t k0 = A.slot_ptr[slice];
-    const int sw = A.slot_ptr[slice + 1] - k0;
-    if (sw > 64) return;   // k_numeric_wide (workgroup-uniform)
-    const int s = lane >> 3, b = lane & 7;
-    // the chain row -> incidences -> connectivity -> coordinates of the NEXT row is issued before the current row is
-    // computed (first 8 incidences; longer rows load the rest inline): one set of registers, rotated
-    struct chain { int64_t row, p0; int deg, rl; int32_t en, colg, ty, mi; double x0, x1, x2; };
-    auto load_chain = [&](int i) {
-        chain c;
-        c.row = i < 4 ? (int64_t)A.rowof[slice * 64 + q * 16 + w * 4 + i] : A.nloc;
-        c.p0 = 0; c.deg = 0; c.rl = 0; c.en = 0; c.colg = 0; c.ty = STAN_HEX8_G2; c.mi = 0; c.x0 = c.x1 = c.x2 = 0.0;
-        if (c.row < A.nloc) {
-            c.p0 = A.ptr[c.row];
-            c.deg = (int)(A.ptr[c.row + 1] - c.p0);
-            c.rl = A.rowlen[c.row];
-            if (s < c.deg) {
-                c.en = A.list[c.p0 + s];
-                const int32_t e = c.en >> 3;
-                c.colg = A.crow[(int64_t)e * 8 + b];
-                c.ty = A.elem_type[e];
-                c.mi = A.elem_mat[e];
-                c.x0 = A.xrow[3 * (int64_t)c.colg + 0];
-                c.x1 = A.xrow[3 * (int64_t)c.colg + 1];
-                c.x2 = A.xrow[3 * (int64_t)c.colg + 2];
-            }
-        }
-        return c;
-    };
-    chain nxt = load_chain(0);
-#define STAN_WAVE_SYNC()                                        \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      \
-    __builtin_amdgcn_wave_barrier();                            \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 1
-    for (int i = 0; i < 4; i++) {
-        const chain cur = nxt;
-        nxt = load_chain(i + 1);
-        const int64_t row = cur.row;
-        const int pos_in_slice = q * 16 + w * 4 + i;
-        double *vout = A.vals + (int64_t)k0 * 9 * 64 + pos_in_slice;   // entry (k, comp): vout[(k * 9 + comp) * 64]
-        const int rl = cur.rl, deg = cur.deg;
-        int32_t gk = 0;
-        int cf = 0;
-        if (row < A.nloc && lane < rl) {
-            const int32_t lc = A.cols[((int64_t)k0 + lane) * 64 + pos_in_slice];
-            gk = lc < A.nloc ? (int32_t)(A.r0 + lc) : A.halo_glob[lc - A.nloc];
-            cf = A.fixmask[gk];
-        }
-        colsl[lane] = gk;
-        double t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        const int64_t p0 = cur.p0;
-        for (int c0 = 0; c0 < deg; c0 += 8) {
-            const bool valid = c0 + s < deg;
-            int32_t e = 0, a = 0, type = STAN_HEX8_G2, colg = 0;
-            double lam = 0, G = 0;
-            STAN_WAVE_SYNC()   // the slot map of the previous chunk / row (aliased with xsw) has been read
-            if (valid) {
-                int32_t en, m;
-                double x0, x1, x2;
-                if (c0 == 0) {
-                    en = cur.en; colg = cur.colg; type = cur.ty; m = cur.mi;
-                    x0 = cur.x0; x1 = cur.x1; x2 = cur.x2;
-                } else {
-                    en = A.list[p0 + c0 + s];
-                    colg = A.crow[(int64_t)(en >> 3) * 8 + b];
-                    type = A.elem_type[en >> 3];
-                    m = A.elem_mat[en >> 3];
-                    x0 = A.xrow[3 * (int64_t)colg + 0];
-                    x1 = A.xrow[3 * (int64_t)colg + 1];
-                    x2 = A.xrow[3 * (int64_t)colg + 2];
-                }
-                e = en >> 3;
-                a = en & 7;
-                lam = A.mat_lamG[2 * m];
-                G = A.mat_lamG[2 * m + 1];
-                xsw[(s * 8 + b) * 3 + 0] = x0;
-                xsw[(s * 8 + b) * 3 + 1] = x1;
-                xsw[(s * 8 + b) * 3 + 2] = x2;
-            }
-            STAN_WAVE_SYNC()
-            if (valid) {   // phase A: this lane = Gauss point b of incidence s
-                double o[10];
-                const double det = hex8_gp_setup(xsw + s * 24, type, b, o);
-                if (det == 0.0 && hex8_gauss_weight(type, b) != 0.0) atomicMin(A.bad_elem, (long long)e);
-#pragma unroll
-                for (int j = 0; j < 10; j++) gpw[(b * 8 + s) * 10 + j] = o[j];
-            }
-            STAN_WAVE_SYNC()
-            double kb[9];
-            int pos = -1;
-            if (valid) {   // phase B: block (a, b) of element e; phase C: its slot (binary search over the ascending columns)
-                hex8_block_ab(gpw + s * 10, 8 * 10, type, a, b, lam, G, kb);
-                int lo = 0, hi = rl;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (colsl[mid] < colg) lo = mid + 1; else hi = mid;
-                }
-                pos = (lo < rl && colsl[lo] == colg) ? lo : -1;
-            }
-            int isdup = 0;
-#pragma unroll
-            for (int j = 0; j < 7; j++) {
-                const int pj = __shfl(pos, (lane & ~7) | j, 64);
-                if (j < b && pj == pos && pos >= 0) isdup = 1;
-            }
-            const bool anydup = __ballot(isdup) != 0ull;
-            STAN_WAVE_SYNC()   // every lane has read the Gauss-point scratch: it becomes the staging area
-            double *stage = gpw;               // [64 lanes][9]
-            int32_t *map = (int32_t *)xsw;     // [8 incidences][64 slots] -> lane, or (a chunk with a duplicate node) [64] slot of lane l
-#pragma unroll
-            for (int j = 0; j < 9; j++) stage[lane * 9 + j] = valid ? kb[j] : 0.0;
-            if (!anydup) {
-                for (int u = lane; u < 8 * 64; u += 64) map[u] = -1;
-                STAN_WAVE_SYNC()
-                if (pos >= 0) map[s * 64 + pos] = lane;
-                STAN_WAVE_SYNC()
-                if (lane < rl) {   // phase D: slot `lane` summed over the chunk's incidences in ascending order, then added to the row's
-                    double t9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                    for (int s2 = 0; s2 < 8; s2++) {
-                        const int32_t l = map[s2 * 64 + lane];
-                        if (l >= 0) {
-#pragma unroll
-                            for (int j = 0; j < 9; j++) t9[j] += stage[l * 9 + j];
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 9; j++) t[j] += t9[j];
-                }
-            } else {   // a degenerate element lists a node twice: two lanes of one incidence hit one slot -- strictly in order
-                map[lane] = pos;
-                STAN_WAVE_SYNC()
-                for (int l = 0; l < 64; l++) {
-                    if (map[l] == lane) {
-#pragma unroll
-                        for (int j = 0; j < 9; j++) t[j] += stage[l * 9 + j];
-                    }
-                }
-            }
-        }
-        // essential BCs in registers, then this lane's nine values (slots beyond the row's length: zeros)
-        if (lane < sw) {
-            const int rfix = row < A.nloc ? A.fixmask[A.r0 + row] : 0;
-            const int32_t grow = (int32_t)(A.r0 + row);
-#pragma unroll
-            for (int m = 0; m < 3; m++)
-#pragma unroll
-                for (int n = 0; n < 3; n++) {
-                    double v = (row < A.nloc && lane < rl) ? t[3 * m + n] : 0.0;
-                    if (row < A.nloc && lane < rl && (((rfix >> m) & 1) || ((cf >> n) & 1))) v = (gk == grow && m == n) ? 1.0 : 0.0;
-                    vout[(int64_t)(lane * 9 + 3 * m + n) * 64] = v;
-                }
-        }
-    }
-#undef STAN_WAVE_SYNC
-}
-
 // ---- step 3, wide slices.  A slice that holds a row of more than STAN_MAX_ROW_BLOCKS blocks (a high-valence node: the
 // axis of a revolved mesh, the centre of a fan) does not fit the LDS accumulators above.  Slow path, one WAVEFRONT per
 // row of such a slice, accumulating straight in K's values: slot k of the row belongs to lane k % 64, which zeroes it,
@@ -1325,25 +1150,11 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         if (lds > 64 * 1024)
             HIPCHK(ctx, hipFuncSetAttribute((const void *)k_numeric,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        static const int variant = getenv("STAN_NUMERIC_VARIANT") ? atoi(getenv("STAN_NUMERIC_VARIANT")) : 0;
-        if (variant >= 1 && variant <= 3 && K->nslices > 0) {   // register form: slices of up to 64 slots, the rest to k_numeric_wide
-            const int32_t wfull = K->max_row_blocks > 0 ? K->max_row_blocks : 1;
-            A.wmax = wfull < 64 ? wfull : 64;
-            // 1 / 2 / 3: register budget for 4 / 3 / 2 waves per SIMD (128 with ~200 B of scratch per lane / 168 / 228 VGPRs)
-            if (variant == 1) hipLaunchKernelGGL(k_numeric_reg<4>, dim3((unsigned)K->nslices * 4), dim3(256), (size_t)4 * 928 * 8, st, A);
-            else if (variant == 2) hipLaunchKernelGGL(k_numeric_reg<3>, dim3((unsigned)K->nslices * 4), dim3(256), (size_t)4 * 928 * 8, st, A);
-            else hipLaunchKernelGGL(k_numeric_reg<2>, dim3((unsigned)K->nslices * 4), dim3(256), (size_t)4 * 928 * 8, st, A);
-            if (wfull > 64) {
-                if ((int64_t)K->nslices * 64 >= (int64_t)1 << 31) { ctx->err = "assemble: too many slices for the wide-row kernel's grid"; return STAN_E_ARG; }
-                hipLaunchKernelGGL(k_numeric_wide, dim3((unsigned)K->nslices * 64), dim3(64), 0, st, A);
-            }
-        } else {
         if (K->nslices > 0)
             hipLaunchKernelGGL(k_numeric, dim3((unsigned)K->nslices * 4), dim3(256), lds, st, A);
         if (wide) {
             if ((int64_t)K->nslices * 64 >= (int64_t)1 << 31) { ctx->err = "assemble: too many slices for the wide-row kernel's grid"; return STAN_E_ARG; }
             hipLaunchKernelGGL(k_numeric_wide, dim3((unsigned)K->nslices * 64), dim3(64), 0, st, A);
-        }
         }
     }
     HIPCHK(ctx, hipGetLastError());
