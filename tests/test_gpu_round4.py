@@ -329,3 +329,40 @@ def test_row_folding_always_reexamines_a_matrix_the_auto_rule_declined(gpu_ctx):
         gpu_ctx.set_option(hip.OPT_ROW_FOLDING, -1)
         gpu_ctx.set_option(hip.OPT_SPMV_SMALL, 1)
         gpu_ctx.set_profiling(False)
+
+
+def test_console_driver_on_a_revolved_mesh(built_libs, oracle, tmp_path):
+    """The whole console path (Solver.Main: STdb -> AssignDOF -> BC tables -> assembly -> CG -> stress recovery -> STdb) on
+    a mesh with collapsed hexes and a high-valence axis: 36 sectors = 144 incidences at an axis node (the slow symbolic
+    path) and a 111-block row (the wide numeric path); nodal displacements against a direct solve of the oracle's K."""
+    import subprocess
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    from stan_amd import host
+    xyz, conn = revolved_mesh(36, 2, 3)
+    d = host.Db()
+    ne = conn.shape[0]
+    d.set_mesh(np.arange(1, xyz.shape[0] + 1), xyz, np.arange(1, ne + 1), np.ones(ne), conn + 1, "HEX8_G2")
+    d.add_material(1, "Steel", 210000.0, 0.3)
+    d.assign_part(1, 1, "HEX8_G2")
+    z0 = np.nonzero(xyz[:, 2] == 0)[0]
+    top = np.nonzero(xyz[:, 2] == xyz[:, 2].max())[0]
+    d.add_bc(1, "fix", "SPC", z0 + 1, np.ones((len(z0), 3)))
+    d.add_bc(2, "load", "PointLoad", top + 1, np.tile([0.0, 10.0, 5.0], (len(top), 1)))
+    d.set_analysis(lin_solver="CG", tol=1e-10)
+    path = str(tmp_path / "revolved.STdb")
+    d.write_stdb(path)
+    exe = os.path.join(ROOT, "stan_amd", "bin", "stan_solver")
+    out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    r = host.Db.read_stdb(path)
+    assert r.sizes()["result_step"] == 1
+    disp = r.results(1)[0]
+    m = host.Db.read_stdb(path); m.assign_dof()
+    fl = m.flat(); red, nfix, F = m.reduction()
+    rc, A = oracle.assemble(fl["xyz"], fl["node_dof"], fl["conn"], fl["elem_mat"], fl["elem_type"], fl["mat_E_nu"], red)
+    assert rc == 0
+    Uu = sp.csr_matrix((A.vals, A.idx, A.ridx), shape=(A.n, A.n))
+    want = spl.spsolve((Uu + sp.triu(Uu, 1).T).tocsc(), F)
+    do = host.nodal_displacements(fl["node_dof"], red, want)
+    assert np.abs(disp - do).max() <= 1e-5 * np.abs(do).max()      # the CG stops by its merit rule (type 7) near 1e-7
