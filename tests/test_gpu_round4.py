@@ -314,6 +314,7 @@ def test_row_folding_always_reexamines_a_matrix_the_auto_rule_declined(gpu_ctx):
     from stan_amd import hip
     job = problem.cube_job(20, jitter=0.05)
     gpu_ctx.set_option(hip.OPT_SPMV_SMALL, 0)          # (small systems never fold: take the large-system kernels)
+    gpu_ctx.set_option(hip.OPT_CG_MERIT_STOP, 0)       # (the type-7 stop lands wherever rounding lets the merit tick up)
     gpu_ctx.set_profiling(True)
     try:
         K = gpu_ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
@@ -328,6 +329,7 @@ def test_row_folding_always_reexamines_a_matrix_the_auto_rule_declined(gpu_ctx):
     finally:
         gpu_ctx.set_option(hip.OPT_ROW_FOLDING, -1)
         gpu_ctx.set_option(hip.OPT_SPMV_SMALL, 1)
+        gpu_ctx.set_option(hip.OPT_CG_MERIT_STOP, 1)
         gpu_ctx.set_profiling(False)
 
 
