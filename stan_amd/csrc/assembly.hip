@@ -219,17 +219,15 @@ __device__ inline void wg_bitonic_sort(int32_t *a, int P) {
     }
 }
 __global__ void __launch_bounds__(256)
-k_symbolic_big(int64_t nloc, int64_t r0, int64_t r1, const int64_t *ptr, int32_t *list, const int32_t *crow,
+k_symbolic_big(const int32_t *big_rows, int64_t r0, int64_t r1, const int64_t *ptr, int32_t *list, const int32_t *crow,
                int32_t *rowlen, int32_t *refflag, int32_t *ucols, int lds_ints, int32_t *scratch, int64_t scratch_ints_per_row,
                unsigned long long *ticket) {
     extern __shared__ int32_t big_lds[];
     __shared__ int32_t *sh_buf;
     __shared__ int sh_base;
-    const int64_t row = blockIdx.x;
-    if (row >= nloc) return;
+    const int64_t row = big_rows[blockIdx.x];   // the rows k_symbolic left out, in no particular order (k_list_big_rows)
     const int64_t p0 = ptr[row];
     const int64_t deg = ptr[row + 1] - p0;
-    if (deg <= STAN_MAX_INCIDENT) return;   // k_symbolic did this row
     int64_t PD = 64, PC = 64;
     while (PD < deg) PD <<= 1;
     while (PC < 8 * deg) PC <<= 1;
@@ -287,11 +285,17 @@ __global__ void k_max_incident(int64_t nrows, const int32_t *cnt, int lds_ints, 
     int m = v;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
-    const unsigned long long g = __ballot(giant);
+    const unsigned long long g = __ballot(giant), bg = __ballot(v > STAN_MAX_INCIDENT);
     if ((threadIdx.x & 63) == 0) {
         if (m > STAN_MAX_INCIDENT) atomicMax((long long *)&status[SS_MAXDEG], (long long)m);
         if (g) atomicAdd((unsigned long long *)&status[SS_NGIANT], (unsigned long long)__popcll(g));
+        if (bg) atomicAdd((unsigned long long *)&status[SS_NBIG], (unsigned long long)__popcll(bg));
     }
+}
+// out[0 .. *counter) = the indices i with v[i] > thresh (any order: every entry is handled on its own)
+__global__ void k_list_above(int64_t n, const int32_t *v, int thresh, int32_t *out, unsigned long long *counter) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && v[i] > thresh) out[atomicAdd(counter, 1ULL)] = (int32_t)i;
 }
 
 // ---- step 2b: SELL-C-sigma.  Rows sorted by length (descending, stable) inside windows of sigma
@@ -470,6 +474,7 @@ struct numeric_args {
     double *vals;
     long long *bad_elem;  // min element index with det J == 0, else LLONG_MAX
     int32_t wmax;         // LDS accumulators are sized for this slice width
+    const int32_t *wide_slices;   // k_numeric_wide: the slices wider than wmax
 };
 
 // two waves per SIMD (<= 128 VGPRs): measured 23.6 ms vs 39.7 ms at 148^3 (tools/asm_lab.sh)
@@ -756,11 +761,10 @@ __global__ void __launch_bounds__(64) k_numeric_wide(numeric_args A) {
     __shared__ double stage[64 * 9];
     __shared__ int32_t posl[64];
     const int lane = threadIdx.x;
-    const int64_t slice = blockIdx.x >> 6;
+    const int64_t slice = A.wide_slices[blockIdx.x >> 6];   // the slices k_numeric left out (k_list_above over the widths)
     const int r = blockIdx.x & 63;
     const int32_t k0 = A.slot_ptr[slice];
     const int sw = A.slot_ptr[slice + 1] - k0;
-    if (sw <= A.wmax) return;   // k_numeric did this slice
     const int64_t row = A.rowof[slice * 64 + r];
     double *vrow = A.vals + (int64_t)k0 * 9 * 64 + r;          // entry (k, comp) of this row: vrow[(k * 9 + comp) * 64]
     const int32_t *crow_cols = A.cols + (int64_t)k0 * 64 + r;  // local column of slot k: crow_cols[k * 64]
@@ -1010,6 +1014,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
 
     // incidence lists of owned rows
     int32_t *d_cnt; STANCHK(stan_dmalloc(ctx, &d_cnt, (size_t)nrows_pad + 1)); tmp.own(d_cnt);
+    int32_t *d_big_rows = nullptr;   // rows with more than STAN_MAX_INCIDENT incidences (listed before d_cnt becomes the fill cursor)
     int64_t *d_ptr; STANCHK(stan_dmalloc(ctx, &d_ptr, (size_t)nrows_pad + 2)); tmp.own(d_ptr);
     HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, ((size_t)nrows_pad + 1) * 4, st));
     if (n_elem > 0)
@@ -1021,7 +1026,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     STANCHK(stan_scan_exclusive(ctx, d_cnt, d_ptr, nrows_pad));
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_ERRBITS, d_status + SS_ERRBITS, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_H_NINC, d_ptr + nrows_pad, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_MAXDEG, d_status + SS_MAXDEG, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_MAXDEG, d_status + SS_MAXDEG, 24, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     if (ctx->h_status[SS_ERRBITS] & ERR_DOF_LAYOUT) {
         ctx->err = "assemble: Node.DOF is not {3i,3i+1,3i+2} with 3i < n_dof (Node.cs:218-223)";
@@ -1032,6 +1037,13 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         return STAN_E_ARG;
     }
     const int64_t n_inc = ctx->h_status[SS_H_NINC];
+    const int64_t n_big = ctx->h_status[SS_NBIG];
+    if (n_big > 0) {
+        STANCHK(stan_dmalloc(ctx, &d_big_rows, (size_t)n_big)); tmp.own(d_big_rows);
+        HIPCHK(ctx, hipMemsetAsync(d_status + SS_COUNTER, 0, 8, st));
+        hipLaunchKernelGGL(k_list_above, dim3(nblk(nrows_pad, 256)), dim3(256), 0, st, nrows_pad, d_cnt, STAN_MAX_INCIDENT, d_big_rows,
+                           (unsigned long long *)(d_status + SS_COUNTER));
+    }
     int32_t *d_list; STANCHK(stan_dmalloc(ctx, &d_list, (size_t)n_inc)); tmp.own(d_list);
     HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, ((size_t)nrows_pad + 1) * 4, st));
     if (n_elem > 0)
@@ -1051,7 +1063,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
     if (nrows_pad > 0)
         hipLaunchKernelGGL(k_symbolic, dim3((unsigned)nrows_pad), dim3(64), 0, st, nloc, r0, r1, d_ptr,
                            d_list, d_crow, K->d_rowlen, d_refflag, d_ucols, d_status);
-    if (ctx->h_status[SS_MAXDEG] > STAN_MAX_INCIDENT && nrows_pad > 0) {   // high-valence nodes: the slow symbolic path
+    if (n_big > 0) {   // high-valence nodes: the slow symbolic path, one workgroup per listed row
         int64_t PD = 64, PC = 64;
         while (PD < ctx->h_status[SS_MAXDEG]) PD <<= 1;
         while (PC < 8 * ctx->h_status[SS_MAXDEG]) PC <<= 1;
@@ -1065,7 +1077,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         HIPCHK(ctx, hipMemsetAsync(d_status + SS_COUNTER, 0, 8, st));   // scratch tickets
         if (lds_ints * 4 > 64 * 1024)
             HIPCHK(ctx, hipFuncSetAttribute((const void *)k_symbolic_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_ints * 4)));
-        hipLaunchKernelGGL(k_symbolic_big, dim3((unsigned)nrows_pad), dim3(256), (size_t)lds_ints * 4, st, nloc, r0, r1, d_ptr, d_list,
+        hipLaunchKernelGGL(k_symbolic_big, dim3((unsigned)n_big), dim3(256), (size_t)lds_ints * 4, st, d_big_rows, r0, r1, d_ptr, d_list,
                            d_crow, K->d_rowlen, d_refflag, d_ucols, (int)lds_ints, d_scratch, PD + PC,
                            (unsigned long long *)(d_status + SS_COUNTER));
     }
@@ -1142,6 +1154,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         A.fixmask = K->d_fixmask; A.halo_glob = K->d_halo_glob; A.halo_rank = d_halo_rank;
         A.rowlen = K->d_rowlen; A.rowof = K->d_rowof; A.slot_ptr = K->d_slot_ptr; A.cols = K->d_cols; A.vals = K->d_vals;
         A.bad_elem = (long long *)(d_status + SS_BAD_ELEM);
+        A.wide_slices = nullptr;
         A.wmax = K->max_row_blocks > 0 ? K->max_row_blocks : 1;
         const bool wide = A.wmax > STAN_MAX_ROW_BLOCKS;   // some slice holds a high-valence row: it goes to k_numeric_wide
         if (wide) A.wmax = STAN_MAX_ROW_BLOCKS;
@@ -1152,9 +1165,17 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (K->nslices > 0)
             hipLaunchKernelGGL(k_numeric, dim3((unsigned)K->nslices * 4), dim3(256), lds, st, A);
-        if (wide) {
-            if ((int64_t)K->nslices * 64 >= (int64_t)1 << 31) { ctx->err = "assemble: too many slices for the wide-row kernel's grid"; return STAN_E_ARG; }
-            hipLaunchKernelGGL(k_numeric_wide, dim3((unsigned)K->nslices * 64), dim3(64), 0, st, A);
+        if (wide) {   // the slices k_numeric skipped, listed from their widths (a handful: one launch of 64 waves per slice)
+            int32_t *d_wide; STANCHK(stan_dmalloc(ctx, &d_wide, (size_t)K->nslices)); tmp.own(d_wide);
+            HIPCHK(ctx, hipMemsetAsync(d_status + SS_COUNTER, 0, 8, st));
+            hipLaunchKernelGGL(k_list_above, dim3(nblk(K->nslices, 256)), dim3(256), 0, st, (int64_t)K->nslices, d_width, STAN_MAX_ROW_BLOCKS, d_wide,
+                               (unsigned long long *)(d_status + SS_COUNTER));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_status + SS_COUNTER, d_status + SS_COUNTER, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            const int64_t n_wide = ctx->h_status[SS_COUNTER];
+            A.wide_slices = d_wide;
+            if (n_wide * 64 >= (int64_t)1 << 31) { ctx->err = "assemble: too many wide slices for one launch"; return STAN_E_ARG; }
+            if (n_wide > 0) hipLaunchKernelGGL(k_numeric_wide, dim3((unsigned)(n_wide * 64)), dim3(64), 0, st, A);
         }
     }
     HIPCHK(ctx, hipGetLastError());

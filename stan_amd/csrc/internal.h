@@ -107,6 +107,7 @@ enum stan_status_slot {
     SS_H_ERRCOPY = 11,   // host: copy of SS_ERRBITS during the colouring rounds
     SS_MAXDEG = 12,      // device + host: most (element, local node) incidences of one owned row when > STAN_MAX_INCIDENT, else 0
     SS_NGIANT = 13,      // device + host: rows whose symbolic sort does not fit the LDS allotment (global scratch)
+    SS_NBIG = 14,        // device + host: rows with more than STAN_MAX_INCIDENT incidences (k_symbolic_big's grid)
     SS_WIDTH_SUM = 16,   // device: sum of row lengths, followed by
     SS_WIDTH_MAX = 17,   //         the longest row (k_slice_width)
     SS_H_CG_STATUS = 16, // host: two 8-word copies of the CG status words (chunk polling)

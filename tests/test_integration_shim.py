@@ -182,3 +182,51 @@ def test_replacement_methods_call_only_declared_imports_with_declared_arity():
     assert calls >= 6
     assert re.search(r"e\.dE\[a\]\.SetFast\(c, 0, strain\[48 \* i \+ 6 \* a \+ c\]\)", t)
     assert re.search(r"e\.dS\[a\]\.SetFast\(c, 0, stress\[48 \* i \+ 6 \* a \+ c\]\)", t)
+
+
+REF = "/root/reference/src"
+
+
+def test_shim_uses_only_members_the_reference_declares():
+    """integration/SolverFunctions.Hip.cs is written against the reference's object model without a compiler to check
+    it: every member it touches must exist, public, in the reference's sources (checked HERE, where the checkout is
+    present; the GPU box has none and skips).  Reads the reference, copies nothing."""
+    import pytest
+    if not os.path.isdir(REF):
+        pytest.skip("no reference checkout on this machine")
+
+    def src(rel):
+        return open(os.path.join(REF, rel), encoding="utf-8-sig").read()
+    node, elem, mat = src("STAN_Database/Node.cs"), src("STAN_Database/Element.cs"), src("STAN_Database/Material.cs")
+    db, ana, mst = src("STAN_Database/Database.cs"), src("STAN_Database/Analysis.cs"), src("STAN_Database/MatrixST.cs")
+    need = [
+        (node, r"public\s+int\s+ID\b"), (node, r"public\s+double\s+X\b"), (node, r"public\s+double\s+Y\b"),
+        (node, r"public\s+double\s+Z\b"), (node, r"public\s+int\[\]\s+DOF\b"), (node, r"public\s+double\[\]\s+dU_buffer\b"),
+        (elem, r"public\s+int\s+ID\b"), (elem, r"public\s+string\s+Type\b"), (elem, r"public\s+int\s+MatID\b"),
+        (elem, r"public\s+List<int>\s+NList\b"), (elem, r"public\s+MatrixST\[\]\s+dE\b"), (elem, r"public\s+MatrixST\[\]\s+dS\b"),
+        (elem, r"public\s+void\s+Update_StrainStress\(int\s+\w+\)"), (elem, r"public\s+void\s+Initialize_Increment\(int\s+\w+\)"),
+        (mat, r"public\s+int\s+ID\b"), (mat, r"public\s+double\s+E\b"), (mat, r"public\s+double\s+Poisson\b"),
+        (db, r"public\s+Dictionary<int,\s*Node>\s+NodeLib\b"), (db, r"public\s+Dictionary<int,\s*Element>\s+ElemLib\b"),
+        (db, r"public\s+Dictionary<int,\s*Material>\s+MatLib\b"), (db, r"public\s+int\s+nDOF\b"),
+        (db, r"public\s+Analysis\s+AnalysisLib\b"),
+        (ana, r"public\s+double\s+GetLinSolverTolerance\(\)"), (ana, r"public\s+int\s+GetLinSolverMaxIter\(\)"),
+        (ana, r"public\s+string\s+GetLinSolver\(\)"),
+        (mst, r"public\s+void\s+SetFast\(int\s+\w+,\s*int\s+\w+,\s*double\s+\w+\)"),
+    ]
+    for text, pat in need:
+        assert re.search(pat, text), pat
+    # the call sites the shim replaces are where INTEGRATION.md says they are
+    solver = src("STAN_Solver/Solver.cs").split("\n")
+    assert "Fun.ParallelAssembly_K(DB, nDOF_reduction, inc" in solver[155]            # Solver.cs:156
+    assert "Fun.LinearSolver_CG(K, F, DB.AnalysisLib)" in solver[161]                 # Solver.cs:162
+    assert "Elem.Recovery_Stress(DB)" in solver[185] and "E.Update_StrainStress(inc)" in solver[208]
+    fun = src("STAN_Solver/SolverFunctions.cs").split("\n")
+    assert "ParallelAssembly_K(" in fun[116] and "LinearSolver_CG(" in fun[269]       # SolverFunctions.cs:117, :270
+    # and every member access of the shim on those objects is in the list above
+    shim = _strip_c_comments(open(SHIM2).read())
+    for m in set(re.findall(r"\b(?:n|e|m)\.(\w+)", shim)):
+        assert m in {"ID", "X", "Y", "Z", "DOF", "dU_buffer", "Type", "MatID", "NList", "dE", "dS", "E", "Poisson"}, m
+    for m in set(re.findall(r"\bDB\.(\w+)", shim)):
+        assert m in {"NodeLib", "ElemLib", "MatLib", "nDOF"}, m
+    for m in set(re.findall(r"\bAnalysisLib\.(\w+)", shim)):
+        assert m in {"GetLinSolverTolerance", "GetLinSolverMaxIter"}, m
