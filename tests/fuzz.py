@@ -145,3 +145,30 @@ def check_shards(ctx_factory, job, nranks):
         K.free()
     assert covered == job.xyz.shape[0]
     ctx.close()
+
+
+def random_revolved_job(seed):
+    """A solid of revolution with collapsed hexes on its axis (stan_amd.cube.revolved_mesh), random sector / ring /
+    layer counts (3 ... 160 sectors: up to 640 incidences and 483 blocks at an axis node), shuffled node and element wire
+    order, two materials: the high-valence slow paths of the assembly (k_symbolic_big, chunked k_fill_cols,
+    k_numeric_wide) and the duplicate-node branches on meshes no test wrote by hand."""
+    from stan_amd.cube import revolved_mesh
+    rng = np.random.default_rng(seed + 77000)
+    sectors = int(rng.choice([3, 5, 8, 16, 17, 24, 33, 48, 72, 100, 160]))
+    rings, layers = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+    xyz, conn = revolved_mesh(sectors, rings, layers, r0=float(rng.uniform(0.5, 2.0)), h=float(rng.uniform(0.5, 2.0)))
+    n_nodes = xyz.shape[0]
+    perm = rng.permutation(n_nodes)                       # node wire order
+    xyz2 = np.empty_like(xyz)
+    xyz2[perm] = xyz
+    conn = perm[conn].astype(np.int32)
+    conn = conn[rng.permutation(conn.shape[0])]           # element wire order
+    zmin, zmax = xyz2[:, 2].min(), xyz2[:, 2].max()
+    spc = np.nonzero(xyz2[:, 2] == zmin)[0].astype(np.int32)
+    ld = np.nonzero(xyz2[:, 2] == zmax)[0].astype(np.int32)
+    job = problem.make_job(xyz2, conn, spc, np.ones((spc.shape[0], 3)), ld, rng.standard_normal((ld.shape[0], 3)) * 10.0)
+    job.elem_mat = rng.integers(0, 2, conn.shape[0]).astype(np.int32)
+    job.mat_E_nu = np.array([[210000.0, 0.3], [float(rng.uniform(5000, 70000)), float(rng.uniform(0.0, 0.4))]])
+    job.has_g1 = False
+    job.sectors = sectors
+    return job

@@ -1,6 +1,8 @@
-"""Fuzz sweep of the hot path against the oracle (tests/fuzz.py): python tools/fuzz_parity.py [first] [count] [fold]
+"""Fuzz sweep of the hot path against the oracle (tests/fuzz.py): python tools/fuzz_parity.py [first] [count] [fold] [kind] [mode]
 fold = 1: the products of every job read the FOLDED streams (STAN_OPT_ROW_FOLDING forced on, the small-system kernel
-off: the jobs are tiny), so the sweep exercises fold.hip's plans on a few hundred ragged meshes."""
+off: the jobs are tiny), so the sweep exercises fold.hip's plans on a few hundred ragged meshes.
+kind: box (default) | collapsed (box jobs with 5 % of their elements collapsed into wedges) | revolved (solids of revolution
+with collapsed hexes on the axis, 3 ... 160 sectors: the high-valence slow paths).  mode: STAN_OPT_ASSEMBLY_MODE (0 / 1)."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,11 +19,14 @@ if fold:
     ctx.set_option(hip.OPT_SPMV_SMALL, 0)
     ctx.set_option(hip.OPT_ROW_FOLDING, 1)
     ctx.set_profiling(True)
+kind = sys.argv[4] if len(sys.argv) > 4 else "box"
+ctx.set_option(hip.OPT_ASSEMBLY_MODE, int(sys.argv[5]) if len(sys.argv) > 5 else 0)
 folded_jobs = 0
 ok = skipped = 0
 worst = {"k_err": 0.0, "u_err": 0.0, "res": 0.0, "res48": 0.0}
 for seed in range(first, first + count):
-    job = fuzz.random_job(seed)
+    job = (fuzz.random_revolved_job(seed) if kind == "revolved" else
+           fuzz.random_job(seed, collapse=0.05 if kind == "collapsed" else 0.0))
     if job is None:
         skipped += 1
         continue
