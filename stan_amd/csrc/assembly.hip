@@ -489,13 +489,13 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
     // carve-up (all 8-byte aligned):
     //   acc   [16][wmax][9]   double
     //   xs    [4 waves][8 inc][8 nodes][3] double
-    //   gps   [4 waves][8 gp][8 inc][10]   double
+    //   gps   [4 waves][8 gp][8 inc][12]   double   {J^-1 (9), c * grad N_a (3)}
     //   colsl [16][wmax] int32, cfix [16][wmax] uint8 (stored as int32 for simplicity)
     const int W = A.wmax;
     double *acc = lds;
     double *xs = acc + 16 * W * 9;
     double *gps = xs + 4 * 8 * 8 * 3;
-    int32_t *colsl = (int32_t *)(gps + 4 * 8 * 8 * 10);
+    int32_t *colsl = (int32_t *)(gps + 4 * 8 * 8 * 12);
     int32_t *cfix = colsl + 16 * W;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -524,57 +524,50 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
     __syncthreads();
 
     double *xsw = xs + w * (8 * 8 * 3);
-    double *gpw = gps + w * (8 * 8 * 10);
+    double *gpw = gps + w * (8 * 8 * 12);
     const int s = lane >> 3, b = lane & 7;
+    // This lane's node b never changes: the signs of its natural coordinates are constants of the lane, and
+    // dN_b/d(xi, eta, zeta) at a Gauss point is (sx/8) fy fz etc. with f = 1 +- gl picked at compile time per point
+    // (hex8_dnl's own expression and association: same bits) -- 6 multiplications instead of ~20 instructions.
+    const double sxb = hex8_sign(HEX8_SX, b), syb = hex8_sign(HEX8_SY, b), szb = hex8_sign(HEX8_SZ, b);
+    const double sx8 = 0.125 * sxb, sy8 = 0.125 * syb, sz8 = 0.125 * szb;
+    // The incidence -> connectivity -> coordinates chain is three dependent global loads: the chain of the NEXT row is
+    // issued before the current row is computed (first 8 incidences; longer rows load the rest inline) -- one set of
+    // registers, rotated (round 4: the four rows' chains up front cost 40 VGPRs that the block arithmetic needs).
+    struct chain { int64_t row, p0; int deg, rl; int32_t en, colg, ty, mi; double x0, x1, x2; };
+    auto load_chain = [&](int i) {
+        chain c;
+        c.row = i < 4 ? (int64_t)A.rowof[row_base + w * 4 + i] : A.nloc;
+        c.p0 = 0; c.deg = 0; c.rl = 0; c.en = 0; c.colg = 0; c.ty = STAN_HEX8_G2; c.mi = 0; c.x0 = c.x1 = c.x2 = 0.0;
+        if (c.row < A.nloc) {
+            c.p0 = A.ptr[c.row];
+            c.deg = (int)(A.ptr[c.row + 1] - c.p0);
+            c.rl = A.rowlen[c.row];
+            if (s < c.deg) {
+                c.en = A.list[c.p0 + s];
+                const int32_t e = c.en >> 3;
+                c.colg = A.crow[(int64_t)e * 8 + b];
+                c.ty = A.elem_type[e];
+                c.mi = A.elem_mat[e];
+                c.x0 = A.xrow[3 * (int64_t)c.colg + 0];
+                c.x1 = A.xrow[3 * (int64_t)c.colg + 1];
+                c.x2 = A.xrow[3 * (int64_t)c.colg + 2];
+            }
+        }
+        return c;
+    };
+    chain nxt = load_chain(0);
 
-    // The incidence -> connectivity -> coordinates chain is three dependent global loads.
-    // Issue it for the wave's four rows up front so that the latencies overlap instead of
-    // being paid row by row (first 8 incidences of each row; longer rows load inline).
-    int64_t P0[4];
-    int DEG[4], RL[4];
-    int32_t EN[4], COLG[4], TY[4], MI[4];
-    double X0[4], X1[4], X2[4];
-    int64_t ROW[4];
-#pragma unroll
+#pragma unroll 1
     for (int i = 0; i < 4; i++) {
-        const int64_t row = ROW[i] = A.rowof[row_base + w * 4 + i];
-        P0[i] = 0; DEG[i] = 0; RL[i] = 0;
-        if (row < A.nloc) {
-            P0[i] = A.ptr[row];
-            DEG[i] = (int)(A.ptr[row + 1] - P0[i]);
-            RL[i] = A.rowlen[row];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) EN[i] = s < DEG[i] ? A.list[P0[i] + s] : 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int32_t e = EN[i] >> 3;
-        COLG[i] = 0; TY[i] = STAN_HEX8_G2; MI[i] = 0;
-        if (s < DEG[i]) {
-            COLG[i] = A.crow[(int64_t)e * 8 + b];
-            TY[i] = A.elem_type[e];
-            MI[i] = A.elem_mat[e];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        X0[i] = X1[i] = X2[i] = 0.0;
-        if (s < DEG[i]) {
-            X0[i] = A.xrow[3 * (int64_t)COLG[i] + 0];
-            X1[i] = A.xrow[3 * (int64_t)COLG[i] + 1];
-            X2[i] = A.xrow[3 * (int64_t)COLG[i] + 2];
-        }
-    }
-
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
+        const chain cur = nxt;
+        nxt = load_chain(i + 1);
         const int r16 = w * 4 + i;
-        const int64_t row = ROW[i];
+        const int64_t row = cur.row;
         if (row >= A.nloc) continue;  // wave-uniform
-        const int64_t p0 = P0[i];
-        const int deg = DEG[i];
-        const int rl = RL[i];
+        const int64_t p0 = cur.p0;
+        const int deg = cur.deg;
+        const int rl = cur.rl;
         for (int c0 = 0; c0 < (STAN_ABL == 6 ? 0 : deg); c0 += 8) {
             const bool valid = c0 + s < deg;
             int32_t e = 0, a = 0, type = STAN_HEX8_G2, colg = 0;
@@ -583,8 +576,8 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
                 int32_t en, m;
                 double x0, x1, x2;
                 if (c0 == 0) {
-                    en = EN[i]; colg = COLG[i]; type = TY[i]; m = MI[i];
-                    x0 = X0[i]; x1 = X1[i]; x2 = X2[i];
+                    en = cur.en; colg = cur.colg; type = cur.ty; m = cur.mi;
+                    x0 = cur.x0; x1 = cur.x1; x2 = cur.x2;
                 } else {
                     en = A.list[p0 + c0 + s];
                     colg = A.crow[(int64_t)(en >> 3) * 8 + b];
@@ -608,8 +601,9 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (valid) {
-                // phase A: this lane = Gauss point b of incidence s
-                double o[10];
+                // phase A: this lane = Gauss point b of incidence s: J^-1, c = det J w, and -- once for the eight lanes
+                // that will need it -- c * grad N_a of the row's own node a
+                double o[10], wa[3];
 #if STAN_ABL == 5
                 double det = 1.0;
                 for (int j = 0; j < 10; j++) o[j] = xsw[s * 24 + j];
@@ -618,8 +612,14 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
 #endif
                 if (det == 0.0 && hex8_gauss_weight(type, b) != 0.0)
                     atomicMin(A.bad_elem, (long long)e);
+                {
+                    const double gl = hex8_gauss_loc(type);
+                    hex8_wgrad(o, a, hex8_sign(HEX8_SX, b) * gl, hex8_sign(HEX8_SY, b) * gl, hex8_sign(HEX8_SZ, b) * gl, wa);
+                }
 #pragma unroll
-                for (int j = 0; j < 10; j++) gpw[(b * 8 + s) * 10 + j] = o[j];
+                for (int j = 0; j < 9; j++) gpw[(b * 8 + s) * 12 + j] = o[j];
+#pragma unroll
+                for (int j = 0; j < 3; j++) gpw[(b * 8 + s) * 12 + 9 + j] = wa[j];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -627,11 +627,24 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
             double kb[9];
             int pos = -1;
             if (valid) {
-                // phase B: block (a, b) of element e
+                // phase B: block (a, b) of element e in the M-form (hex8_device.h): per Gauss point J^-1 and c grad N_a
+                // from LDS, grad N_b = J^-1 dnb[g] from the lane's constants, nine fused multiply-adds into M
 #if STAN_ABL == 1
-                for (int j = 0; j < 9; j++) kb[j] = gpw[s * 10 + j];
+                for (int j = 0; j < 9; j++) kb[j] = gpw[s * 12 + j];
 #else
-                hex8_block_ab(gpw + s * 10, 8 * 10, type, a, b, lam, G, kb);
+                const double glt = hex8_gauss_loc(type);   // (HEX8_G1: 0 -- every point at the origin, c = 0 beyond the first)
+                const double fxp = 1.0 + sxb * glt, fxm = 1.0 - sxb * glt, fyp = 1.0 + syb * glt, fym = 1.0 - syb * glt,
+                             fzp = 1.0 + szb * glt, fzm = 1.0 - szb * glt;
+                double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 2   // (fully unrolled the scheduler hoists all 96 LDS reads: 256 VGPRs and scratch)
+                for (int g = 0; g < 8; g++) {
+                    const double *q = gpw + (g * 8 + s) * 12;
+                    const double fx = ((HEX8_SX >> g) & 1u) ? fxp : fxm, fy = ((HEX8_SY >> g) & 1u) ? fyp : fym,
+                                 fz = ((HEX8_SZ >> g) & 1u) ? fzp : fzm;
+                    const double d[3] = {sx8 * fy * fz, sy8 * fx * fz, sz8 * fx * fy};
+                    hex8_m_accum(q, q + 9, d, M);
+                }
+                hex8_k_from_m(M, lam, G, kb);
 #endif
                 // phase C: slot of column colg in this row.  The row's columns ascend in GLOBAL
                 // index (the symbolic phase sorted them), so a binary search over the global
@@ -1159,7 +1172,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         const bool wide = A.wmax > STAN_MAX_ROW_BLOCKS;   // some slice holds a high-valence row: it goes to k_numeric_wide
         if (wide) A.wmax = STAN_MAX_ROW_BLOCKS;
         const size_t lds = (size_t)16 * A.wmax * 9 * 8 + (size_t)4 * 8 * 8 * 3 * 8 +
-                           (size_t)4 * 8 * 8 * 10 * 8 + (size_t)2 * 16 * A.wmax * 4;
+                           (size_t)4 * 8 * 8 * 12 * 8 + (size_t)2 * 16 * A.wmax * 4;
         if (lds > 64 * 1024)
             HIPCHK(ctx, hipFuncSetAttribute((const void *)k_numeric,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

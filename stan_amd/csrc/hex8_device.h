@@ -88,33 +88,64 @@ __device__ __forceinline__ void hex8_grad(const double *inv, int i, double px, d
     gr[2] = inv[6] * d[0] + inv[7] * d[1] + inv[8] * d[2];
 }
 
-// Accumulate the (a,b) 3x3 block of K_e over the element's Gauss points.
+// The (a,b) 3x3 block of K_e over the element's Gauss points, in the M-form (round 4):
+//   M_ab = sum_g (c_g grad N_a)(grad N_b)^T          9 fused multiply-adds per Gauss point
+//   K_ab = lambda M + G M^T + G tr(M) I               once, after the loop
+// -- the same algebra as before (K_ab[m][n] = sum_g c_g (lambda ga[m] gb[n] + G ga[n] gb[m] + delta_mn G ga.gb)) with a
+// third of the instructions per Gauss point.  Every product and sum is spelled out with fma() so that the kernels that
+// share these helpers (row-owner gather, its wide-row form, the colour scatter, k_ke_batch) round alike whatever the
+// compiler would contract on its own.
+// grad = J^-1 d, d = dN/d(xi,eta,zeta) of one node
+__device__ __forceinline__ void hex8_inv_times(const double *inv, const double d[3], double gr[3]) {
+    gr[0] = fma(inv[2], d[2], fma(inv[1], d[1], inv[0] * d[0]));
+    gr[1] = fma(inv[5], d[2], fma(inv[4], d[1], inv[3] * d[0]));
+    gr[2] = fma(inv[8], d[2], fma(inv[7], d[1], inv[6] * d[0]));
+}
+// w = c * grad N_a at the Gauss point whose {J^-1, c} is q[0..9]
+__device__ __forceinline__ void hex8_wgrad(const double *q, int a, double px, double py, double pz, double w[3]) {
+    double d[3], ga[3];
+    hex8_dnl(a, px, py, pz, d);
+    hex8_inv_times(q, d, ga);
+    w[0] = q[9] * ga[0]; w[1] = q[9] * ga[1]; w[2] = q[9] * ga[2];
+}
+// M += w (J^-1 d_b)^T
+__device__ __forceinline__ void hex8_m_accum(const double *inv, const double w[3], const double d[3], double M[9]) {
+    double gb[3];
+    hex8_inv_times(inv, d, gb);
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int n = 0; n < 3; n++) M[3 * m + n] = fma(w[m], gb[n], M[3 * m + n]);
+}
+__device__ __forceinline__ void hex8_k_from_m(const double M[9], double lam, double G, double k[9]) {
+    const double gtr = G * ((M[0] + M[4]) + M[8]);
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int n = 0; n < 3; n++) {
+            const double v = fma(lam, M[3 * m + n], G * M[3 * n + m]);
+            k[3 * m + n] = m == n ? v + gtr : v;
+        }
+}
 // gp: per Gauss point 10 doubles {J^-1, c} with stride `gstride` doubles between points.
 #ifndef STAN_GP_UNROLL
-#define STAN_GP_UNROLL 2  // 231 VGPRs, no spill at 2 waves/SIMD (full unroll spills)
+#define STAN_GP_UNROLL 2
 #endif
 __device__ __forceinline__ void hex8_block_ab(const double *gp, int gstride, int type, int a,
                                               int b, double lam, double G, double k[9]) {
     const double gl = hex8_gauss_loc(type);
-#pragma unroll
-    for (int j = 0; j < 9; j++) k[j] = 0.0;
+    double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll STAN_GP_UNROLL
     for (int g = 0; g < 8; g++) {
         const double *q = gp + g * gstride;
-        const double c = q[9];
         const double px = hex8_sign(HEX8_SX, g) * gl, py = hex8_sign(HEX8_SY, g) * gl,
                      pz = hex8_sign(HEX8_SZ, g) * gl;
-        double ga[3], gb[3];
-        hex8_grad(q, a, px, py, pz, ga);
-        hex8_grad(q, b, px, py, pz, gb);
-        const double t = c * lam, u = c * G;
-        const double dot = u * (ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2]);
-#pragma unroll
-        for (int m = 0; m < 3; m++)
-#pragma unroll
-            for (int n = 0; n < 3; n++)
-                k[3 * m + n] += t * ga[m] * gb[n] + u * ga[n] * gb[m] + (m == n ? dot : 0.0);
+        double w[3], d[3];
+        hex8_wgrad(q, a, px, py, pz, w);
+        hex8_dnl(b, px, py, pz, d);
+        hex8_m_accum(q, w, d, M);
     }
+    hex8_k_from_m(M, lam, G, k);
 }
 
 // Lame constants exactly as Material.SetElastic forms them (Material.cs:39-40).
