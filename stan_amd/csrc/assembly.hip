@@ -674,52 +674,28 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
             const bool anydup = __ballot(isdup) != 0ull;
             if (STAN_ABL == 2) {
                 if (pos == 12345) acc[0] = kb[0];
-            } else if (!anydup && W <= 48) {
-                // Gather form: every lane stages its block, a map says which lane of incidence
-                // s2 feeds slot k, then lane k sums its slot over s2 = 0..7 in registers
-                // (ascending element index => fixed order) with independent, pipelined LDS
-                // reads -- instead of eight dependent read-modify-write rounds.
-                // stage aliases the Gauss-point scratch (dead after phase B), map the coordinates.
-                double *stage = gpw;             // [64 lanes][9]
-                int32_t *map = (int32_t *)xsw;   // [8 incidences][W slots] -> lane or -1
-                for (int t = lane; t < 8 * W; t += 64) map[t] = -1;
-#pragma unroll
-                for (int j = 0; j < 9; j++) stage[lane * 9 + j] = kb[j];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (pos >= 0) map[s * W + pos] = lane;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                for (int k = lane; k < rl; k += 64) {
-                    double t9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                    for (int s2 = 0; s2 < 8; s2++) {
-                        const int32_t l = map[s2 * W + k];
-                        if (l >= 0) {
-#pragma unroll
-                            for (int j = 0; j < 9; j++) t9[j] += stage[l * 9 + j];
-                        }
-                    }
-                    double *ak = acc + (r16 * W + k) * 9;
-#pragma unroll
-                    for (int j = 0; j < 9; j++) ak[j] += t9[j];
-                }
             } else {
-                // rows wider than the map, or a degenerate element listing one node twice:
-                // ordered read-modify-write, incidence by incidence
-                volatile double *ar = acc + r16 * W * 9;
+                // One incidence after the other (ascending element index, then local node: the fixed order that makes K
+                // bit-reproducible), each lane adding its block to its slot with LDS fp64 adds (ds_add_f64, no return
+                // value): the eight lanes of one incidence hit eight different slots unless the element lists a node
+                // twice, and the LDS executes a wave's instructions in program order, so the adds of successive rounds
+                // to one slot land in that order.  Round 4: replaces the staged gather (stage 64 x 9 doubles, a slot map,
+                // 72 reads per lane) -- the kernel is bound by the bytes it moves through the LDS pipe
+                // (profiles/r04/k_numeric_ablations_*.txt), and this form moves a quarter of the gather's.
+                double *ar = acc + r16 * W * 9;
+#pragma unroll 1
                 for (int s2 = 0; s2 < 8; s2++) {
                     if (s == s2 && pos >= 0 && !isdup) {
 #pragma unroll
-                        for (int j = 0; j < 9; j++) ar[pos * 9 + j] = ar[pos * 9 + j] + kb[j];
+                        for (int j = 0; j < 9; j++)
+                            __hip_atomic_fetch_add(ar + pos * 9 + j, kb[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     }
-                    if (anydup) {
+                    if (anydup) {   // a degenerate element: the later listings of a node, in order
                         for (int b2 = 1; b2 < 8; b2++) {
                             if (s == s2 && b == b2 && pos >= 0 && isdup) {
 #pragma unroll
-                                for (int j = 0; j < 9; j++) ar[pos * 9 + j] = ar[pos * 9 + j] + kb[j];
+                                for (int j = 0; j < 9; j++)
+                                    __hip_atomic_fetch_add(ar + pos * 9 + j, kb[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                             }
                         }
                     }
@@ -1173,11 +1149,15 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         if (wide) A.wmax = STAN_MAX_ROW_BLOCKS;
         const size_t lds = (size_t)16 * A.wmax * 9 * 8 + (size_t)4 * 8 * 8 * 3 * 8 +
                            (size_t)4 * 8 * 8 * 12 * 8 + (size_t)2 * 16 * A.wmax * 4;
-        if (lds > 64 * 1024)
+        size_t lds_launch = lds;
+#ifdef STAN_LAB_LDS_PAD   // lab: occupancy experiment (more LDS per workgroup -> fewer workgroups per CU)
+        if (const char *pad_ = getenv("STAN_NUM_LDS_PAD")) lds_launch += (size_t)atoi(pad_);
+#endif
+        if (lds_launch > 64 * 1024)
             HIPCHK(ctx, hipFuncSetAttribute((const void *)k_numeric,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch));
         if (K->nslices > 0)
-            hipLaunchKernelGGL(k_numeric, dim3((unsigned)K->nslices * 4), dim3(256), lds, st, A);
+            hipLaunchKernelGGL(k_numeric, dim3((unsigned)K->nslices * 4), dim3(256), lds_launch, st, A);
         if (wide) {   // the slices k_numeric skipped, listed from their widths (a handful: one launch of 64 waves per slice)
             int32_t *d_wide; STANCHK(stan_dmalloc(ctx, &d_wide, (size_t)K->nslices)); tmp.own(d_wide);
             HIPCHK(ctx, hipMemsetAsync(d_status + SS_COUNTER, 0, 8, st));
