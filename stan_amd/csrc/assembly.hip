@@ -482,21 +482,29 @@ struct numeric_args {
 #define STAN_ABL 0
 #endif
 #ifndef STAN_NUM_WAVES
-#define STAN_NUM_WAVES 2
+#define STAN_NUM_WAVES 3   // workgroups of k_numeric per CU the register budget must allow (168 VGPRs)
+#endif
+#ifndef STAN_NUM_ROWS
+#define STAN_NUM_ROWS 8    // block rows per workgroup of k_numeric (4 waves: 2 each); 16 = rounds 1-3
 #endif
 __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A) {
     extern __shared__ double lds[];
+    // A workgroup assembles NR = 8 consecutive positions of a slice, two per wavefront (round 4; 16 until then: the
+    // accumulators of 16 rows held a CU to two workgroups, and the kernel's time follows the waves in flight: 18.9 ms
+    // with one workgroup per CU, 11.5 with two -- profiles/r04/k_numeric_ablations_*.txt).  The write-out then stores
+    // 64-B half lines; the other half of a line follows from the neighbouring workgroup.
     // carve-up (all 8-byte aligned):
-    //   acc   [16][wmax][9]   double
+    //   acc   [NR][wmax][9]   double
     //   xs    [4 waves][8 inc][8 nodes][3] double
     //   gps   [4 waves][8 gp][8 inc][12]   double   {J^-1 (9), c * grad N_a (3)}
-    //   colsl [16][wmax] int32, cfix [16][wmax] uint8 (stored as int32 for simplicity)
+    //   colsl [NR][wmax] int32, cfix [NR][wmax] uint8 (stored as int32 for simplicity)
+    constexpr int NR = STAN_NUM_ROWS;
     const int W = A.wmax;
     double *acc = lds;
-    double *xs = acc + 16 * W * 9;
+    double *xs = acc + NR * W * 9;
     double *gps = xs + 4 * 8 * 8 * 3;
     int32_t *colsl = (int32_t *)(gps + 4 * 8 * 8 * 12);
-    int32_t *cfix = colsl + 16 * W;
+    int32_t *cfix = colsl + NR * W;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // XCD-chunked mapping (round 4): with the identity mapping every XCD's L2 sees the coordinates and connectivity of
@@ -506,17 +514,17 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
 #define STAN_NUM_CH 32
 #endif
     const int64_t bid = STAN_NUM_CH > 0 ? xcd_chunked(blockIdx.x, gridDim.x, STAN_NUM_CH) : (int64_t)blockIdx.x;
-    const int64_t slice = bid >> 2;
-    const int q = (int)(bid & 3);
-    const int64_t row_base = slice * 64 + q * 16;   // first POSITION of this workgroup
+    const int64_t slice = bid / (64 / NR);
+    const int q = (int)(bid % (64 / NR));
+    const int64_t row_base = slice * 64 + q * NR;   // first POSITION of this workgroup
     const int32_t k0 = A.slot_ptr[slice];
     const int sw = A.slot_ptr[slice + 1] - k0;  // this slice's width
     if (sw > W) return;   // wider than the LDS accumulators (a high-valence node): k_numeric_wide (workgroup-uniform)
 
-    for (int i = tid; i < 16 * W * 9; i += 256) acc[i] = 0.0;
-    for (int i = tid; i < 16 * sw; i += 256) {
-        const int r16 = i & 15, k = i >> 4;
-        const int32_t lc = A.cols[((int64_t)k0 + k) * 64 + q * 16 + r16];
+    for (int i = tid; i < NR * W * 9; i += 256) acc[i] = 0.0;
+    for (int i = tid; i < NR * sw; i += 256) {
+        const int r16 = i % NR, k = i / NR;
+        const int32_t lc = A.cols[((int64_t)k0 + k) * 64 + q * NR + r16];
         const int64_t g = lc < A.nloc ? A.r0 + lc : (int64_t)A.halo_glob[lc - A.nloc];
         colsl[r16 * W + k] = (int32_t)g;  // GLOBAL block column: ascending along the row
         cfix[r16 * W + k] = A.fixmask[g];
@@ -537,7 +545,7 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
     struct chain { int64_t row, p0; int deg, rl; int32_t en, colg, ty, mi; double x0, x1, x2; };
     auto load_chain = [&](int i) {
         chain c;
-        c.row = i < 4 ? (int64_t)A.rowof[row_base + w * 4 + i] : A.nloc;
+        c.row = i < NR / 4 ? (int64_t)A.rowof[row_base + w * (NR / 4) + i] : A.nloc;
         c.p0 = 0; c.deg = 0; c.rl = 0; c.en = 0; c.colg = 0; c.ty = STAN_HEX8_G2; c.mi = 0; c.x0 = c.x1 = c.x2 = 0.0;
         if (c.row < A.nloc) {
             c.p0 = A.ptr[c.row];
@@ -559,10 +567,10 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
     chain nxt = load_chain(0);
 
 #pragma unroll 1
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < NR / 4; i++) {
         const chain cur = nxt;
         nxt = load_chain(i + 1);
-        const int r16 = w * 4 + i;
+        const int r16 = w * (NR / 4) + i;
         const int64_t row = cur.row;
         if (row >= A.nloc) continue;  // wave-uniform
         const int64_t p0 = cur.p0;
@@ -708,20 +716,21 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
     }
     __syncthreads();
 
-    // write-out with the essential BCs applied: 16 consecutive lanes = one full 128-B line
-    // a thread keeps its row (t & 15 is loop-invariant) and walks (k, comp) by 16 per step
+    // write-out with the essential BCs applied: NR consecutive lanes = one 64-B half line (NR = 16: a full 128-B line)
+    // a thread keeps its row (t % NR is loop-invariant) and walks (k, comp) by 256 / NR per step
     {
-        const int r16 = tid & 15;
+        const int r16 = tid % NR;
         const int64_t row = A.rowof[row_base + r16];
         const bool live = row < A.nloc;
         const int rfix = live ? A.fixmask[A.r0 + row] : 0;
         const int rlen = live ? A.rowlen[row] : 0;
         const int32_t grow = (int32_t)(A.r0 + row);
-        int kc = tid >> 4;                 // = k * 9 + comp
+        constexpr int STEP = 256 / NR;     // (k, comp) pairs per step
+        int kc = tid / NR;                 // = k * 9 + comp
         int k = kc / 9, comp = kc - 9 * k;
-        double *out = A.vals + (int64_t)k0 * 9 * 64 + q * 16 + r16;
+        double *out = A.vals + (int64_t)k0 * 9 * 64 + q * NR + r16;
         const int kc_end = STAN_ABL == 3 ? 1 : sw * 9;
-        for (; kc < kc_end; kc += 16) {
+        for (; kc < kc_end; kc += STEP) {
             double v = 0.0;
             if (k < rlen) {
                 const int m = comp >= 6 ? 2 : comp >= 3 ? 1 : 0, n = comp - 3 * m;
@@ -732,8 +741,8 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
                     v = acc[(r16 * W + k) * 9 + comp];
             }
             out[(int64_t)kc * 64] = v;
-            comp += 16 - 9;                // 16 = 9 + 7
-            k += 1;
+            comp += STEP % 9;
+            k += STEP / 9;
             if (comp >= 9) { comp -= 9; k += 1; }
         }
     }
@@ -1147,8 +1156,8 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         A.wmax = K->max_row_blocks > 0 ? K->max_row_blocks : 1;
         const bool wide = A.wmax > STAN_MAX_ROW_BLOCKS;   // some slice holds a high-valence row: it goes to k_numeric_wide
         if (wide) A.wmax = STAN_MAX_ROW_BLOCKS;
-        const size_t lds = (size_t)16 * A.wmax * 9 * 8 + (size_t)4 * 8 * 8 * 3 * 8 +
-                           (size_t)4 * 8 * 8 * 12 * 8 + (size_t)2 * 16 * A.wmax * 4;
+        const size_t lds = (size_t)STAN_NUM_ROWS * A.wmax * 9 * 8 + (size_t)4 * 8 * 8 * 3 * 8 +
+                           (size_t)4 * 8 * 8 * 12 * 8 + (size_t)2 * STAN_NUM_ROWS * A.wmax * 4;
         size_t lds_launch = lds;
 #ifdef STAN_LAB_LDS_PAD   // lab: occupancy experiment (more LDS per workgroup -> fewer workgroups per CU)
         if (const char *pad_ = getenv("STAN_NUM_LDS_PAD")) lds_launch += (size_t)atoi(pad_);
@@ -1157,7 +1166,7 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
             HIPCHK(ctx, hipFuncSetAttribute((const void *)k_numeric,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch));
         if (K->nslices > 0)
-            hipLaunchKernelGGL(k_numeric, dim3((unsigned)K->nslices * 4), dim3(256), lds_launch, st, A);
+            hipLaunchKernelGGL(k_numeric, dim3((unsigned)K->nslices * (64 / STAN_NUM_ROWS)), dim3(256), lds_launch, st, A);
         if (wide) {   // the slices k_numeric skipped, listed from their widths (a handful: one launch of 64 waves per slice)
             int32_t *d_wide; STANCHK(stan_dmalloc(ctx, &d_wide, (size_t)K->nslices)); tmp.own(d_wide);
             HIPCHK(ctx, hipMemsetAsync(d_status + SS_COUNTER, 0, 8, st));
