@@ -484,6 +484,15 @@ struct numeric_args {
 #ifndef STAN_NUM_WAVES
 #define STAN_NUM_WAVES 3   // workgroups of k_numeric per CU the register budget must allow (168 VGPRs)
 #endif
+#ifndef STAN_NUM_XS
+#define STAN_NUM_XS 25     // doubles per incidence of the coordinate scratch (24 + padding against LDS bank conflicts)
+#endif
+#ifndef STAN_NUM_GS
+#define STAN_NUM_GS 13     // doubles per (Gauss point, incidence) record (12 + padding)
+#endif
+#ifndef STAN_B_UNROLL
+#define STAN_B_UNROLL 4    // Gauss points per trip of the block arithmetic's loop (2: 10.11 ms, 4: 9.98 ms)
+#endif
 #ifndef STAN_NUM_ROWS
 #define STAN_NUM_ROWS 8    // block rows per workgroup of k_numeric (4 waves: 2 each); 16 = rounds 1-3
 #endif
@@ -495,15 +504,18 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
     // 64-B half lines; the other half of a line follows from the neighbouring workgroup.
     // carve-up (all 8-byte aligned):
     //   acc   [NR][wmax][9]   double
-    //   xs    [4 waves][8 inc][8 nodes][3] double
-    //   gps   [4 waves][8 gp][8 inc][12]   double   {J^-1 (9), c * grad N_a (3)}
+    //   xs    [4 waves][8 inc][XS = 25]    double   8 nodes x 3 coordinates + 1 of padding
+    //   gps   [4 waves][8 gp][8 inc][GS = 13] double  {J^-1 (9), c * grad N_a (3)} + 1 of padding
+    // The paddings are LDS bank hygiene: the eight lanes of an incidence read ONE record, the wave eight records at a
+    // time; with strides of 24 / 12 doubles the records of incidences s and s + 2 / s + 4 start in the same bank (4- / 2-way
+    // conflicts on every read of the two read-heaviest phases); 25 / 13 spread the eight over distinct banks.
     //   colsl [NR][wmax] int32, cfix [NR][wmax] uint8 (stored as int32 for simplicity)
-    constexpr int NR = STAN_NUM_ROWS;
+    constexpr int NR = STAN_NUM_ROWS, XS = STAN_NUM_XS, GS = STAN_NUM_GS;
     const int W = A.wmax;
     double *acc = lds;
     double *xs = acc + NR * W * 9;
-    double *gps = xs + 4 * 8 * 8 * 3;
-    int32_t *colsl = (int32_t *)(gps + 4 * 8 * 8 * 12);
+    double *gps = xs + 4 * 8 * XS;
+    int32_t *colsl = (int32_t *)(gps + 4 * 8 * 8 * GS);
     int32_t *cfix = colsl + NR * W;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -511,7 +523,7 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
     // three whole breadth-first levels (4.8 MB at 148^3, L2: 4 MB); each XCD now assembles NUM_CH consecutive workgroups
     // (8 slices) at a time and its L2 holds their neighbourhood only.
 #ifndef STAN_NUM_CH
-#define STAN_NUM_CH 32
+#define STAN_NUM_CH 64
 #endif
     const int64_t bid = STAN_NUM_CH > 0 ? xcd_chunked(blockIdx.x, gridDim.x, STAN_NUM_CH) : (int64_t)blockIdx.x;
     const int64_t slice = bid / (64 / NR);
@@ -521,18 +533,8 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
     const int sw = A.slot_ptr[slice + 1] - k0;  // this slice's width
     if (sw > W) return;   // wider than the LDS accumulators (a high-valence node): k_numeric_wide (workgroup-uniform)
 
-    for (int i = tid; i < NR * W * 9; i += 256) acc[i] = 0.0;
-    for (int i = tid; i < NR * sw; i += 256) {
-        const int r16 = i % NR, k = i / NR;
-        const int32_t lc = A.cols[((int64_t)k0 + k) * 64 + q * NR + r16];
-        const int64_t g = lc < A.nloc ? A.r0 + lc : (int64_t)A.halo_glob[lc - A.nloc];
-        colsl[r16 * W + k] = (int32_t)g;  // GLOBAL block column: ascending along the row
-        cfix[r16 * W + k] = A.fixmask[g];
-    }
-    __syncthreads();
-
-    double *xsw = xs + w * (8 * 8 * 3);
-    double *gpw = gps + w * (8 * 8 * 12);
+    double *xsw = xs + w * (8 * XS);
+    double *gpw = gps + w * (8 * 8 * GS);
     const int s = lane >> 3, b = lane & 7;
     // This lane's node b never changes: the signs of its natural coordinates are constants of the lane, and
     // dN_b/d(xi, eta, zeta) at a Gauss point is (sx/8) fy fz etc. with f = 1 +- gl picked at compile time per point
@@ -564,7 +566,17 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
         }
         return c;
     };
-    chain nxt = load_chain(0);
+    chain nxt = load_chain(0);   // (issued in front of the staging below: its five dependent loads overlap the staging's two)
+
+    for (int i = tid; i < NR * W * 9; i += 256) acc[i] = 0.0;
+    for (int i = tid; i < NR * sw; i += 256) {
+        const int r16 = i % NR, k = i / NR;
+        const int32_t lc = A.cols[((int64_t)k0 + k) * 64 + q * NR + r16];
+        const int64_t g = lc < A.nloc ? A.r0 + lc : (int64_t)A.halo_glob[lc - A.nloc];
+        colsl[r16 * W + k] = (int32_t)g;  // GLOBAL block column: ascending along the row
+        cfix[r16 * W + k] = A.fixmask[g];
+    }
+    __syncthreads();
 
 #pragma unroll 1
     for (int i = 0; i < NR / 4; i++) {
@@ -599,9 +611,9 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
                 a = en & 7;
                 lam = A.mat_lamG[2 * m];
                 G = A.mat_lamG[2 * m + 1];
-                xsw[(s * 8 + b) * 3 + 0] = x0;
-                xsw[(s * 8 + b) * 3 + 1] = x1;
-                xsw[(s * 8 + b) * 3 + 2] = x2;
+                xsw[s * XS + b * 3 + 0] = x0;
+                xsw[s * XS + b * 3 + 1] = x1;
+                xsw[s * XS + b * 3 + 2] = x2;
             }
             // (all LDS traffic below is private to this wavefront: program order suffices,
             //  the fences only stop the compiler from reordering across the hand-off)
@@ -614,9 +626,9 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
                 double o[10], wa[3];
 #if STAN_ABL == 5
                 double det = 1.0;
-                for (int j = 0; j < 10; j++) o[j] = xsw[s * 24 + j];
+                for (int j = 0; j < 10; j++) o[j] = xsw[s * XS + j];
 #else
-                const double det = hex8_gp_setup(xsw + s * 24, type, b, o);
+                const double det = hex8_gp_setup(xsw + s * XS, type, b, o);
 #endif
                 if (det == 0.0 && hex8_gauss_weight(type, b) != 0.0)
                     atomicMin(A.bad_elem, (long long)e);
@@ -625,9 +637,9 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
                     hex8_wgrad(o, a, hex8_sign(HEX8_SX, b) * gl, hex8_sign(HEX8_SY, b) * gl, hex8_sign(HEX8_SZ, b) * gl, wa);
                 }
 #pragma unroll
-                for (int j = 0; j < 9; j++) gpw[(b * 8 + s) * 12 + j] = o[j];
+                for (int j = 0; j < 9; j++) gpw[(b * 8 + s) * GS + j] = o[j];
 #pragma unroll
-                for (int j = 0; j < 3; j++) gpw[(b * 8 + s) * 12 + 9 + j] = wa[j];
+                for (int j = 0; j < 3; j++) gpw[(b * 8 + s) * GS + 9 + j] = wa[j];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -638,15 +650,15 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
                 // phase B: block (a, b) of element e in the M-form (hex8_device.h): per Gauss point J^-1 and c grad N_a
                 // from LDS, grad N_b = J^-1 dnb[g] from the lane's constants, nine fused multiply-adds into M
 #if STAN_ABL == 1
-                for (int j = 0; j < 9; j++) kb[j] = gpw[s * 12 + j];
+                for (int j = 0; j < 9; j++) kb[j] = gpw[s * GS + j];
 #else
                 const double glt = hex8_gauss_loc(type);   // (HEX8_G1: 0 -- every point at the origin, c = 0 beyond the first)
                 const double fxp = 1.0 + sxb * glt, fxm = 1.0 - sxb * glt, fyp = 1.0 + syb * glt, fym = 1.0 - syb * glt,
                              fzp = 1.0 + szb * glt, fzm = 1.0 - szb * glt;
                 double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 2   // (fully unrolled the scheduler hoists all 96 LDS reads: 256 VGPRs and scratch)
+#pragma unroll STAN_B_UNROLL   // (fully unrolled the scheduler hoists all 96 LDS reads: 256 VGPRs and scratch)
                 for (int g = 0; g < 8; g++) {
-                    const double *q = gpw + (g * 8 + s) * 12;
+                    const double *q = gpw + (g * 8 + s) * GS;
                     const double fx = ((HEX8_SX >> g) & 1u) ? fxp : fxm, fy = ((HEX8_SY >> g) & 1u) ? fyp : fym,
                                  fz = ((HEX8_SZ >> g) & 1u) ? fzp : fzm;
                     const double d[3] = {sx8 * fy * fz, sy8 * fx * fz, sz8 * fx * fy};
@@ -1156,8 +1168,8 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         A.wmax = K->max_row_blocks > 0 ? K->max_row_blocks : 1;
         const bool wide = A.wmax > STAN_MAX_ROW_BLOCKS;   // some slice holds a high-valence row: it goes to k_numeric_wide
         if (wide) A.wmax = STAN_MAX_ROW_BLOCKS;
-        const size_t lds = (size_t)STAN_NUM_ROWS * A.wmax * 9 * 8 + (size_t)4 * 8 * 8 * 3 * 8 +
-                           (size_t)4 * 8 * 8 * 12 * 8 + (size_t)2 * STAN_NUM_ROWS * A.wmax * 4;
+        const size_t lds = (size_t)STAN_NUM_ROWS * A.wmax * 9 * 8 + (size_t)4 * 8 * STAN_NUM_XS * 8 +
+                           (size_t)4 * 8 * 8 * STAN_NUM_GS * 8 + (size_t)2 * STAN_NUM_ROWS * A.wmax * 4;
         size_t lds_launch = lds;
 #ifdef STAN_LAB_LDS_PAD   // lab: occupancy experiment (more LDS per workgroup -> fewer workgroups per CU)
         if (const char *pad_ = getenv("STAN_NUM_LDS_PAD")) lds_launch += (size_t)atoi(pad_);
