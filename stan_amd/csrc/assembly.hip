@@ -484,6 +484,9 @@ struct numeric_args {
 #ifndef STAN_NUM_WAVES
 #define STAN_NUM_WAVES 3   // workgroups of k_numeric per CU the register budget must allow (168 VGPRs)
 #endif
+#ifndef STAN_NUM_NT
+#define STAN_NUM_NT 0      // non-temporal stores in k_numeric's write-out (lab)
+#endif
 #ifndef STAN_NUM_XS
 #define STAN_NUM_XS 25     // doubles per incidence of the coordinate scratch (24 + padding against LDS bank conflicts)
 #endif
@@ -752,7 +755,11 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
                 else
                     v = acc[(r16 * W + k) * 9 + comp];
             }
+#if STAN_NUM_NT
+            __builtin_nontemporal_store(v, out + (int64_t)kc * 64);   // K is written once and read by another kernel much later
+#else
             out[(int64_t)kc * 64] = v;
+#endif
             comp += STEP % 9;
             k += STEP / 9;
             if (comp >= 9) { comp -= 9; k += 1; }

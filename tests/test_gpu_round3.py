@@ -73,7 +73,8 @@ def test_sell_c_sigma_keeps_the_cube(gpu_ctx):
     args = (job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
     x = np.random.default_rng(1).standard_normal(job.n_red)
     res = {}
-    try:
+    gpu_ctx.set_option(1, 0)   # STAN_OPT_CG_MERIT_STOP off: the type-7 stop lands wherever rounding lets the merit tick up
+    try:                       # (the dot-product partials add up in another order with sigma = 32), the residual test does not
         for sigma in (1, 32):
             gpu_ctx.set_option(OPT_SELL_SIGMA, sigma)
             K = gpu_ctx.assemble_hex8(*args)
@@ -83,6 +84,7 @@ def test_sell_c_sigma_keeps_the_cube(gpu_ctx):
             K.free()
     finally:
         gpu_ctx.set_option(OPT_SELL_SIGMA, 1)
+        gpu_ctx.set_option(1, 1)
     assert res[32][0] <= res[1][0] + 1e-12 and res[32][0] < 0.03
     assert np.array_equal(res[1][1], res[32][1])
     assert res[1][3]["terminationtype"] == res[32][3]["terminationtype"]
