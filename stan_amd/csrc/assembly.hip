@@ -21,9 +21,10 @@
 // walks the (element, local node) incidences of its node in ascending element order
 // and sums the element blocks K_e[a][b] it recomputes from the nodal coordinates
 // (lane = (incidence s, local node b); the eight lanes of an incidence share the
-// element's J^-1 at the 8 Gauss points through LDS).  Every value of K is written
-// exactly once, in full 128-B lines, with no atomics and a fixed summation order
-// (bit-reproducible, unlike the reference's lock(K) scatter, SolverFunctions.cs:162).
+// element's J^-1 and c grad N_a at the 8 Gauss points through LDS).  Every value of K is
+// written to memory exactly once, with no global atomics and a fixed summation order (the
+// row's blocks add up in LDS, one incidence after the other: bit-reproducible, unlike the
+// reference's lock(K) scatter, SolverFunctions.cs:162).
 #include <algorithm>
 
 #include "internal.h"
@@ -477,7 +478,9 @@ struct numeric_args {
     const int32_t *wide_slices;   // k_numeric_wide: the slices wider than wmax
 };
 
-// two waves per SIMD (<= 128 VGPRs): measured 23.6 ms vs 39.7 ms at 148^3 (tools/asm_lab.sh)
+// tuning macros of k_numeric (tools/asm_lab.sh builds variants with -D; profiles/r04/k_numeric_ablations_2_and_tuning.txt)
+// STAN_ABL: timing-only ablations -- 1 no block arithmetic, 2 no accumulation, 3 no write-out, 4 no slot search, 5 no Jacobians,
+// 6 no incidence chunks at all
 #ifndef STAN_ABL
 #define STAN_ABL 0
 #endif
