@@ -17,6 +17,9 @@ dist.init_process_group("gloo")
 if spec.startswith("fuzz:"):   # tests/fuzz.py job: shuffled wire order, several neighbours, empty ranks
     from tests import fuzz
     job = fuzz.random_job(int(spec[5:]))
+elif spec.startswith("rev:"):  # a solid of revolution: collapsed hexes and a high-valence axis (the assembly's slow paths on a shard)
+    from tests import fuzz
+    job = fuzz.random_revolved_job(int(spec[4:]))
 else:
     job = problem.cube_job(int(spec), jitter=0.05)
 ctx = hip.Context(0)

@@ -368,3 +368,30 @@ def test_console_driver_on_a_revolved_mesh(built_libs, oracle, tmp_path):
     want = spl.spsolve((Uu + sp.triu(Uu, 1).T).tocsc(), F)
     do = host.nodal_displacements(fl["node_dof"], red, want)
     assert np.abs(disp - do).max() <= 1e-5 * np.abs(do).max()      # the CG stops by its merit rule (type 7) near 1e-7
+
+
+def test_stress_recovery_and_nodal_forces_on_collapsed_hexes(gpu_ctx, oracle):
+    """Element.Recovery_Stress / Compute_NodalForces (Element.cs:211-255) on the revolved mesh: the wedge-collapsed hexes
+    on the axis list a node twice -- their 8x6 strain / stress blocks (two rows then belong to the same node, each
+    extrapolated with its own shape-function row, as the reference does) and the R assembly, where the repeated node
+    receives both listings' forces, against the oracle element by element."""
+    xyz, conn = revolved_mesh(24, 2, 2)
+    job = _job(xyz, conn)
+    disp = np.random.default_rng(11).standard_normal(job.xyz.shape) * 1e-3
+    strain, stress = gpu_ctx.recover_hex8(job.xyz, disp, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu)
+    f, R = gpu_ctx.nodal_forces_hex8(job.xyz, disp, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu)
+    fo = np.zeros_like(f)
+    E, nu = job.mat_E_nu[0]
+    ncollapsed = 0
+    for e in range(job.conn.shape[0]):
+        rc, eo, so = oracle.recover_hex8(job.xyz[job.conn[e]], E, nu, 2, disp[job.conn[e]].ravel())
+        rc2, fo[e] = oracle.nodal_forces_hex8(job.xyz[job.conn[e]], 2, so)
+        assert rc == 0 and rc2 == 0
+        assert np.abs(strain[e] - eo).max() <= 1e-11 * np.abs(eo).max()
+        assert np.abs(stress[e] - so).max() <= 1e-11 * np.abs(so).max()
+        ncollapsed += job.conn[e, 0] == job.conn[e, 3]
+    assert ncollapsed == 48
+    assert np.abs(f - fo).max() <= 1e-11 * np.abs(fo).max()
+    Ro = np.zeros(job.n_dof)
+    np.add.at(Ro, job.node_dof[job.conn].reshape(-1, 24), fo)
+    assert np.abs(R - Ro).max() <= 1e-10 * np.abs(Ro).max()

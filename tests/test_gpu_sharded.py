@@ -49,7 +49,7 @@ def _torchrun(nproc, script_args, env_extra):
 
 
 @pytest.mark.parametrize("world,overlap,spec", [(2, 1, "12"), (3, 1, "12"), (3, 0, "12"),
-                                                (4, 1, "fuzz:124"), (4, 1, "fuzz:101")])
+                                                (4, 1, "fuzz:124"), (4, 1, "fuzz:101"), (3, 1, "rev:3")])
 def test_sharded_solve_matches_oracle(built_libs, oracle, tmp_path, world, overlap, spec):
     """fuzz:124 = 383 shuffled nodes on 4 ranks (1, 3, 2, 2 neighbours); fuzz:101 = 191 nodes on
     4 ranks, the first of which owns no rows.  More processes than that on the one GPU next to the
@@ -62,6 +62,9 @@ def test_sharded_solve_matches_oracle(built_libs, oracle, tmp_path, world, overl
     if spec.startswith("fuzz:"):
         from tests import fuzz
         job = fuzz.random_job(int(spec[5:]))
+    elif spec.startswith("rev:"):     # round 4: 72 sectors, shuffled wire order: collapsed hexes, 288 incidences on the axis
+        from tests import fuzz
+        job = fuzz.random_revolved_job(int(spec[4:]))
     else:
         job = problem.cube_job(int(spec), jitter=0.05)
     rc, A = oracle.assemble(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
