@@ -654,6 +654,11 @@ def main():
                        # SURVEY section 8d assembly bytes: coords + connectivity read, K written once
                        "assembly_GBs": (conn.shape[0] * (192 + 32) + info["n_slots"] * 64 * 72)
                                        / (asm_ms / args.steps * 1e-3) / 1e9 if asm_ms > 0 else None,
+                       # the same section's flop figure: the dense B'DB costs ~75 kflop per G2 element (an eighth per G1
+                       # element); the kernels exploit B's sparsity and recompute an element once per incident row, so
+                       # this is the rate of the WORK DEFINED, not of the instructions issued
+                       "assembly_GFLOPs_dense_equivalent": conn.shape[0] * (75e3 if args.etype == 2 else 75e3 / 8)
+                                                           / (asm_ms / args.steps * 1e-3) / 1e9 if asm_ms > 0 else None,
                        "device_read_GBs": dev_read},
             "roofline": {"bound": "hbm", "kernel": "k_spmv (BSELL-64 SpMV + fused p.Ap)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

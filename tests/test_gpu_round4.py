@@ -395,3 +395,55 @@ def test_stress_recovery_and_nodal_forces_on_collapsed_hexes(gpu_ctx, oracle):
     Ro = np.zeros(job.n_dof)
     np.add.at(Ro, job.node_dof[job.conn].reshape(-1, 24), fo)
     assert np.abs(R - Ro).max() <= 1e-10 * np.abs(Ro).max()
+
+
+def test_device_memory_does_not_grow_over_many_jobs():
+    """A context that is created, used (both assembly modes, the high-valence symbolic path with its global scratch, fp64 /
+    fp32-matrix / FIXED-48 solves, folded streams, recovery) and closed gives every byte back: 40 such lives leave the
+    device's free memory where it was; inside ONE context 40 assemble / solve / free rounds stay within the block pool's
+    bound (the pool parks blocks for reuse, it must not accumulate them)."""
+    import torch
+    from stan_amd import hip
+    torch.cuda.synchronize()
+
+    def free_mb():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info(0)[0] / 2 ** 20
+
+    jobs = [problem.cube_job(12, jitter=0.1)]
+    xyz, conn = revolved_mesh(72, 2, 2)
+    jobs.append(_job(xyz, conn))
+    xyz, conn = revolved_mesh(1000, 1, 2)          # a node with 4000 incidences: k_symbolic_big's global scratch
+    jobs.append(_job(xyz, conn))
+
+    def one_life():
+        ctx = hip.Context(0)
+        for i, job in enumerate(jobs):
+            ctx.set_option(OPT_ASSEMBLY_MODE, i & 1)
+            ctx.set_option(hip.OPT_ROW_FOLDING, 1 if i == 1 else -1)
+            K = ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+            for prec in (hip.PREC_FP64, hip.PREC_MIXED, hip.PREC_FIXED48):
+                U, rep = K.cg_solve(job.F, 1e-8, 400, prec)
+            K.free()
+        ctx.close()
+
+    one_life()                                      # whatever the runtime keeps for itself is taken here
+    one_life()
+    before = free_mb()
+    for _ in range(40):
+        one_life()
+    after = free_mb()
+    assert before - after < 8, "40 context lives cost %.1f MB of device memory" % (before - after)
+
+    ctx = hip.Context(0)
+    marks = []
+    for r in range(40):
+        for job in jobs[:2]:
+            K = ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+            K.cg_solve(job.F, 1e-8, 200)
+            K.free()
+        if r in (4, 39):
+            marks.append(free_mb())
+    ctx.close()
+    assert marks[0] - marks[1] < 8, "rounds 5 -> 40 inside one context cost %.1f MB" % (marks[0] - marks[1])
+    assert free_mb() >= before - 8
