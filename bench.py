@@ -650,7 +650,8 @@ def main():
                        "placement_search": {"candidates_timed": prof["placement_candidates"],
                                             "probe_ms_kept": prof["placement_ms_best"],
                                             "probe_ms_slowest": prof["placement_ms_worst"],
-                                            "vectors_moved_instead": bool(prof["placement_moved_vectors"])},
+                                            "vectors_moved_instead": prof["placement_moved_vectors"] == 1,
+                                            "product_vectors_moved": prof["placement_moved_vectors"] == 2},
                        # SURVEY section 8d assembly bytes: coords + connectivity read, K written once
                        "assembly_GBs": (conn.shape[0] * (192 + 32) + info["n_slots"] * 64 * 72)
                                        / (asm_ms / args.steps * 1e-3) / 1e9 if asm_ms > 0 else None,

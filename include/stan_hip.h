@@ -392,7 +392,7 @@ typedef struct stan_profile {
     int32_t placement_candidates;     /* blocks the last allocation-by-search timed (0: none) */
     float placement_ms_best, placement_ms_worst; /* SpMV probe time of the kept / the slowest candidate */
     int64_t col_slots_packed;         /* ELL slots whose columns the last solve read from the packed stream */
-    int32_t placement_moved_vectors;  /* 1: no candidate was clear of the vectors' group and the search re-allocated the CG's vectors instead */
+    int32_t placement_moved_vectors;  /* 1: no candidate was clear of the vectors' group and the search re-allocated the CG's vectors instead; 2: only the two vectors the products write (second stage, behind spacer blocks) */
     int32_t repacked_streams;         /* 1: the last solve's products read the folded streams (STAN_OPT_ROW_FOLDING) */
     int64_t loop_stream_waits;        /* peer-to-peer exchanges (STAN_OPT_COMM_P2P): stream waits the loop enqueued instead of collectives */
     double comm_reduce_ms_total;      /* sharded loop: stream time between "reduction issued" and "sums available", summed   */

@@ -409,6 +409,38 @@ int stan_cg_workspace_move(stan_ctx *ctx, const stan_matrix *K, bool commit, sta
     return STAN_OK;
 }
 
+// Round 4 (tools/lab/spmv_steps_lab.cpp, profiles/r04/spmv_steps/): what makes a pairing slow is the vector the product
+// WRITES lying in the memory group of the values it reads -- the gather vector's place does not matter.  So the cheap move is
+// the two product buffers v and w alone.  step 0: fresh v, w straight from the driver (they lie beyond whatever the caller
+// holds allocated), the old ones parked in old[]; step 1: keep the new ones; step 2: back to the old ones.
+int stan_cg_products_move(stan_ctx *ctx, int step, double *old[2]) {
+    stan_cg_ws &ws = ctx->ws;
+    const size_t bytes = (size_t)(ws.n3 > 0 ? ws.n3 : 1) * 8;
+    if (step == 0) {
+        old[0] = old[1] = nullptr;
+        if (!ws.v || !ws.w) return STAN_OK;
+        double *nv = nullptr, *nw = nullptr;
+        if (hipMalloc((void **)&nv, bytes) != hipSuccess || hipMalloc((void **)&nw, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            if (nv) hipFree(nv);
+            return STAN_OK;   // no memory for it: keep what we have
+        }
+        old[0] = ws.v; old[1] = ws.w;
+        ws.v = nv; ws.w = nw;
+        return STAN_OK;
+    }
+    if (!old[0]) return STAN_OK;
+    if (step == 1) {
+        for (int i = 0; i < 2; i++) { ctx->pool.live.erase((void *)old[i]); hipFree(old[i]); }
+        if (ctx->pool.enabled && bytes >= stan_pool::MIN_BYTES) { ctx->pool.live[(void *)ws.v] = bytes; ctx->pool.live[(void *)ws.w] = bytes; }
+    } else {
+        hipFree(ws.v); hipFree(ws.w);
+        ws.v = old[0]; ws.w = old[1];
+    }
+    old[0] = old[1] = nullptr;
+    return STAN_OK;
+}
+
 // Diagonal scaling of the matrix (once per matrix): A^ = S K S.
 static int ensure_scaled(stan_ctx *ctx, stan_matrix *K) {
     if (K->scaled) return STAN_OK;

@@ -373,6 +373,7 @@ int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K);
 int stan_cg_workspace(stan_ctx *ctx, const stan_matrix *K);  // (re)allocates ctx->ws for K's sizes
 void stan_cg_workspace_free(stan_ctx *ctx);
 int stan_cg_workspace_move(stan_ctx *ctx, const stan_matrix *K, bool commit, stan_cg_ws *saved);
+int stan_cg_products_move(stan_ctx *ctx, int step, double *old[2]);   // v, w only (placement.hip, second stage)
 
 // ---- recovery.hip ---------------------------------------------------------------------------
 int stan_recover_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz, const double *d_disp,

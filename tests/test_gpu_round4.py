@@ -447,3 +447,40 @@ def test_device_memory_does_not_grow_over_many_jobs():
     ctx.close()
     assert marks[0] - marks[1] < 8, "rounds 5 -> 40 inside one context cost %.1f MB" % (marks[0] - marks[1])
     assert free_mb() >= before - 8
+
+
+def test_placement_second_stage_moves_only_the_product_vectors(oracle):
+    """placement.hip, second stage (round 4): when no candidate block is clear of the vectors' memory group, only the two
+    vectors the products WRITE are re-allocated behind spacer blocks (tools/lab/spmv_steps_lab.cpp: the place of y alone
+    decides 1.00 or 1.13 ms).  Forced here (STAN_PLACEMENT_TRACE=stage2 enters the stage whatever the first found): the solve
+    that follows runs on the moved vectors and must give the bits of a solve without any search; the spacers are given back."""
+    import torch
+    from stan_amd import hip
+    job = problem.cube_job(60)
+    args = (job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+    ctx = hip.Context(0)
+    ctx.set_option(hip.OPT_PLACEMENT_TRIES, 1)
+    K = ctx.assemble_hex8(*args)
+    U0, rep0 = K.cg_solve(job.F, 1e-8)
+    K.free()
+    ctx.close()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    os.environ["STAN_PLACEMENT_TRACE"] = "stage2"
+    try:
+        ctx = hip.Context(0)
+        ctx.set_option(hip.OPT_PLACEMENT_TRIES, 4)
+        K = ctx.assemble_hex8(*args)
+        prof = ctx.profile()
+        U1, rep1 = K.cg_solve(job.F, 1e-8)
+        K2 = ctx.assemble_hex8(*args)                  # a second matrix of the size: the parked block, no second search
+        U2, rep2 = K2.cg_solve(job.F, 1e-8)
+    finally:
+        del os.environ["STAN_PLACEMENT_TRACE"]
+    assert prof["placement_candidates"] >= 1 and prof["placement_moved_vectors"] in (0, 2)
+    assert rep1 == rep0 and np.array_equal(U1, U0)
+    assert rep2 == rep0 and np.array_equal(U2, U0)
+    K.free(); K2.free()
+    ctx.close()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(0)[0] >= free0 - (8 << 20)

@@ -26,6 +26,11 @@
 //   S27 = S2 + the stores after the 7th of the 13 trips (the running sums)
 //   S31 = S4 + every wave times (wall_clock64, 10 ns ticks) from its stores to their acknowledgement (s_waitcnt vmcnt(0)) and from
 //         its first load to the end; S32 = the same with three LOADS of y in place of the stores (S15)
+//   S33 = S4 + the product's p.Ap epilogue: x of the own rows read again, a workgroup sum through LDS behind __syncthreads, one
+//         partial stored per workgroup;  S34 = the same sum without the barrier (the last of the four waves to arrive adds up);
+//   S35 = S4 with the slot bases read by per-lane loads through a lane-selected pointer (what the two-base loop compiles to)
+//   S36 = S4 with the gather of x replaced by three lane-contiguous loads of the same 1.5 KB window (wrong products: what does the
+//         FORM of the gather cost?)
 //   S19 = S6 with the pieces at a multiplicative hash of s;  S20 = S6 with piece s ^ 1 ... (neighbours swapped: control)
 // The numbers are not products (values are zeros + noise): only times matter.
 #include <hip/hip_runtime.h>
@@ -55,6 +60,9 @@ __global__ void __launch_bounds__(256) k_steps(int nslices, long long nb, const 
                                                const uint32_t *__restrict__ cw, const int *__restrict__ base,
                                                const double *__restrict__ x, double *__restrict__ y, double *sink) {
     __shared__ double ysh[4][192];
+    __shared__ double dsh[4];
+    __shared__ int arrived;
+    if (STEP == 34) { if (threadIdx.x == 0) arrived = 0; __syncthreads(); }
     const int lane = threadIdx.x & 63;
     long long bid = blockIdx.x;
     if (STEP >= 4) {
@@ -91,9 +99,18 @@ __global__ void __launch_bounds__(256) k_steps(int nslices, long long nb, const 
 #pragma unroll
         for (int j = 0; j < 9; j++) b[j] = __builtin_nontemporal_load(vp + STRIDE + j * 64);
         if (STEP >= 2) {
-            const long long c = (long long)bp[k] + (wd & 0xffffu), c2 = (long long)bp[k + 1] + (wd >> 16);
-            const double x0 = x[3 * c], x1 = x[3 * c + 1], x2 = x[3 * c + 2];
-            const double z0 = x[3 * c2], z1 = x[3 * c2 + 1], z2 = x[3 * c2 + 2];
+            const int *bl = (STEP == 35 && ((0x5555555555555555ull >> lane) & 1ull) && lane > 64) ? bp + 1 : bp;   // never taken, not provable
+            const long long c = (long long)(STEP == 35 ? __builtin_nontemporal_load(bl + k) : bp[k]) + (wd & 0xffffu),
+                            c2 = (long long)(STEP == 35 ? __builtin_nontemporal_load(bl + k + 1) : bp[k + 1]) + (wd >> 16);
+            double x0, x1, x2, z0, z1, z2;
+            if (STEP == 36) {
+                const long long cb0 = 3 * (c - lane > 0 ? c - lane : 0) + lane, cb2 = 3 * (c2 - lane > 0 ? c2 - lane : 0) + lane;
+                x0 = x[cb0]; x1 = x[cb0 + 64]; x2 = x[cb0 + 128];
+                z0 = x[cb2]; z1 = x[cb2 + 64]; z2 = x[cb2 + 128];
+            } else {
+                x0 = x[3 * c]; x1 = x[3 * c + 1]; x2 = x[3 * c + 2];
+                z0 = x[3 * c2]; z1 = x[3 * c2 + 1]; z2 = x[3 * c2 + 2];
+            }
             y0 += a[0] * x0 + a[1] * x1 + a[2] * x2;
             y1 += a[3] * x0 + a[4] * x1 + a[5] * x2;
             y2 += a[6] * x0 + a[7] * x1 + a[8] * x2;
@@ -151,6 +168,28 @@ __global__ void __launch_bounds__(256) k_steps(int nslices, long long nb, const 
                 else if (STEP != 7) __builtin_nontemporal_store(w[64 * j + lane], yo + 64 * j + lane);
                 else yo[64 * j + lane] = w[64 * j + lane];
             }
+    } else if (STEP == 33 || STEP == 34) {
+        double d = 0;
+        if (row < nb) {
+            __builtin_nontemporal_store(y0, y + 3 * row);
+            __builtin_nontemporal_store(y1, y + 3 * row + 1);
+            __builtin_nontemporal_store(y2, y + 3 * row + 2);
+            d = y0 * x[3 * row] + y1 * x[3 * row + 1] + y2 * x[3 * row + 2];
+        }
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o);
+        const int wv = threadIdx.x >> 6;
+        if (STEP == 33) {
+            if (lane == 0) dsh[wv] = d;
+            __syncthreads();
+            if (threadIdx.x == 0) sink[1024 + blockIdx.x] = (dsh[0] + dsh[1]) + (dsh[2] + dsh[3]);
+        } else if (lane == 0) {
+            dsh[wv] = d;
+            __threadfence_block();
+            if (atomicAdd(&arrived, 1) == 3) {
+                __threadfence_block();
+                sink[1024 + blockIdx.x] = (((volatile double *)dsh)[0] + ((volatile double *)dsh)[1]) + (((volatile double *)dsh)[2] + ((volatile double *)dsh)[3]);
+            }
+        }
     } else if (STEP == 31 || STEP == 32) {
         const long long t1 = wall_clock64();
         double q = 0;
@@ -335,7 +374,7 @@ int main(int argc, char **argv) {
     // the vectors first, the matrix last: the order the library allocates in
     CK(hipMalloc(&x, (size_t)(nslices * 64LL + 64) * 3 * 8));
     CK(hipMalloc(&y, (size_t)(nslices * 64LL + 64) * 3 * 8));
-    CK(hipMalloc(&sink, 64 + (size_t)nslices * 16));
+    CK(hipMalloc(&sink, 64 + (size_t)nslices * 16 + 1024 * 8));
     unsigned long long *cnt;
     CK(hipMalloc(&cnt, 8 * 16 * 8));
     double *yf = nullptr, *yu = nullptr;
@@ -375,7 +414,7 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(cw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
     const double gb_vals = (double)nslices * W * STRIDE * 8 / 1e9, gb_all = gb_vals + nslices * 14 * 256 / 1e9 + 2 * nb * 24 / 1e9;
     printf("cube %d^3: %lld block rows, %d slices, value stream %.3f GB, with columns, x and y %.3f GB\n", n, nb, nslices, gb_vals, gb_all);
-    const char *names[31] = {"S0 values only", "S1 + column words", "S2 + x gather + FMAs", "S3 + y stored", "S4 + XCD-chunked mapping",
+    const char *names[37] = {"S0 values only", "S1 + column words", "S2 + x gather + FMAs", "S3 + y stored", "S4 + XCD-chunked mapping",
                             "S5 + column word one trip ahead", "S6 = S4, y through LDS, nt stores", "S7 = S6, plain stores",
                             "S8 = S4, plain strided stores", "S9 = S4, 4 slices per wave", "S10 = S4, y into a 1.5 MB window",
                             "S11 = S4, 8 slices per wave", "S12 = S4, plain stores, 1.5 MB window", "S13 = S4, y0 only", "S14 = S4, even slices store",
@@ -383,17 +422,41 @@ int main(int argc, char **argv) {
                             "S19 = S6, pieces hashed within 1024", "S20 = S6, neighbours swapped", "S21 = S6, stores sc0", "S22 = S6, stores sc1",
                             "S23 = S6, stores sc0 sc1", "S24 = S6, stores sc0 sc1 nt", "S25 = S6, y behind the slice's values",
                             "S26 = S2 + stores at the wave's START", "S27 = S2 + stores mid-way", "S28 = S4 as PERSISTENT waves, XCD queues",
-                            "S29 = S28, queue by blockIdx % 8", "S30 = S28 capped at 6 workgroups per CU"};
+                            "S29 = S28, queue by blockIdx % 8", "S30 = S28 capped at 6 workgroups per CU", "", "", "S33 = S4 + p.Ap epilogue (barrier)",
+                            "S34 = S4 + p.Ap epilogue, no barrier", "S35 = S4, bases by per-lane loads", "S36 = S4, x window read lane-contiguous"};
+    if (argc > 2 && strstr(argv[2], "sweep")) {
+        // where y lies: S4 timed with y carved out of the start of 28 spacer blocks of 8 GB, allocated one after the other
+        printf("S2 (no stores): %.4f ms;  S4 with the y of the ordinary allocation order: %.4f ms\n",
+               run<2>(nslices, nb, vals, cw, base, x, y, sink, 20), run<4>(nslices, nb, vals, cw, base, x, y, sink, 20));
+        std::vector<double *> sp;
+        for (int i = 0; i < 28; i++) {
+            double *q = nullptr;
+            if (hipMalloc(&q, (size_t)8 << 30) != hipSuccess) { (void)hipGetLastError(); break; }
+            sp.push_back(q);
+        }
+        for (size_t i = 0; i < sp.size(); i++) {
+            const float a = run<4>(nslices, nb, vals, cw, base, x, sp[i], sink, 20);
+            const float b = run<4>(nslices, nb, vals, cw, base, x, sp[i] + ((size_t)4 << 27), sink, 20);   // 4 GB further in
+            printf("  y in spacer %2zu (%p): %.4f ms   4 GB further in: %.4f ms\n", i, (void *)sp[i], a, b);
+        }
+        // and x (the gather vector) moved instead, y where it was
+        for (size_t i = 0; i < sp.size(); i += 4) {
+            (void)hipMemset(sp[i], 0, (size_t)(nslices * 64LL + 64) * 3 * 8);
+            printf("  x in spacer %2zu: %.4f ms (S4), %.4f ms (S2)\n", i, run<4>(nslices, nb, vals, cw, base, sp[i], y, sink, 20),
+                   run<2>(nslices, nb, vals, cw, base, sp[i], y, sink, 20));
+        }
+        return 0;
+    }
     // argv[2]: comma-separated steps (default: all), argv[3]: timed launches per step (default 40)
-    bool want[31];
-    for (int i = 0; i < 31; i++) want[i] = argc <= 2;
-    if (argc > 2) for (const char *q = argv[2]; *q;) { want[atoi(q) % 31] = true; while (*q && *q != ',') q++; if (*q) q++; }
+    bool want[37];
+    for (int i = 0; i < 37; i++) want[i] = argc <= 2 && i != 31 && i != 32;
+    if (argc > 2) for (const char *q = argv[2]; *q;) { want[atoi(q) % 37] = true; while (*q && *q != ',') q++; if (*q) q++; }
     const int reps = argc > 3 ? atoi(argv[3]) : 40;
     for (int round = 0; round < (argc > 3 ? 1 : 2); round++) {
-        float t[31] = {0};
+        float t[37] = {0};
 #define RUN(S) if (want[S]) t[S] = run<S>(nslices, nb, vals, cw, base, x, y, sink, reps);
         RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15)
-        RUN(18) RUN(19) RUN(20) RUN(21) RUN(22) RUN(23) RUN(24) RUN(25) RUN(26) RUN(27)
+        RUN(18) RUN(19) RUN(20) RUN(21) RUN(22) RUN(23) RUN(24) RUN(25) RUN(26) RUN(27) RUN(33) RUN(34) RUN(35) RUN(36)
 #undef RUN
         for (int st = 31; st <= 32; st++)
             if (argc <= 2 || strstr(argv[2], st == 31 ? "31" : "32")) {
@@ -410,8 +473,8 @@ int main(int argc, char **argv) {
         if (want[30]) t[30] = run_persist<0>(nslices, nb, vals, cw, base, x, y, cnt, reps, 6);
         if (want[16]) t[16] = yf ? run<4>(nslices, nb, vals, cw, base, x, yf, sink, reps) : 0.f;
         if (want[17]) t[17] = yu ? run<4>(nslices, nb, vals, cw, base, x, yu, sink, reps) : 0.f;
-        for (int i = 0; i < 31; i++)
-            if (want[i])
+        for (int i = 0; i < 37; i++)
+            if (want[i] && i != 31 && i != 32)
                 printf("  %-34s %.4f ms   values / t = %.0f GB/s, all bytes / t = %.0f GB/s\n", names[i], t[i], gb_vals / (t[i] * 1e-3),
                        (i == 0 ? gb_vals : i == 1 ? gb_vals + nslices * 14 * 256 / 1e9 : gb_all) / (t[i] * 1e-3));
     }
