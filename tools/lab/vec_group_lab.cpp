@@ -38,6 +38,33 @@ static float run(long long n, const double *r, const double *v, double *o, int r
     return ms / reps * 1e3f;
 }
 
+// cold form: a 6.4 GB read sweep between the launches (what the SpMV leaves behind in the CG), events around the axpy alone
+__global__ void __launch_bounds__(256) k_sweep(const double *__restrict__ p, long long n, double *sink) {
+    const long long stride = (long long)gridDim.x * 256;
+    double a = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) a += __builtin_nontemporal_load(p + i);
+    if (a == 0.1234567890123) sink[0] = a;
+}
+template <int NT>
+static float run_cold(long long n, const double *r, const double *v, double *o, const double *big, double *sink, int reps) {
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    float sum = 0;
+    for (int i = 0; i < reps + 2; i++) {
+        hipLaunchKernelGGL(k_sweep, dim3(256 * 24), dim3(256), 0, 0, big, (long long)800 << 20, sink);
+        (void)hipEventRecord(a, 0);
+        hipLaunchKernelGGL((k_axpy<NT>), dim3(grid), dim3(256), 0, 0, n, r, v, o, 0.5);
+        (void)hipEventRecord(b, 0);
+        (void)hipEventSynchronize(b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        if (i >= 2) sum += ms;
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return sum / reps * 1e3f;
+}
+
 int main() {
     const long long n = 9857244;   // the reduced system of the 148^3 cube
     std::vector<double *> sp;
@@ -55,5 +82,13 @@ int main() {
     for (size_t j = 1; j < sp.size(); j++)
         printf("  r, v in spacer 0, r' in spacer %2zu:                  %.2f | %.2f     (r in 0, v in %2zu, in place: %.2f)\n", j,
                run<0>(n, r, v, sp[j], 200), run<1>(n, r, v, sp[j], 200), j, run<1>(n, r, sp[j], r, 200));
+    printf("COLD (a 6.4 GB read sweep of spacer %zu before every launch), non-temporal store:\n", sp.size() - 1);
+    const double *big = sp.back();
+    printf("  in place, r and v in spacer 0:                     %.2f\n", run_cold<1>(n, r, v, r, big, sp[1], 20));
+    printf("  out of place, all three in spacer 0:               %.2f\n", run_cold<1>(n, r, v, o, big, sp[1], 20));
+    for (size_t j = 1; j + 1 < sp.size(); j += 2)
+        printf("  r' in spacer %2zu: %.2f     v in spacer %2zu, in place: %.2f     r and v in spacer %2zu, in place: %.2f\n", j,
+               run_cold<1>(n, r, v, sp[j] + pad, big, sp[1], 20), j, run_cold<1>(n, r, sp[j] + pad, r, big, sp[1], 20), j,
+               run_cold<1>(n, sp[j] + pad, sp[j] + 2 * pad, sp[j] + pad, big, sp[1], 20));
     return 0;
 }
