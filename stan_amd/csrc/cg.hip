@@ -32,6 +32,14 @@
 #ifndef STAN_Y_NT
 #define STAN_Y_NT 1
 #endif
+// loads of the vector kernels (k_step, k_update): operands a kernel only READS (v in k_step; r, x in k_update) and operands
+// it rewrites in place (r in k_step, p in k_update).  1 = non-temporal, 0 = plain.
+#ifndef STAN_VLD_RO_NT
+#define STAN_VLD_RO_NT 1
+#endif
+#ifndef STAN_VLD_RMW_NT
+#define STAN_VLD_RMW_NT 1
+#endif
 // round 2 (tools/fold_ab.py, profiles/r02/fold_ab_incg_*.txt): the in-CG penalty of the SpMV is the
 // REWRITING of its gather vector between two products, nothing else (a k_step pass in between costs
 // nothing).  Rewritten by plain stores the following product ran 1.5 / 1.6 / 2.7 / 3.9 / 11 %
