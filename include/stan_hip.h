@@ -167,12 +167,14 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
                            STAN_OPT_PLACEMENT_MAX_BYTES is reached or free device memory falls under 4 block
                            sizes; then the fastest real pairing is kept -- after one more attempt: the CG's
                            vectors are re-allocated beyond the held candidates and kept if that pairing is
-                           clear.  Second stage (a search that ends without a clear pairing, or a block with no
-                           rivals within the budget: 400^3): only the two vectors the products WRITE are
-                           re-allocated behind spacer blocks (free / 24, 1-8 GB each, same budget) until the real
-                           pairing is clear -- the place of the written vector alone decides.
-                           Environment, diagnosis only: STAN_PLACEMENT_TRACE=1 prints every probe on stderr,
-                           =sweep walks all spacers and keeps nothing, =stage2 enters the second stage anyway.
+                           clear.  Second stage, when that search ended without a clear pairing (also a block
+                           with no rivals within the budget: 400^3): blocks of free / 48 (1-4 GB, same budget)
+                           are allocated one after the other, the real pairing timed with the two vectors the
+                           products WRITE carved out of each, and the best place kept -- block and all -- if it
+                           is 1 % better than the pairing so far and 3 % clear of the reference: the place of
+                           the written vector alone decides.  Environment, diagnosis only:
+                           STAN_PLACEMENT_TRACE=1 prints every probe on stderr, =sweep walks the blocks
+                           whatever the first stage found and keeps nothing.
                            Only blocks of 256 MB and more are searched for; ~10 ms per candidate once
                            per context and size; the block pool keeps the winner; the results do not depend on
                            it.  Destroying a context detaches its matrices: they may be freed afterwards. */

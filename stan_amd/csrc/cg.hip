@@ -367,6 +367,7 @@ int stan_cg_workspace(stan_ctx *ctx, const stan_matrix *K) {
 }
 void stan_cg_workspace_free(stan_ctx *ctx) {
     stan_cg_ws &ws = ctx->ws;
+    if (ws.vw_owner) { stan_dfree(ctx, ws.vw_owner); ws.vw_owner = ws.v = ws.w = nullptr; }   // v, w carved out of one block
     for (double **q : {&ws.xb[0], &ws.xb[1], &ws.p, &ws.r, &ws.v, &ws.w, &ws.bh, &ws.sv}) {
         if (*q) stan_dfree(ctx, *q);
         *q = nullptr;
@@ -383,7 +384,7 @@ int stan_cg_workspace_move(stan_ctx *ctx, const stan_matrix *K, bool commit, sta
     if (saved && !commit && saved->p == nullptr) {          // step 1: swap fresh vectors in, keep the old ones in *saved
         if (!ws.p) return STAN_OK;
         *saved = ws;
-        stan_cg_ws nw;
+        stan_cg_ws nw;   // (nw.vw_owner stays null: eight blocks of their own)
         nw.ng = ws.ng; nw.n3 = ws.n3;
         bool ok = true;
         double **dst[8] = {&nw.xb[0], &nw.xb[1], &nw.p, &nw.r, &nw.v, &nw.w, &nw.bh, &nw.sv};
@@ -403,6 +404,7 @@ int stan_cg_workspace_move(stan_ctx *ctx, const stan_matrix *K, bool commit, sta
     // step 2: keep the new vectors (release the old ones for real) or go back to the old ones
     stan_cg_ws &drop = commit ? *saved : ws;
     stan_cg_ws keep = commit ? ws : *saved;
+    if (drop.vw_owner) { ctx->pool.live.erase((void *)drop.vw_owner); hipFree(drop.vw_owner); drop.vw_owner = drop.v = drop.w = nullptr; }
     for (double *q : {drop.xb[0], drop.xb[1], drop.p, drop.r, drop.v, drop.w, drop.bh, drop.sv}) {
         if (!q) continue;
         ctx->pool.live.erase((void *)q);
@@ -412,41 +414,36 @@ int stan_cg_workspace_move(stan_ctx *ctx, const stan_matrix *K, bool commit, sta
     if (commit && ctx->pool.enabled)   // the new blocks are pooled-class blocks from now on
         for (double *q : {ws.xb[0], ws.xb[1], ws.p, ws.r}) if ((size_t)ws.ng * 8 >= stan_pool::MIN_BYTES) ctx->pool.live[(void *)q] = (size_t)ws.ng * 8;
     if (commit && ctx->pool.enabled)
-        for (double *q : {ws.v, ws.w, ws.bh, ws.sv}) if ((size_t)ws.n3 * 8 >= stan_pool::MIN_BYTES) ctx->pool.live[(void *)q] = (size_t)ws.n3 * 8;
+        for (double *q : {ws.vw_owner ? (double *)nullptr : ws.v, ws.vw_owner ? (double *)nullptr : ws.w, ws.bh, ws.sv})
+            if (q && (size_t)ws.n3 * 8 >= stan_pool::MIN_BYTES) ctx->pool.live[(void *)q] = (size_t)ws.n3 * 8;
     saved->p = nullptr;
     return STAN_OK;
 }
 
 // Round 4 (tools/lab/spmv_steps_lab.cpp, profiles/r04/spmv_steps/): what makes a pairing slow is the vector the product
 // WRITES lying in the memory group of the values it reads -- the gather vector's place does not matter.  So the cheap move is
-// the two product buffers v and w alone.  step 0: fresh v, w straight from the driver (they lie beyond whatever the caller
-// holds allocated), the old ones parked in old[]; step 1: keep the new ones; step 2: back to the old ones.
-int stan_cg_products_move(stan_ctx *ctx, int step, double *old[2]) {
+// the two product buffers v and w alone, CARVED out of a block the caller has placed (a fresh small allocation would land in
+// whatever hole the allocator finds, not behind the caller's spacers).  set: v, w point into `block` (saved[] takes the old
+// v, w, owner) or, with block == nullptr, back to saved[]; adopt: the carved pair stays, `block` becomes its owner and the
+// saved pair is released.
+static int64_t vw_stride(const stan_cg_ws &ws) { return ((ws.n3 > 0 ? ws.n3 : 1) + 511) & ~(int64_t)511; }
+size_t stan_cg_products_bytes(const stan_ctx *ctx) { return (size_t)(2 * vw_stride(ctx->ws)) * 8; }
+void stan_cg_products_set(stan_ctx *ctx, double *block, double *saved[3]) {
     stan_cg_ws &ws = ctx->ws;
-    const size_t bytes = (size_t)(ws.n3 > 0 ? ws.n3 : 1) * 8;
-    if (step == 0) {
-        old[0] = old[1] = nullptr;
-        if (!ws.v || !ws.w) return STAN_OK;
-        double *nv = nullptr, *nw = nullptr;
-        if (hipMalloc((void **)&nv, bytes) != hipSuccess || hipMalloc((void **)&nw, bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            if (nv) hipFree(nv);
-            return STAN_OK;   // no memory for it: keep what we have
-        }
-        old[0] = ws.v; old[1] = ws.w;
-        ws.v = nv; ws.w = nw;
-        return STAN_OK;
-    }
-    if (!old[0]) return STAN_OK;
-    if (step == 1) {
-        for (int i = 0; i < 2; i++) { ctx->pool.live.erase((void *)old[i]); hipFree(old[i]); }
-        if (ctx->pool.enabled && bytes >= stan_pool::MIN_BYTES) { ctx->pool.live[(void *)ws.v] = bytes; ctx->pool.live[(void *)ws.w] = bytes; }
+    if (block) {
+        saved[0] = ws.v; saved[1] = ws.w; saved[2] = ws.vw_owner;
+        ws.v = block; ws.w = block + vw_stride(ws);
     } else {
-        hipFree(ws.v); hipFree(ws.w);
-        ws.v = old[0]; ws.w = old[1];
+        ws.v = saved[0]; ws.w = saved[1]; ws.vw_owner = saved[2];
     }
-    old[0] = old[1] = nullptr;
-    return STAN_OK;
+}
+void stan_cg_products_adopt(stan_ctx *ctx, double *block, size_t bytes, double *saved[3]) {
+    stan_cg_ws &ws = ctx->ws;
+    if (saved[2]) { ctx->pool.live.erase((void *)saved[2]); hipFree(saved[2]); }
+    else for (int i = 0; i < 2; i++) if (saved[i]) { ctx->pool.live.erase((void *)saved[i]); hipFree(saved[i]); }
+    ws.v = block; ws.w = block + vw_stride(ws); ws.vw_owner = block;
+    if (ctx->pool.enabled && bytes >= stan_pool::MIN_BYTES) ctx->pool.live[(void *)block] = bytes;
+    saved[0] = saved[1] = saved[2] = nullptr;
 }
 
 // Diagonal scaling of the matrix (once per matrix): A^ = S K S.

@@ -122,6 +122,7 @@ struct stan_cg_ws {
     int64_t ng = 0, n3 = 0;        // capacities: gather-sized (owned + pad + halo) / owned-sized, in doubles
     double *xb[2] = {nullptr, nullptr}, *p = nullptr, *r = nullptr;   // ng each
     double *v = nullptr, *w = nullptr, *bh = nullptr, *sv = nullptr;  // n3 each
+    double *vw_owner = nullptr;    // non-null: v and w are carved out of this one block (placement.hip, second stage): it is what gets freed
 };
 
 // ---- peer-to-peer exchanges of the one-process multi-GPU handle (p2p.hip) ---------------------
@@ -373,7 +374,9 @@ int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K);
 int stan_cg_workspace(stan_ctx *ctx, const stan_matrix *K);  // (re)allocates ctx->ws for K's sizes
 void stan_cg_workspace_free(stan_ctx *ctx);
 int stan_cg_workspace_move(stan_ctx *ctx, const stan_matrix *K, bool commit, stan_cg_ws *saved);
-int stan_cg_products_move(stan_ctx *ctx, int step, double *old[2]);   // v, w only (placement.hip, second stage)
+size_t stan_cg_products_bytes(const stan_ctx *ctx);   // bytes of a block that holds v and w
+void stan_cg_products_set(stan_ctx *ctx, double *block, double *saved[3]);   // v, w carved out of `block` (nullptr: back to saved[]); placement.hip, second stage
+void stan_cg_products_adopt(stan_ctx *ctx, double *block, size_t bytes, double *saved[3]);   // keep the carved pair for good, release the saved one
 
 // ---- recovery.hip ---------------------------------------------------------------------------
 int stan_recover_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz, const double *d_disp,

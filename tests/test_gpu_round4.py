@@ -452,8 +452,9 @@ def test_device_memory_does_not_grow_over_many_jobs():
 def test_placement_second_stage_moves_only_the_product_vectors(oracle):
     """placement.hip, second stage (round 4): when no candidate block is clear of the vectors' memory group, only the two
     vectors the products WRITE are re-allocated behind spacer blocks (tools/lab/spmv_steps_lab.cpp: the place of y alone
-    decides 1.00 or 1.13 ms).  Forced here (STAN_PLACEMENT_TRACE=stage2 enters the stage whatever the first found): the solve
-    that follows runs on the moved vectors and must give the bits of a solve without any search; the spacers are given back."""
+    decides 1.00 or 1.13 ms).  Whether the stage is entered and what it keeps depends on the box; here it is forced
+    (STAN_PLACEMENT_TRACE=stage2): the solve that follows runs on the carved vectors and must give the bits of a solve without
+    any search; the blocks are given back, the kept one with the context."""
     import torch
     from stan_amd import hip
     job = problem.cube_job(60)
@@ -466,7 +467,7 @@ def test_placement_second_stage_moves_only_the_product_vectors(oracle):
     ctx.close()
     torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info(0)[0]
-    os.environ["STAN_PLACEMENT_TRACE"] = "stage2"
+    os.environ["STAN_PLACEMENT_TRACE"] = "stage2"      # enter the stage and adopt its best block whatever it gains
     try:
         ctx = hip.Context(0)
         ctx.set_option(hip.OPT_PLACEMENT_TRIES, 4)
@@ -477,7 +478,7 @@ def test_placement_second_stage_moves_only_the_product_vectors(oracle):
         U2, rep2 = K2.cg_solve(job.F, 1e-8)
     finally:
         del os.environ["STAN_PLACEMENT_TRACE"]
-    assert prof["placement_candidates"] >= 1 and prof["placement_moved_vectors"] in (0, 2)
+    assert prof["placement_candidates"] >= 1 and prof["placement_moved_vectors"] == 2
     assert rep1 == rep0 and np.array_equal(U1, U0)
     assert rep2 == rep0 and np.array_equal(U2, U0)
     K.free(); K2.free()

@@ -447,6 +447,23 @@ int main(int argc, char **argv) {
         }
         return 0;
     }
+    if (argc > 2 && strstr(argv[2], "data")) {
+        // does the CONTENT of the value stream matter?  zeros (what a fresh block and this lab's other modes hold) against noise
+        printf("values all zero:      S0 %.4f  S2 %.4f  S4 %.4f ms\n", run<0>(nslices, nb, vals, cw, base, x, y, sink, 40),
+               run<2>(nslices, nb, vals, cw, base, x, y, sink, 40), run<4>(nslices, nb, vals, cw, base, x, y, sink, 40));
+        {
+            std::vector<double> h((size_t)1 << 24);
+            unsigned long long z = 88172645463325252ull;
+            for (double &d : h) { z ^= z << 13; z ^= z >> 7; z ^= z << 17; d = (double)(long long)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5; }
+            for (size_t o = 0; o < nv; o += h.size()) CK(hipMemcpy(vals + o, h.data(), std::min(h.size(), nv - o) * 8, hipMemcpyHostToDevice));
+        }
+        printf("values random fp64:   S0 %.4f  S2 %.4f  S4 %.4f ms\n", run<0>(nslices, nb, vals, cw, base, x, y, sink, 40),
+               run<2>(nslices, nb, vals, cw, base, x, y, sink, 40), run<4>(nslices, nb, vals, cw, base, x, y, sink, 40));
+        CK(hipMemset(vals, 0, nv * 8));
+        printf("values all zero again: S0 %.4f  S2 %.4f  S4 %.4f ms\n", run<0>(nslices, nb, vals, cw, base, x, y, sink, 40),
+               run<2>(nslices, nb, vals, cw, base, x, y, sink, 40), run<4>(nslices, nb, vals, cw, base, x, y, sink, 40));
+        return 0;
+    }
     // argv[2]: comma-separated steps (default: all), argv[3]: timed launches per step (default 40)
     bool want[37];
     for (int i = 0; i < 37; i++) want[i] = argc <= 2 && i != 31 && i != 32;
