@@ -1190,23 +1190,31 @@ int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, size_t byte
     HIPCHK(ctx, hipMemcpyAsync(stt, init, sizeof(init), hipMemcpyHostToDevice, st_));
     hipLaunchKernelGGL(k_fill, dim3(vec_grid(ng)), dim3(VEC_T), 0, st_, x, ng, 1.0);
     event_bag ev;
-    float t[3] = {0, 0, 0};
-    for (int r = 0; r < 4; r++) {
-        hipEvent_t a = ev.make(), b = ev.make();
-        hipEventRecord(a, st_);
+    // one launch to warm up, then two groups of three launches back to back, the faster group counts.  (Round 4: single
+    // launches between host synchronisations -- the first form of this probe -- start on an idle device and read 2-3 %
+    // under the same product inside a sequence of kernels.)
+    auto one = [&]() {
         if (precision == STAN_PREC_FIXED48)
             launch_spmv<uint32_t, 1>(ctx, K, (const uint32_t *)vals, x, y, partial, stt, 1);
         else if (precision == STAN_PREC_MIXED)
             launch_spmv<float, 1>(ctx, K, (const float *)vals, x, y, partial, stt, 1);
         else
             launch_spmv<double, 1>(ctx, K, (const double *)vals, x, y, partial, stt, 1);
+    };
+    one();
+    float best = 0;
+    for (int g = 0; g < 2; g++) {
+        hipEvent_t a = ev.make(), b = ev.make();
+        hipEventRecord(a, st_);
+        for (int r = 0; r < 3; r++) one();
         hipEventRecord(b, st_);
         HIPCHK(ctx, hipEventSynchronize(b));
-        if (r > 0) hipEventElapsedTime(&t[r - 1], a, b);
+        float t = 0;
+        hipEventElapsedTime(&t, a, b);
+        if (g == 0 || t < best) best = t;
     }
     HIPCHK(ctx, hipGetLastError());
-    const float lo = t[0] < t[1] ? t[0] : t[1], hi = t[0] < t[1] ? t[1] : t[0];
-    *ms_out = t[2] < lo ? lo : (t[2] > hi ? hi : t[2]);
+    *ms_out = best / 3;
     return STAN_OK;
 }
 
