@@ -177,7 +177,10 @@ int stan_dmalloc_streamed(stan_ctx *ctx, void **p, size_t bytes,
     // Only when the first stage did not end on a clear pairing.  (A thorough form -- the first stage going on until a pairing
     // is 7 % clear, this stage always walking its blocks -- found probes of 1.00-1.02 ms where the ordinary search keeps
     // 1.02-1.03, and the solves ran no faster: 1.020-1.043 ms per product in the CG against 1.021-1.027, four runs each on
-    // one box.  A probe is a launch on an idle device; it ranks places, it does not resolve the last two percent.)
+    // one box.  With the probe timing launches back to back, twelve alternating runs each: five more candidates after the
+    // first clear one change nothing (1.032-1.035 ms either way; the 1.00 ms pairings of a box come with the process, not with
+    // the search); this stage walking its blocks after every search, keeping nothing, makes the solve 1 % SLOWER (1.013-1.016
+    // against 1.004-1.007 ms: what is allocated afterwards lands elsewhere) -- profiles/r04/placement/extra_candidates_and_always_stage2_ab.txt.)
     if ((sweep || force2 || (!clear && !ctx->prof_placement_moved_vectors)) && tself[ibest] > 0 && ctx->ws.v && ctx->ws.w) {
         std::vector<void *> blocks;
         std::vector<float> tb;
