@@ -439,6 +439,19 @@ int main(int argc, char **argv) {
             const float b = run<4>(nslices, nb, vals, cw, base, x, sp[i] + ((size_t)4 << 27), sink, 20);   // 4 GB further in
             printf("  y in spacer %2zu (%p): %.4f ms   4 GB further in: %.4f ms\n", i, (void *)sp[i], a, b);
         }
+        // the column words moved (y in the best place found above, x where it was)
+        {
+            size_t jb = 0; float tbest = 1e30f;
+            for (size_t i = 0; i < sp.size(); i++) { const float t = run<4>(nslices, nb, vals, cw, base, x, sp[i], sink, 10); if (t < tbest) { tbest = t; jb = i; } }
+            printf("  best y: spacer %zu (%.4f ms); column words copied into other spacers:\n", jb, tbest);
+            for (size_t i = 0; i < sp.size(); i += 2) {
+                if (i == jb) continue;
+                uint32_t *cw2 = (uint32_t *)(sp[i] + ((size_t)1 << 27));
+                (void)hipMemcpy(cw2, cw, (size_t)nslices * 14 * 64 * 4, hipMemcpyDeviceToDevice);
+                printf("    column words in spacer %2zu: %.4f ms\n", i, run<4>(nslices, nb, vals, cw2, base, x, sp[jb], sink, 20));
+            }
+            printf("    column words where they were: %.4f ms\n", run<4>(nslices, nb, vals, cw, base, x, sp[jb], sink, 20));
+        }
         // and x (the gather vector) moved instead, y where it was
         for (size_t i = 0; i < sp.size(); i += 4) {
             (void)hipMemset(sp[i], 0, (size_t)(nslices * 64LL + 64) * 3 * 8);
