@@ -20,6 +20,8 @@ if spec.startswith("fuzz:"):   # tests/fuzz.py job: shuffled wire order, several
 elif spec.startswith("rev:"):  # a solid of revolution: collapsed hexes and a high-valence axis (the assembly's slow paths on a shard)
     from tests import fuzz
     job = fuzz.random_revolved_job(int(spec[4:]))
+elif spec.startswith("bench:"):   # the bench-mode job of a golden fixture (tests/golden/bench_mode_<n>.npz): no jitter
+    job = problem.cube_job(int(spec[6:]))
 else:
     job = problem.cube_job(int(spec), jitter=0.05)
 ctx = hip.Context(0)
@@ -33,6 +35,16 @@ if p2p:
     ctx.set_profiling(True)
 K = ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
 info = K.info()
+if spec.startswith("bench:"):     # bench mode: merit stop off, 1e-8, fp64 only; the whole U comes back on every rank
+    ctx.set_option(hip.OPT_CG_MERIT_STOP, 0)
+    U, rep = K.cg_solve(job.F, 1e-8)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), U=U, its=rep["iterations"], term=rep["terminationtype"],
+             rows=np.array([info["row_begin"], info["row_end"], info["n_halo"]]))
+    K.free()
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0)
 res = {}
 for tag, eps, prec in (("fp64", 1e-6, hip.PREC_FP64), ("mixed", 1e-5, hip.PREC_MIXED),
                        ("fixed48", 1e-6, hip.PREC_FIXED48)):

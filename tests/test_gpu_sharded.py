@@ -86,6 +86,30 @@ def test_sharded_solve_matches_oracle(built_libs, oracle, tmp_path, world, overl
     assert all(r[2] > 0 for r in rows if r[1] > r[0])     # every rank that owns rows has a halo
 
 
+@pytest.mark.parametrize("n,world,p2p", [(100, 2, False), (100, 4, False), (100, 2, True), (148, 2, False), (148, 3, True)])
+def test_sharded_bench_mode_against_the_oracle_fixture(built_libs, tmp_path, n, world, p2p):
+    """BASELINE config 4 in miniature: the rows of the 100^3 cube (config 2's size, 3 M DOF) and of the 148^3 cube (the
+    headline's 10 M DOF) partitioned over 2 / 3 / 4 ranks -- here all on the one GPU, over the test transport, RCCL-shaped
+    exchanges and peer-to-peer mailboxes -- in bench mode (merit stop off, 1e-8) against the ORACLE's committed answer
+    (tests/golden/bench_mode_<n>.npz): iterations within 2,
+    max |dU| / max |U| <= 1e-9 at the 4096 sampled DOFs, the norms; every rank returns the same bits."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "bench_mode_%d.npz" % n))
+    args = [os.path.join(ROOT, "tests", "sharded_worker.py"), "bench:%d" % n, str(tmp_path), "1"] + (["p2p"] if p2p else [])
+    out = _torchrun(world, args, {"GPU_MAX_HW_QUEUES": str(2 * world + 4)} if p2p else {})
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    r0 = np.load(os.path.join(str(tmp_path), "rank0.npz"))
+    um = float(g["u_max"])
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert int(d["term"]) == int(g["terminationtype"]) == 1
+        assert abs(int(d["its"]) - int(g["iterations"])) <= 2, (int(d["its"]), int(g["iterations"]))
+        assert d["U"].shape[0] == int(g["n_red"])
+        assert np.abs(d["U"][g["idx"]] - g["U"]).max() <= 1e-9 * um
+        assert abs(np.sqrt(d["U"] @ d["U"]) - float(g["u_l2"])) <= 1e-9 * float(g["u_l2"])
+        assert np.array_equal(d["U"], r0["U"])
+        assert d["rows"][2] > 0                                  # a halo on every rank
+
+
 @pytest.mark.parametrize("world,spec", [(2, "12"), (3, "12"), (4, "fuzz:124")])
 def test_sharded_solve_peer_to_peer_between_processes(built_libs, tmp_path, world, spec):
     """STAN_OPT_COMM_P2P with one PROCESS per rank (what bench.py --gpus N --p2p runs under the launcher): the
