@@ -58,7 +58,10 @@
 
 namespace {
 
-constexpr int VEC_BLOCKS = 2048;  // grid of the streaming vector kernels (8 blocks per CU)
+#ifndef STAN_VEC_BLOCKS
+#define STAN_VEC_BLOCKS 2048
+#endif
+constexpr int VEC_BLOCKS = STAN_VEC_BLOCKS;  // grid of the streaming vector kernels (2048 = 8 blocks per CU)
 constexpr int VEC_T = 256;
 constexpr int CHUNK = 32;         // iterations enqueued between two status polls
 constexpr int CHUNK_DIST = 8;     // ... of a sharded loop
