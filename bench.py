@@ -348,6 +348,11 @@ def main():
     ap.add_argument("--placement-fraction", type=float, default=0.75,
                     help="fraction of the free device memory the placement search may hold while it runs "
                          "(STAN_OPT_PLACEMENT_MAX_BYTES; 0 = the library's default, a quarter)")
+    ap.add_argument("--pool-fraction", type=float, default=0.9,
+                    help="fraction of the free device memory the context's block pool may keep parked between steps "
+                         "(STAN_OPT_POOL_MAX_BYTES; the library's own default -- half the device -- is for a library "
+                         "inside a foreign host; this process owns its GPU.  At 400^3 the fp64 values and their fp32 "
+                         "copy are 126 + 63 GB: with half the device one of them went back to the driver every step)")
     ap.add_argument("--p2p", action="store_true",
                     help="STAN_OPT_COMM_P2P (N > 1): the CG's reductions and halo exchanges go peer to peer between the "
                          "rank processes (HIP IPC mappings; no RCCL launch in the loop) instead of over RCCL")
@@ -427,6 +432,8 @@ def main():
     if args.placement_fraction > 0 and not os.environ.get("STAN_BENCH_DEVICE"):   # (ranks sharing one GPU in the tests: default)
         placement_budget = int(args.placement_fraction * torch.cuda.mem_get_info(dev)[0])
         ctx.set_option(hip.OPT_PLACEMENT_MAX_BYTES, placement_budget)
+    if args.pool_fraction > 0 and not os.environ.get("STAN_BENCH_DEVICE"):
+        ctx.set_option(hip.OPT_POOL_MAX_BYTES, int(args.pool_fraction * torch.cuda.mem_get_info(dev)[0]))
     if args.single_reduce:
         ctx.set_option(hip.OPT_CG_SINGLE_REDUCE, 1)
     if args.sell_sigma > 0:

@@ -340,6 +340,10 @@ typedef struct stan_matrix_info {
                                       walks 16 % fewer slots than in the padded layout); known after the first solve */
 } stan_matrix_info;
 int stan_hip_matrix_info(stan_matrix *K, stan_matrix_info *out);
+/* The same for ONE shard of a matrix assembled on a multi-device handle (stan_hip_init_multi): part = rank
+ * 0 .. n_devices-1; row_begin / row_end / n_halo / n_blocks are that rank's (the halo block rows it receives per
+ * product: SURVEY.md section 8e).  On an ordinary matrix part must be 0 and the call is stan_hip_matrix_info. */
+int stan_hip_matrix_part_info(stan_matrix *K, int32_t part, stan_matrix_info *out);
 
 /* K_e of one element (debug/parity; Element.cs:118-155): 24x24 row-major into out[576]. */
 int stan_hip_ke_hex8(stan_ctx *ctx, const double xyz8[24], double E, double nu, int32_t type,
@@ -410,6 +414,12 @@ typedef struct stan_profile {
 } stan_profile;
 int stan_hip_set_profiling(stan_ctx *ctx, int32_t enabled);
 int stan_hip_get_profile(stan_ctx *ctx, stan_profile *out);
+/* The profile of ONE rank of a multi-device handle (stan_hip_get_profile reports rank 0's); rank must be 0 on an
+ * ordinary context. */
+int stan_hip_get_profile_rank(stan_ctx *ctx, int32_t rank, stan_profile *out);
+/* Which physical device a rank drives: HIP ordinal and PCI bus id ("0000:c1:00.0"; bus_id [32], either may be NULL).
+ * bench.py prints them next to a multi-GPU line. */
+int stan_hip_device_info(stan_ctx *ctx, int32_t rank, int32_t *hip_ordinal, char bus_id[32]);
 
 #ifdef __cplusplus
 }

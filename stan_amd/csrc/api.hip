@@ -187,6 +187,29 @@ int stan_hip_set_profiling(stan_ctx *ctx, int32_t enabled) {
     ctx->profiling = enabled != 0;
     return STAN_OK;
 }
+int stan_hip_get_profile_rank(stan_ctx *ctx, int32_t rank, stan_profile *out) {
+    if (!ctx || !out || rank < 0) return STAN_E_ARG;
+    if (ctx->group) {
+        if (rank >= stan_group_size(ctx)) return STAN_E_ARG;
+        return stan_hip_get_profile(stan_group_rank(ctx, rank), out);
+    }
+    if (rank != 0) return STAN_E_ARG;
+    return stan_hip_get_profile(ctx, out);
+}
+int stan_hip_device_info(stan_ctx *ctx, int32_t rank, int32_t *hip_ordinal, char bus_id[32]) {
+    if (!ctx || rank < 0) return STAN_E_ARG;
+    stan_ctx *c = ctx;
+    if (ctx->group) {
+        if (rank >= stan_group_size(ctx)) return STAN_E_ARG;
+        c = stan_group_rank(ctx, rank);
+    } else if (rank != 0) return STAN_E_ARG;
+    if (hip_ordinal) *hip_ordinal = c->device;
+    if (bus_id) {
+        bus_id[0] = 0;
+        if (hipDeviceGetPCIBusId(bus_id, 32, c->device) != hipSuccess) { (void)hipGetLastError(); bus_id[0] = 0; }
+    }
+    return STAN_OK;
+}
 int stan_hip_get_profile(stan_ctx *ctx, stan_profile *out) {
     if (!ctx || !out) return STAN_E_ARG;
     if (ctx->group) ctx = stan_group_rank0(ctx);   // rank 0's timings; spmv_bytes is that shard's
@@ -441,6 +464,13 @@ int stan_hip_nodal_forces_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz
     if (R) HIPCHK(ctx, hipMemcpyAsync(R, dR.p, (size_t)n_dof * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return STAN_OK;
+}
+
+int stan_hip_matrix_part_info(stan_matrix *K, int32_t part, stan_matrix_info *o) {
+    if (!K || !o || part < 0) return STAN_E_ARG;
+    if (K->parts.empty()) return part == 0 ? stan_hip_matrix_info(K, o) : STAN_E_ARG;
+    if ((size_t)part >= K->parts.size()) return STAN_E_ARG;
+    return stan_hip_matrix_info(K->parts[(size_t)part], o);
 }
 
 int stan_hip_matrix_info(stan_matrix *K, stan_matrix_info *o) {

@@ -484,6 +484,7 @@ int stan_group_recover(stan_ctx *lead, int64_t n_nodes, const double *xyz, const
 int stan_group_set_p2p(stan_ctx *lead, bool on);
 int stan_group_rank0_call(stan_ctx *lead, const std::function<int(stan_ctx *)> &fn);
 stan_ctx *stan_group_rank0(stan_ctx *lead);
+stan_ctx *stan_group_rank(stan_ctx *lead, int r);
 int stan_group_size(stan_ctx *lead);
 // entry points that have no meaning for a group handle (device pointers, single-rank helpers)
 #define STAN_NO_GROUP(ctx, what)                                                                   \

@@ -405,4 +405,5 @@ int stan_group_rank0_call(stan_ctx *lead, const std::function<int(stan_ctx *)> &
 }
 
 stan_ctx *stan_group_rank0(stan_ctx *lead) { return lead->group->ctx[0]; }
+stan_ctx *stan_group_rank(stan_ctx *lead, int r) { return lead->group->ctx[(size_t)r]; }
 int stan_group_size(stan_ctx *lead) { return (int)lead->group->ctx.size(); }

@@ -44,6 +44,7 @@ EXPORTS = [
     "stan_hip_set_profiling", "stan_hip_get_profile", "stan_hip_set_option", "stan_hip_recover_hex8", "stan_hip_recover_hex8_dev",
     "stan_hip_nodal_forces_hex8", "stan_hip_pool_info",
     "stan_hip_matrix_plan", "stan_hip_spmv_local", "stan_hip_comm_info",
+    "stan_hip_matrix_part_info", "stan_hip_get_profile_rank", "stan_hip_device_info",
 ]
 # only in the lab build (stan_amd/csrc/lab/stan_hip_lab.h, selected with STAN_HIP_LIB)
 LAB_EXPORTS = ["stan_hip_csr_spmv_bench", "stan_hip_lab_placement_map", "stan_hip_lab_placement_variants", "stan_hip_lab_placement_alloc", "stan_hip_lab_placement_rounds", "stan_hip_lab_placement_cross", "stan_hip_lab_incg_penalty", "stan_hip_lab_placement_vecalloc", "stan_hip_lab_placement_vecshape", "stan_hip_lab_pairing_pmc"]
@@ -167,6 +168,18 @@ class Context:
         p = Profile()
         self._chk(self.lib.stan_hip_get_profile(self.h, C.byref(p)))
         return {k: getattr(p, k) for k, _ in Profile._fields_}
+
+    def profile_rank(self, rank):
+        """Profile of one rank of a multi-device handle (profile() reports rank 0's)."""
+        p = Profile()
+        self._chk(self.lib.stan_hip_get_profile_rank(self.h, C.c_int32(rank), C.byref(p)))
+        return {k: getattr(p, k) for k, _ in Profile._fields_}
+
+    def device_info(self, rank=0):
+        """(HIP ordinal, PCI bus id) of the device a rank drives."""
+        o, b = C.c_int32(-1), C.create_string_buffer(32)
+        self._chk(self.lib.stan_hip_device_info(self.h, C.c_int32(rank), C.byref(o), b))
+        return o.value, b.value.decode()
 
     def pool_info(self):
         """(bytes, blocks) of device memory the context keeps parked for reuse (OPT_POOL)."""
@@ -305,6 +318,12 @@ class Matrix:
     def info(self):
         i = MatrixInfo()
         self.ctx._chk(self.ctx.lib.stan_hip_matrix_info(self.k, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in MatrixInfo._fields_}
+
+    def part_info(self, part):
+        """info() of one shard of a matrix on a multi-device handle."""
+        i = MatrixInfo()
+        self.ctx._chk(self.ctx.lib.stan_hip_matrix_part_info(self.k, C.c_int32(part), C.byref(i)))
         return {k: getattr(i, k) for k, _ in MatrixInfo._fields_}
 
     def cg_solve(self, F, eps_f, max_its=0, precision_mode=PREC_FP64):

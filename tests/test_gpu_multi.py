@@ -156,3 +156,52 @@ def test_more_ranks_than_slices_through_the_group_handle(built_libs, oracle, tmp
     assert int(d["term"]) == int(d["term_s"]) == rep["terminationtype"] == 1
     for key in ("U", "Ux", "Us"):
         assert np.abs(d[key] - Uo).max() <= 1e-4 * np.abs(Uo).max(), key
+
+
+@pytest.mark.parametrize("transport", ["rccl", "p2p"])
+def test_config4_200_cubed_on_8_ranks_against_the_oracle_fixture(built_libs, tmp_path, transport):
+    """BASELINE.json config 4 -- "200^3 cube row-partitioned across 8 x MI355X, RCCL dot-allreduce + SpMV halo" -- at its
+    own size and rank count (Solver.cs:156-162 are the two calls it replaces): one process, eight
+    ranks through stan_hip_init_multi, bench mode, against the oracle's committed answer (tests/golden/bench_mode_200.npz:
+    iterations within 2, max |dU| / max |U| <= 1e-9).  Every rank reports the same iteration count and code, the
+    device-derived halo of every rank equals the host plan's (tests/test_partition_plan.py: 30 k - 111 k block rows per
+    neighbour), the RCCL-shaped loop makes two collectives per iteration and the peer-to-peer loop none."""
+    import torch
+    from stan_amd import host
+    golden = os.path.join(ROOT, "tests", "golden", "bench_mode_200.npz")
+    if not os.path.exists(golden):
+        pytest.skip("fixture bench_mode_200.npz not generated")
+    if torch.cuda.mem_get_info(0)[0] < 60e9:
+        pytest.skip("GPU has %.0f GB free: eight shards of the 200^3 matrix with their node arrays need ~40 GB"
+                    % (torch.cuda.mem_get_info(0)[0] / 1e9))
+    n, nranks = 200, 8
+    out = str(tmp_path / "config4.npz")
+    env = dict(os.environ, STAN_RCCL_LIB=FAKE, GPU_MAX_HW_QUEUES=str(2 * nranks + 4))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "config4_worker.py"), str(n), str(nranks), transport, golden, out],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    print(p.stdout[-400:])
+    d, g = np.load(out), np.load(golden)
+    assert int(d["term"]) == int(g["terminationtype"]) == 1
+    assert abs(int(d["its"]) - int(g["iterations"])) <= 2, (int(d["its"]), int(g["iterations"]))
+    assert float(d["rel"]) <= float(g["eps"])
+    um = float(g["u_max"])
+    assert np.abs(d["U_at_idx"] - g["U"]).max() <= 1e-9 * um
+    assert abs(float(d["u_max"]) - um) <= 1e-9 * um
+    assert abs(float(d["u_l2"]) - float(g["u_l2"])) <= 1e-9 * float(g["u_l2"])
+    # every rank took the same decisions
+    assert np.all(d["its_rank"] == d["its"]) and np.all(d["term_rank"] == 1)
+    # the shards: the host plan's rows and halos, entry by entry
+    job = problem.cube_job(n)
+    for r in range(nranks):
+        plan = host.partition_plan(job.node_index, job.conn, nranks, r)
+        assert int(d["row_begin"][r]) == int(plan["row_starts"][r]) and int(d["row_end"][r]) == int(plan["row_starts"][r + 1])
+        assert int(d["halo_rows"][r]) == len(plan["halo_glob"])
+        per_nbr = np.diff(plan["recv_off"])
+        assert len(plan["nbr"]) <= 2 and 25_000 <= per_nbr.min() and per_nbr.max() <= 120_000
+    assert int(d["n_blocks"].sum()) == (3 * n + 1) ** 3
+    its = int(d["its"])
+    if transport == "rccl":
+        assert np.all(d["waits"] == 0) and np.all(d["coll"] >= 2 * its)
+    else:
+        assert np.all(d["coll"] == 0) and np.all(d["waits"] >= 2 * its)
