@@ -109,6 +109,7 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
  *   17 STAN_OPT_SELL_SIGMA           1     SELL-C-sigma sorting window in slices
  *   18 STAN_OPT_COMM_P2P             0     sharded CG exchanges peer to peer instead of over RCCL
  *   19 STAN_OPT_ROW_FOLDING          -1    folded rows on irregular meshes (auto)
+ *   20 STAN_OPT_CG_REFINE            1     reduced-precision streams: 0 fp64 check only, 1 + refinement passes, 2 + fp64 refresh
  * The descriptions follow in the order the options were added.
  *   STAN_OPT_CG_MERIT_STOP  1 (default): stop with type 7 when the merit function x'Ax-2b'x
  *                           no longer decreases (rounding floor, ~1e-7 relative residual on
@@ -222,6 +223,22 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
                            rank-ordered all-reduce); boundary rows are written straight into the neighbours' gather
                            vectors.  Needs peer access between all devices of the handle (STAN_E_UNSUPPORTED
                            otherwise; also on a handle with more than 16 ranks). */
+#define STAN_OPT_CG_REFINE 20 /* STAN_PREC_MIXED / STAN_PREC_FIXED48 only (the fp64 stream is alglib's loop as it is).  The
+                           loop of such a solve iterates on a ROUNDED copy of S K S; its own residual recurrence says nothing
+                           about K.  Every such solve therefore ends with ONE product on the fp64 values (they stay resident
+                           next to their copy): r_t = S F - (S K S) x^, and rel_residual reports ||r_t|| / ||S F||.  Measured
+                           before this existed: fp32 copy, 400^3, "type 1 at 9.9e-9" for an answer whose fp64 residual was
+                           1.3e-3 (kappa-amplified rounding of the entries).
+                           0: check only -- a solve whose recurrence met eps_f while r_t does not returns type 7 (no further
+                              progress at this precision), never type 1.
+                           1 (default): iterative refinement -- while r_t misses eps_f, another pass of the same loop solves
+                              (S K S) d = r_t on the reduced-precision stream to ||r|| <= eps_f ||S F|| and x^ += d in fp64; at
+                              most 8 passes, stopped with type 7 when a pass does not halve r_t, type 5 at max_its (counted
+                              over all passes); iterations = the sum.
+                           2: as 1, and the loop's periodic residual recomputation (STAN_OPT_CG_RUPDATE, every 10th
+                              iteration) multiplies with the fp64 values ("reliable updates": the recurrence is re-anchored to
+                              the true residual while the Krylov directions are kept; costs one fp64 product per 10
+                              reduced-precision ones instead of the fused two-product pass). */
 #define STAN_OPT_POOL 7 /* 1 (default): device blocks >= 8 MB freed by the library stay with the
                            context and are reused by its next allocations (a hipMalloc of tens of GB
                            costs 0.4-1.8 s here); 0: release them now, plain hipMalloc/hipFree from then on */
@@ -282,8 +299,10 @@ void stan_hip_matrix_free(stan_matrix *K);
  * eps_f / max_its = Analysis.LinSolverTolerance / LinSolverIterMax (Analysis.cs:10-11),
  * both zero -> eps_f = 1e-6 (lincgsetcond).  termination_type: 1 converged, 5 max_its,
  * 7 no further progress (best point returned), -5 not SPD, -4 overflow.
- * rel_residual = ||r||/||b|| of the diagonally scaled system at exit.  Any out pointer
- * except U may be NULL. */
+ * rel_residual = ||r||/||b|| of the diagonally scaled system at exit: for STAN_PREC_FP64 the loop's own recurrence
+ * (what alglib reports); for STAN_PREC_MIXED / STAN_PREC_FIXED48 the residual of the returned point under the FP64
+ * matrix, from one extra product (STAN_OPT_CG_REFINE; stan_profile keeps both).  Type 1 is only ever reported with
+ * rel_residual <= eps_f.  Any out pointer except U may be NULL. */
 int stan_hip_cg_solve(stan_ctx *ctx, stan_matrix *K, const double *F, double eps_f,
                       int32_t max_its, int32_t precision_mode, double *U,
                       int32_t *termination_type, int32_t *iterations, double *rel_residual);
@@ -370,6 +389,10 @@ int stan_hip_matrix_plan(stan_ctx *ctx, stan_matrix *K, int64_t *row_starts, int
  * columns in plan order (host pointers; the UNSCALED matrix, i.e. before any solve). */
 int stan_hip_spmv_local(stan_ctx *ctx, stan_matrix *K, const double *x_local, double *y_owned);
 
+/* diag [N] = K_ii of the reduced system (the unscaled K; alglib's lincg takes its Jacobi scaling s_i = 1/sqrt(K_ii) from
+ * it, SolverFunctions.cs:300-305): with it a host can form the scaled residual S (F - K U) the solver reports.  Single-rank
+ * contexts only. */
+int stan_hip_matrix_diagonal(stan_ctx *ctx, stan_matrix *K, double *diag);
 /* y = K x on the reduced system (host x,y of length N); single-rank contexts only. */
 int stan_hip_spmv(stan_ctx *ctx, stan_matrix *K, const double *x, double *y);
 /* Timing helper for the roofline: `reps` back-to-back launches of the CG's SpMV kernel on
@@ -411,6 +434,11 @@ typedef struct stan_profile {
     int64_t comm_reduce_calls;        /*   over this many reduction points (RCCL all-reduce launches or peer-to-peer waits)   */
     double comm_halo_ms_total;        /* the same for the halo exchanges (pack + send/recv, or pack + peer-to-peer wait)     */
     int64_t comm_halo_calls;
+    double rel_residual_recurrence;   /* ||r|| / ||b|| of the loop's own recurrence at exit (all streams) */
+    double rel_residual_fp64;         /* reduced-precision streams: ||S F - (S K S) x^|| / ||S F|| with the fp64 values; fp64 stream: -1 */
+    int32_t refine_passes;            /* passes of the loop the last solve made (1: no refinement pass was needed) */
+    int32_t fp64_products;            /* products with the fp64 values inside a reduced-precision solve (checks, STAN_OPT_CG_REFINE = 2 refreshes) */
+    double fp64_products_ms;          /* their stream time, not part of spmv_ms_total */
 } stan_profile;
 int stan_hip_set_profiling(stan_ctx *ctx, int32_t enabled);
 int stan_hip_get_profile(stan_ctx *ctx, stan_profile *out);

@@ -63,6 +63,11 @@ namespace STAN_Solver
         public long comm_reduce_calls;
         public double comm_halo_ms_total;
         public long comm_halo_calls;
+        public double rel_residual_recurrence;
+        public double rel_residual_fp64;
+        public int refine_passes;
+        public int fp64_products;
+        public double fp64_products_ms;
     }
 
     internal static class StanHipNative
@@ -82,7 +87,7 @@ namespace STAN_Solver
                            STAN_OPT_CG_SINGLE_REDUCE = 10, STAN_OPT_CG_FOLD_REDUCE = 11, STAN_OPT_VEC_STORE_NT = 12,
                            STAN_OPT_PACKED_COLUMNS = 13, STAN_OPT_CG_DEFER_X = 14, STAN_OPT_SPMV_SMALL = 15,
                            STAN_OPT_PLACEMENT_MAX_BYTES = 16, STAN_OPT_SELL_SIGMA = 17, STAN_OPT_COMM_P2P = 18,
-                           STAN_OPT_ROW_FOLDING = 19;
+                           STAN_OPT_ROW_FOLDING = 19, STAN_OPT_CG_REFINE = 20;
 
         // ---- context
         [DllImport(Lib)] internal static extern int stan_hip_init(int device, out IntPtr ctx);
@@ -132,6 +137,8 @@ namespace STAN_Solver
 
         // ---- introspection / parity helpers
         [DllImport(Lib)] internal static extern int stan_hip_matrix_info(IntPtr K, out StanMatrixInfo info);
+        [DllImport(Lib)] internal static extern int stan_hip_matrix_diagonal(IntPtr ctx, IntPtr K, [Out] double[] diag);
+        [DllImport(Lib)] internal static extern int stan_hip_matrix_part_info(IntPtr K, int part, out StanMatrixInfo info);
         [DllImport(Lib)] internal static extern int stan_hip_ke_hex8(IntPtr ctx, double[] xyz8, double E, double nu, int type, [Out] double[] ke576);
         [DllImport(Lib)] internal static extern int stan_hip_ke_hex8_batch(IntPtr ctx, long n, double[] xyz8, double E, double nu, byte[] type, [Out] double[] ke);
         [DllImport(Lib)] internal static extern int stan_hip_matrix_to_csr(IntPtr ctx, IntPtr K, int upper_only, ref long nnz, [Out] long[] rowptr, [Out] int[] col, [Out] double[] val);
@@ -143,6 +150,8 @@ namespace STAN_Solver
         [DllImport(Lib)] internal static extern int stan_hip_spmv_bench(IntPtr ctx, IntPtr K, int precision_mode, int reps, out double avg_ms);
         [DllImport(Lib)] internal static extern int stan_hip_set_profiling(IntPtr ctx, int enabled);
         [DllImport(Lib)] internal static extern int stan_hip_get_profile(IntPtr ctx, out StanProfile profile);
+        [DllImport(Lib)] internal static extern int stan_hip_get_profile_rank(IntPtr ctx, int rank, out StanProfile profile);
+        [DllImport(Lib)] internal static extern int stan_hip_device_info(IntPtr ctx, int rank, out int hip_ordinal, [Out] byte[] bus_id);
     }
 
     /// Owner of the context and of K (library-owned objects, explicit free).  One per solve in the reference's

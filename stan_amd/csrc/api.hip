@@ -122,6 +122,7 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
     else if (option == STAN_OPT_CG_FUSED_REFRESH) ctx->cg_fused_refresh = value != 0;
     else if (option == STAN_OPT_CG_SINGLE_REDUCE) ctx->cg_single_reduce = value != 0;
     else if (option == STAN_OPT_CG_FOLD_REDUCE) ctx->cg_fold_reduce = value != 0;
+    else if (option == STAN_OPT_CG_REFINE && value >= 0 && value <= 2) ctx->cg_refine = (int)value;
     else if (option == STAN_OPT_VEC_STORE_NT && value >= 0 && value <= 3) ctx->vec_store_nt = (int)value;
     else if (option == STAN_OPT_PACKED_COLUMNS) ctx->cols16 = value != 0;
     else if (option == STAN_OPT_CG_DEFER_X) ctx->cg_defer_x = value != 0;
@@ -582,6 +583,19 @@ int stan_hip_spmv(stan_ctx *ctx, stan_matrix *K, const double *x, double *y) {
     STANCHK(dy.alloc(ctx, N));
     STANCHK(stan_spmv_reduced(ctx, K, dx.p, dy.p));
     if (N) HIPCHK(ctx, hipMemcpyAsync(y, dy.p, N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return STAN_OK;
+}
+
+int stan_hip_matrix_diagonal(stan_ctx *ctx, stan_matrix *K, double *diag) {
+    if (!ctx || !K || !diag || K->ctx != ctx) return STAN_E_ARG;
+    STAN_NO_GROUP(ctx, "matrix_diagonal");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t N = (size_t)K->n_red;
+    dbuf<double> dd;
+    STANCHK(dd.alloc(ctx, N ? N : 1));
+    STANCHK(stan_matrix_diagonal(ctx, K, dd.p));
+    if (N) HIPCHK(ctx, hipMemcpyAsync(diag, dd.p, N * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return STAN_OK;
 }

@@ -71,7 +71,9 @@ enum { S_BNORM = 0, S_VMV = 1, S_R2NEW = 2, S_MERIT = 3, S_RHO0 = 4, S_RHO1 = 5,
        S_PMF1 = 7, S_R2OUT = 8,
        // single-reduction loop: the three sums of one iteration are contiguous (ONE all-reduce)
        S_SR_GAMMA = 9, S_SR_DELTA = 10, S_SR_MERIT = 11, S_SR_GP0 = 12, S_SR_GP1 = 13, S_SR_AP0 = 14,
-       S_SR_AP1 = 15, S_NSCAL = 24 };
+       S_SR_AP1 = 15,
+       // fp64 check of a reduced-precision solve: ||b - A64 x||^2 and the merit sum of the same pass
+       S_CHK_R2 = 16, S_CHK_MF = 17, S_NSCAL = 24 };
 // device status slots (int64)
 enum { T_ITER_A = 0, T_ITER_B = 1, T_TYPE = 2, T_ITERS = 3, T_XSEL = 4, T_NSTAT = 8 };
 
@@ -610,110 +612,83 @@ static int cg_wait(stan_ctx *ctx, bool p2p, hipStream_t st, hipEvent_t ev) {
     return STAN_E_COMM;
 }
 
-int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_f,
-                   int32_t max_its, int32_t precision_mode, double *d_U, int32_t *term_out,
-                   int32_t *iters_out, double *rel_res_out) {
-    if (precision_mode != STAN_PREC_FP64 && precision_mode != STAN_PREC_MIXED &&
-        precision_mode != STAN_PREC_FIXED48) {
-        ctx->err = "cg_solve: unknown precision_mode";
-        return STAN_E_UNSUPPORTED;
-    }
-    if (eps_f < 0 || max_its < 0) {
-        ctx->err = "cg_solve: eps_f and max_its must be >= 0";
-        return STAN_E_ARG;
-    }
-    if (eps_f == 0 && max_its == 0) eps_f = 1.0e-6;  // lincgsetcond
-    hipStream_t st_ = ctx->stream;
+namespace {
+
+// ---- one solve -------------------------------------------------------------------------------------------
+// cg_run holds the state of ONE call of stan_cg_device and is its three parts:
+//   setup()    streams and vectors: workspace, scaling, packed columns, value streams, scalars, counters
+//   pass()     ONE run of the CG loop on the right-hand side in bh (begin_pass: k_init / k_init_b, first
+//              residual test; iterate: chunks of iterations enqueued ahead of a polled status word)
+//   finish()   U = S x^, the report, the profile
+// and, for the reduced-precision value streams (STAN_PREC_MIXED, STAN_PREC_FIXED48), what lies between two passes:
+//   fp64_check()   r_t = b^ - A^64 x^ with the fp64 values (which stay resident next to their copy): the residual
+//                  the caller gets REPORTED, and the right-hand side of the next pass when it misses eps
+//                  (STAN_OPT_CG_REFINE: iterative refinement; the passes' iterates add up in fp64).
+// The fp64 stream makes exactly one pass and no check: alglib's loop as the reference runs it.
+struct cg_run {
+    stan_ctx *ctx;
+    stan_matrix *K;
+    const double *d_F;
+    double eps_f;
+    int32_t max_its;
+    int32_t precision_mode;
+    double *d_U;
+
+    hipStream_t st_ = nullptr;
     event_bag events;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (ctx->profiling) {
-        ev0 = events.make(); ev1 = events.make();
-        hipEventRecord(ev0, st_);
-    }
-    const bool dist = ctx->comm != nullptr || ctx->nranks > 1;  // exchanges in the loop
-    // peer to peer (one-process group handle, STAN_OPT_COMM_P2P): no RCCL call below this line
-    const bool p2p = dist && ctx->comm_p2p && ctx->p2p != nullptr;
-    // no hipFree while the peers' streams wait for this rank's future exchanges (stan_ctx::defer_frees)
-    struct free_later { stan_ctx *c; bool on; ~free_later() { if (on) { stan_flush_deferred(c); stan_p2p_ipc_trim(c); } } } free_guard{ctx, p2p};
-    if (p2p && ctx->p2p->broken.load()) {   // refused at once: not another collective with a peer that is gone
-        ctx->err = "cg: the peer-to-peer exchange of this context is broken (a peer rank failed earlier); start a fresh process";
-        return STAN_E_COMM;
-    }
-    if (p2p) ctx->defer_frees = true;
-    STANCHK(stan_cg_workspace(ctx, K));   // the context's vectors (the placement search probed with them)
-    if (p2p) {
-        // my neighbours write their boundary rows straight into these vectors: tell them where they are
-        const int64_t ns_ = 3 * ((int64_t)K->nslices * 64 + K->nhalo);
-        if (!K->d_scale) STANCHK(stan_dmalloc(ctx, &K->d_scale, (size_t)ns_));
-        double *const pub[5] = {ctx->ws.xb[0], ctx->ws.xb[1], ctx->ws.p, ctx->ws.r, K->d_scale};
-        STANCHK(stan_p2p_publish_vectors(ctx, K, pub));
-    }
-    STANCHK(ensure_scaled(ctx, K));
-    if (ctx->cols16) STANCHK(stan_matrix_make_cols16(ctx, K));
-    if (precision_mode == STAN_PREC_MIXED) STANCHK(stan_matrix_make_fp32(ctx, K));
-    if (precision_mode == STAN_PREC_FIXED48) STANCHK(stan_matrix_make_fx48(ctx, K));
-    // the stream the products really read (FIXED-48 falls back to fp64 when K is not SPD-scalable)
-    const int vs = precision_mode == STAN_PREC_FIXED48 ? (K->d_vals48 ? STAN_PREC_FIXED48 : STAN_PREC_FP64)
-                                                       : precision_mode;
-    if (!stan_small_system(ctx, K)) {
-        const int rc_fold = stan_matrix_make_folded(ctx, K, vs);
-        if (rc_fold == STAN_E_ALLOC) {   // an optimisation must not fail the solve: the padded streams serve
-            stan_matrix_abandon_folding(ctx, K);
-            ctx->err.clear();
-        } else
-            STANCHK(rc_fold);
-    }
-    const bool sr = ctx->cg_single_reduce;
-    const bool foldr = ctx->cg_fold_reduce;
-
-    const int64_t n3 = 3 * K->nloc;
-    const int64_t npad = (int64_t)K->nslices * 64;
-    const int64_t ng = 3 * ((npad > K->nloc + K->nhalo ? npad : K->nloc + K->nhalo));
-    const int64_t dof0 = 3 * K->r0;
+    bool dist = false, p2p = false, sr = false, foldr = false, split = false;
+    int vs = STAN_PREC_FP64;          // the stream the loop's products read
+    int refine = 0;                   // STAN_OPT_CG_REFINE, reduced-precision streams only
+    int64_t n3 = 0, npad = 0, ng = 0, dof0 = 0;
     dev_bufs bufs;
-    double *xb[2], *p, *r, *v, *w, *bh, *partial, *sc, *sv = nullptr;
-    int64_t *stt;
-    unsigned long long *tick;
-    xb[0] = ctx->ws.xb[0]; xb[1] = ctx->ws.xb[1]; p = ctx->ws.p; r = ctx->ws.r;
-    v = ctx->ws.v; w = ctx->ws.w; bh = ctx->ws.bh;
-    if (sr) sv = ctx->ws.sv;
-    const unsigned spmv_blocks = stan_small_system(ctx, K) ? (unsigned)K->nslices : nblk(K->nslices, 4);
-    const size_t npart = 2 * (size_t)(spmv_blocks > VEC_BLOCKS ? spmv_blocks : VEC_BLOCKS) + 16;
-    STANCHK(alloc(ctx, bufs, &partial, npart));
-    STANCHK(alloc(ctx, bufs, &sc, (size_t)S_NSCAL));
-    STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
-    STANCHK(alloc(ctx, bufs, &tick, (size_t)(2 * FOLD_WORDS)));   // two ticket-counter sets
-    HIPCHK(ctx, hipMemsetAsync(sc, 0, S_NSCAL * 8, st_));
-    HIPCHK(ctx, hipMemsetAsync(tick, 0, 2 * FOLD_WORDS * 8, st_));
-    HIPCHK(ctx, hipMemsetAsync(xb[0], 0, (size_t)ng * 8, st_));
-    HIPCHK(ctx, hipMemsetAsync(xb[1], 0, (size_t)ng * 8, st_));
-    HIPCHK(ctx, hipMemsetAsync(p, 0, (size_t)ng * 8, st_));
-    if (sr) {
-        HIPCHK(ctx, hipMemsetAsync(r, 0, (size_t)ng * 8, st_));
-        HIPCHK(ctx, hipMemsetAsync(sv, 0, (size_t)n3 * 8, st_));
-    }
-    // folded reductions: counter A serves the products, counter B the vector kernels
+    double *xb[2] = {nullptr, nullptr}, *p = nullptr, *r = nullptr, *v = nullptr, *w = nullptr, *bh = nullptr;
+    double *partial = nullptr, *sc = nullptr, *sv = nullptr;
+    double *xacc = nullptr, *b0 = nullptr;   // refinement: the sum of the passes' iterates, the original b^ (allocated when a second pass starts)
+    int64_t *stt = nullptr;
+    unsigned long long *tick = nullptr;
+    const stan_p2p_dev *p2p_tab = nullptr;
+    unsigned vg = 1;
+    int64_t its_before_restart = 1;
+    static constexpr int64_t hard_cap = 0x7fffffff;   // iteration counter is int32 in the report
+    int64_t *h_st = nullptr;          // pinned status words
+    double *h_sc = nullptr;           // pinned copy of the scalars
+    hipEvent_t poll[2] = {nullptr, nullptr};
+    // profile
+    std::vector<hipEvent_t> red_ev, halo_ev, spmv_ev, spmv2_ev, spmv64_ev;
+    std::vector<int64_t> spmv_k, spmv2_k;   // iteration of each timed launch
+    int64_t n_coll = 0, n_wait = 0, n_launch = 0, n_enqueued = 0;
+    double prof_spmv_ms = 0, prof_spmv2_ms = 0, prof_spmv64_ms = 0;
+    int64_t prof_spmv_n = 0, prof_spmv2_n = 0, prof_spmv64_n = 0;
+    // result of the last pass
+    int pass_type = 0;
+    int64_t pass_its = 0;
+    const double *xfin = nullptr;
+
     // Where the sums of a reduction go.  One rank, or RCCL: the local scalars (RCCL all-reduces them in
     // place).  Peer to peer: every rank's mailbox slot `slot`, columns j0.. (+ arrival count when this is
     // the producer that completes the exchange); the consumers then read through a red_src.
-    const stan_p2p_dev *p2p_tab = p2p ? stan_p2p_table(ctx) : nullptr;
-    auto p2p_to = [&](int j0, bool signal) {
+    p2p_out p2p_to(int j0, bool signal) {
         return p2p ? p2p_out{p2p_tab, stan_p2p_reduce_slot(ctx), j0, signal ? 1 : 0} : NO_P2P;
-    };
-    auto fold_to = [&](int which, double *out, p2p_out po = NO_P2P) {
+    }
+    // folded reductions: counter set 0 serves the products, set 1 the vector kernels
+    fold_args fold_to(int which, double *out, p2p_out po = NO_P2P) {
         return fold_args{foldr ? tick + FOLD_WORDS * which : nullptr, 0, 0, out, po};
-    };
-    auto reduce_if_unfolded = [&](int np, int nv, double *out, p2p_out po = NO_P2P, int64_t k_ = -1) {
+    }
+    fold_args vec_fold(double *out, p2p_out po = NO_P2P) {
+        fold_args f = fold_to(1, out, po);
+        f.nblocks = vg; f.np = (int)vg;
+        return f;
+    }
+    void reduce_if_unfolded(int np, int nv, double *out, p2p_out po = NO_P2P, int64_t k_ = -1) {
         if (foldr || np <= 0) return;
         const int64_t *sk = k_ >= 1 ? stt : nullptr;   // (k_init's sum is formed before the status exists)
         if (nv == 2) hipLaunchKernelGGL(k_reduce<2>, dim3(1), dim3(256), 0, st_, partial, np, out, po, sk, k_);
         else hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, np, out, po, sk, k_);
-    };
+    }
     // One exchange point of the sharded loop: RCCL all-reduce of `count` scalars in place, or the stream
     // wait for every rank's arrival; returns where the consumers find the sums.
-    std::vector<hipEvent_t> red_ev, halo_ev;   // profiling: events around the exchanges
-    int64_t n_coll = 0, n_wait = 0;            // RCCL collectives / stream waits enqueued by the loop (profile)
-    auto exchange_sums = [&](double *scalars, int count, red_src *rs) -> int {
+    int exchange_sums(double *scalars, int count, red_src *rs) {
         *rs = red_src{nullptr, 0, nullptr, 0};
         if (!dist) return STAN_OK;
         if (ctx->profiling) { red_ev.push_back(events.make()); hipEventRecord(red_ev.back(), st_); }
@@ -728,60 +703,32 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         }
         if (ctx->profiling) { red_ev.push_back(events.make()); hipEventRecord(red_ev.back(), st_); }
         return rc_;
-    };
-    auto halo = [&](double *x) -> int {
+    }
+    int halo(double *x) {
         if (ctx->profiling) { halo_ev.push_back(events.make()); hipEventRecord(halo_ev.back(), st_); }
         const int rc_ = stan_comm_halo_exchange(ctx, K, x);
         if (p2p && !K->nbr.empty()) n_wait++;
         if (ctx->profiling) { halo_ev.push_back(events.make()); hipEventRecord(halo_ev.back(), st_); }
         return rc_;
-    };
-
-    const unsigned vg = vec_grid(n3);
-    {
-        fold_args f = fold_to(1, sc + S_VMV, p2p_to(0, true));
-        f.nblocks = vg; f.np = (int)vg;
-        hipLaunchKernelGGL(k_init, dim3(vg), dim3(VEC_T), 0, st_, n3, dof0, K->d_red, d_F, K->d_scale,
-                           bh, xb[0], r, p, partial, f);
-        reduce_if_unfolded((int)vg, 1, sc + S_VMV, p2p_to(0, true));
     }
-    red_src rs_b;
-    STANCHK(exchange_sums(sc + S_VMV, 1, &rs_b));
-    hipLaunchKernelGGL(k_init_scalars, dim3(1), dim3(64), 0, st_, sc, stt, eps_f, rs_b);
-    HIPCHK(ctx, hipGetLastError());
 
-    // lincgcreate: ItsBeforeRestart = N (global reduced size)
-    int64_t its_before_restart = K->n_red > 0 ? K->n_red : 1;
-    const int64_t hard_cap = 0x7fffffff;  // iteration counter is int32 in the report
-
-    // Sharded SpMV with the halo exchange hidden behind the interior slices: the slices whose
-    // rows reference no halo column run on a side stream while the main stream packs, sends
-    // and receives; the boundary slices follow on the main stream.  RCCL only ever sees the
-    // main stream.
-    const bool split = dist && ctx->overlap_halo && K->d_sl_bnd != nullptr;
-    if (split && !ctx->side) {
-        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
-    }
-    std::vector<hipEvent_t> spmv_ev, spmv2_ev;
-    std::vector<int64_t> spmv_k, spmv2_k;  // iteration of each timed launch (see the profile below)
-    int64_t n_launch = 0;                  // kernels enqueued by the loop (profile)
-    // y = A^ x (x gets its halo filled first when sharded) with `dot` sums (k_spmv's DOT) reduced
-    // into out[0..dot): folded into the last launch of the product, or by k_reduce.
-    auto spmv = [&](double *x, double *y, int dot, double *out, int64_t k, p2p_out po = NO_P2P) -> int {
+    // y = A^ x (x gets its halo filled first when sharded) with `dot` sums (k_spmv's DOT) reduced into out[0..dot):
+    // folded into the last launch of the product, or by k_reduce.  kind: the value stream (the loop's own, or
+    // STAN_PREC_FP64 for the check / refresh products of a reduced-precision solve).
+    int spmv(double *x, double *y, int dot, double *out, int64_t k, p2p_out po, int kind) {
+        const bool own = kind == vs;
         if (ctx->profiling) {
             hipEvent_t a = events.make(), b = events.make();
             hipEventRecord(a, st_);
-            spmv_ev.push_back(a); spmv_ev.push_back(b);
-            spmv_k.push_back(k);
+            if (own) { spmv_ev.push_back(a); spmv_ev.push_back(b); spmv_k.push_back(k); }
+            else { spmv64_ev.push_back(a); spmv64_ev.push_back(b); }
         }
         auto go = [&](int which, hipStream_t s, bool last) -> unsigned {
             const fold_args f = (dot && last) ? fold_to(0, out, po) : NO_FOLD;
             n_launch++;
-            return dot == 2 ? launch_spmv_any<2>(ctx, K, vs, x, y, partial, stt, k, which, s, f)
-                 : dot == 1 ? launch_spmv_any<1>(ctx, K, vs, x, y, partial, stt, k, which, s, f)
-                            : launch_spmv_any<0>(ctx, K, vs, x, y, partial, stt, k, which, s, f);
+            return dot == 2 ? launch_spmv_any<2>(ctx, K, kind, x, y, partial, stt, k, which, s, f)
+                 : dot == 1 ? launch_spmv_any<1>(ctx, K, kind, x, y, partial, stt, k, which, s, f)
+                            : launch_spmv_any<0>(ctx, K, kind, x, y, partial, stt, k, which, s, f);
         };
         unsigned parts = 0;
         bool folded = foldr;
@@ -808,12 +755,12 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
                 n_launch++;
             } else HIPCHK(ctx, hipMemsetAsync(out, 0, 8 * dot, st_));   // a rank that owns no rows
         }
-        if (ctx->profiling) hipEventRecord(spmv_ev.back(), st_);
+        if (ctx->profiling) hipEventRecord(own ? spmv_ev.back() : spmv64_ev.back(), st_);
         return STAN_OK;
-    };
+    }
 
     // v = A^ x and w = A^ x2 in one matrix pass (fused residual refresh), x.v -> out
-    auto spmv2 = [&](double *x, double *x2, double *out, int64_t k, p2p_out po = NO_P2P) -> int {
+    int spmv2(double *x, double *x2, double *out, int64_t k, p2p_out po) {
         if (ctx->profiling) {
             hipEvent_t a = events.make(), b = events.make();
             hipEventRecord(a, st_);
@@ -851,28 +798,141 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         }
         if (ctx->profiling) hipEventRecord(spmv2_ev.back(), st_);
         return STAN_OK;
-    };
-    auto vec_fold = [&](double *out, p2p_out po = NO_P2P) {
-        fold_args f = fold_to(1, out, po);
-        f.nblocks = vg; f.np = (int)vg;
-        return f;
-    };
+    }
 
-    int64_t *h_st = ctx->h_status + SS_H_CG_STATUS;  // pinned
-    hipEvent_t poll[2] = {events.make(hipEventDisableTiming), events.make(hipEventDisableTiming)};
+    int setup();
+    int begin_pass(bool from_F, double eps_pass, bool *done);
+    int iterate(double eps_pass, int32_t max_its_pass);
+    int pass(bool from_F, double eps_pass, int32_t max_its_pass);
+    void account_pass();
+    int fp64_check(double *xg, const double *b, double *r2_out);
+    int finish(const double *x_result, int type, int64_t its, double rel_rec, double rel64, int passes,
+               int32_t *term_out, int32_t *iters_out, double *rel_res_out);
+};
+
+// ---- set-up ------------------------------------------------------------------------------------------------
+int cg_run::setup() {
+    st_ = ctx->stream;
+    if (ctx->profiling) {
+        ev0 = events.make(); ev1 = events.make();
+        hipEventRecord(ev0, st_);
+    }
+    dist = ctx->comm != nullptr || ctx->nranks > 1;  // exchanges in the loop
+    // peer to peer (one-process group handle, STAN_OPT_COMM_P2P): no RCCL call below this line
+    p2p = dist && ctx->comm_p2p && ctx->p2p != nullptr;
+    if (p2p && ctx->p2p->broken.load()) {   // refused at once: not another collective with a peer that is gone
+        ctx->err = "cg: the peer-to-peer exchange of this context is broken (a peer rank failed earlier); start a fresh process";
+        return STAN_E_COMM;
+    }
+    if (p2p) ctx->defer_frees = true;   // no hipFree while the peers' streams wait for this rank's future exchanges (stan_ctx::defer_frees)
+    STANCHK(stan_cg_workspace(ctx, K));   // the context's vectors (the placement search probed with them)
+    if (p2p) {
+        // my neighbours write their boundary rows straight into these vectors: tell them where they are
+        const int64_t ns_ = 3 * ((int64_t)K->nslices * 64 + K->nhalo);
+        if (!K->d_scale) STANCHK(stan_dmalloc(ctx, &K->d_scale, (size_t)ns_));
+        double *const pub[5] = {ctx->ws.xb[0], ctx->ws.xb[1], ctx->ws.p, ctx->ws.r, K->d_scale};
+        STANCHK(stan_p2p_publish_vectors(ctx, K, pub));
+    }
+    STANCHK(ensure_scaled(ctx, K));
+    if (ctx->cols16) STANCHK(stan_matrix_make_cols16(ctx, K));
+    if (precision_mode == STAN_PREC_MIXED) STANCHK(stan_matrix_make_fp32(ctx, K));
+    if (precision_mode == STAN_PREC_FIXED48) STANCHK(stan_matrix_make_fx48(ctx, K));
+    // the stream the products really read (FIXED-48 falls back to fp64 when K is not SPD-scalable)
+    vs = precision_mode == STAN_PREC_FIXED48 ? (K->d_vals48 ? STAN_PREC_FIXED48 : STAN_PREC_FP64) : precision_mode;
+    refine = vs == STAN_PREC_FP64 ? 0 : ctx->cg_refine;
+    if (!stan_small_system(ctx, K)) {
+        const int rc_fold = stan_matrix_make_folded(ctx, K, vs);
+        if (rc_fold == STAN_E_ALLOC) {   // an optimisation must not fail the solve: the padded streams serve
+            stan_matrix_abandon_folding(ctx, K);
+            ctx->err.clear();
+        } else
+            STANCHK(rc_fold);
+    }
+    sr = ctx->cg_single_reduce;
+    foldr = ctx->cg_fold_reduce;
+
+    n3 = 3 * K->nloc;
+    npad = (int64_t)K->nslices * 64;
+    ng = 3 * ((npad > K->nloc + K->nhalo ? npad : K->nloc + K->nhalo));
+    dof0 = 3 * K->r0;
+    xb[0] = ctx->ws.xb[0]; xb[1] = ctx->ws.xb[1]; p = ctx->ws.p; r = ctx->ws.r;
+    v = ctx->ws.v; w = ctx->ws.w; bh = ctx->ws.bh;
+    if (sr) sv = ctx->ws.sv;
+    const unsigned spmv_blocks = stan_small_system(ctx, K) ? (unsigned)K->nslices : nblk(K->nslices, 4);
+    const size_t npart = 2 * (size_t)(spmv_blocks > VEC_BLOCKS ? spmv_blocks : VEC_BLOCKS) + 16;
+    STANCHK(alloc(ctx, bufs, &partial, npart));
+    STANCHK(alloc(ctx, bufs, &sc, (size_t)S_NSCAL));
+    STANCHK(alloc(ctx, bufs, &stt, (size_t)T_NSTAT));
+    STANCHK(alloc(ctx, bufs, &tick, (size_t)(2 * FOLD_WORDS)));   // two ticket-counter sets
+    HIPCHK(ctx, hipMemsetAsync(sc, 0, S_NSCAL * 8, st_));
+    HIPCHK(ctx, hipMemsetAsync(tick, 0, 2 * FOLD_WORDS * 8, st_));
+    HIPCHK(ctx, hipMemsetAsync(xb[0], 0, (size_t)ng * 8, st_));
+    HIPCHK(ctx, hipMemsetAsync(xb[1], 0, (size_t)ng * 8, st_));
+    HIPCHK(ctx, hipMemsetAsync(p, 0, (size_t)ng * 8, st_));
+    if (sr) {
+        HIPCHK(ctx, hipMemsetAsync(r, 0, (size_t)ng * 8, st_));
+        HIPCHK(ctx, hipMemsetAsync(sv, 0, (size_t)n3 * 8, st_));
+    }
+    p2p_tab = p2p ? stan_p2p_table(ctx) : nullptr;
+    vg = vec_grid(n3);
+    its_before_restart = K->n_red > 0 ? K->n_red : 1;   // lincgcreate: ItsBeforeRestart = N (global reduced size)
+    // Sharded SpMV with the halo exchange hidden behind the interior slices: the slices whose
+    // rows reference no halo column run on a side stream while the main stream packs, sends
+    // and receives; the boundary slices follow on the main stream.  RCCL only ever sees the
+    // main stream.
+    split = dist && ctx->overlap_halo && K->d_sl_bnd != nullptr;
+    if (split && !ctx->side) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
+    }
+    h_st = ctx->h_status + SS_H_CG_STATUS;  // pinned
+    h_sc = (double *)(ctx->h_status + SS_H_CG_SCALARS);
+    poll[0] = events.make(hipEventDisableTiming);
+    poll[1] = events.make(hipEventDisableTiming);
+    return STAN_OK;
+}
+
+// ---- one pass of the loop ------------------------------------------------------------------------------------
+// Right-hand side, x0 = 0, r0 = p0 = b^, ||b^||, first residual test.  from_F: b^ = S F (the caller's load vector);
+// otherwise b^ = the vector in r (a refinement pass: the fp64 residual fp64_check left there).
+int cg_run::begin_pass(bool from_F, double eps_pass, bool *done) {
+    {
+        fold_args f = fold_to(1, sc + S_VMV, p2p_to(0, true));
+        f.nblocks = vg; f.np = (int)vg;
+        if (from_F)
+            hipLaunchKernelGGL(k_init, dim3(vg), dim3(VEC_T), 0, st_, n3, dof0, K->d_red, d_F, K->d_scale,
+                               bh, xb[0], r, p, partial, f);
+        else
+            hipLaunchKernelGGL(k_init_b, dim3(vg), dim3(VEC_T), 0, st_, n3, (const double *)r, bh, xb[0], r, p, partial, f);
+        reduce_if_unfolded((int)vg, 1, sc + S_VMV, p2p_to(0, true));
+    }
+    red_src rs_b;
+    STANCHK(exchange_sums(sc + S_VMV, 1, &rs_b));
+    hipLaunchKernelGGL(k_init_scalars, dim3(1), dim3(64), 0, st_, sc, stt, eps_pass, rs_b);
+    HIPCHK(ctx, hipGetLastError());
+    // status of "iteration 0" (initial residual test)
+    HIPCHK(ctx, hipMemcpyAsync(h_st, stt, T_NSTAT * 8, hipMemcpyDeviceToHost, st_));
+    STANCHK(cg_wait(ctx, p2p, st_, nullptr));   // (peer to peer: behind the first reduction's wait)
+    *done = h_st[T_ITER_A] == 0;
+    return STAN_OK;
+}
+
+int cg_run::iterate(double eps_pass, int32_t max_its_pass) {
     int64_t k = 1;
     int chunk_id = 0;
     bool done = false;
     int rc = STAN_OK;
-    // status of "iteration 0" (initial residual test)
-    HIPCHK(ctx, hipMemcpyAsync(h_st, stt, T_NSTAT * 8, hipMemcpyDeviceToHost, st_));
-    STANCHK(cg_wait(ctx, p2p, st_, nullptr));   // (peer to peer: behind the first reduction's wait)
-    if (h_st[T_ITER_A] == 0) done = true;
     red_src rs_sr{nullptr, 0, nullptr, 0}, rs_vmv{nullptr, 0, nullptr, 0}, rs_r2{nullptr, 0, nullptr, 0};
-    if (sr && !done) {   // w_0 = A r_0 with gamma_0, delta_0 (merit_0 = 0 sits in the zeroed scalars)
+    // STAN_OPT_CG_REFINE = 2 on a reduced-precision stream: the periodic residual recomputation (alglib's
+    // ItsBeforeRUpdate) multiplies with the fp64 values -- the recurrence is re-anchored to the true residual
+    // ("reliable updates"), so the literal second product replaces the fused two-product pass
+    const bool refresh64 = refine >= 2 && vs != STAN_PREC_FP64;
+    const int kind_refresh = refresh64 ? STAN_PREC_FP64 : vs;
+    if (sr) {   // w_0 = A r_0 with gamma_0, delta_0 (merit_0 = 0 sits in the zeroed scalars)
         if (p2p)         // ... or, peer to peer, is sent as this rank's zero into the slot of the first reduction
             hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, 0, sc + S_SR_MERIT, p2p_to(2, false), (const int64_t *)nullptr, (int64_t)0);
-        rc = spmv(r, w, 2, sc + S_SR_GAMMA, 0, p2p_to(0, true));
+        rc = spmv(r, w, 2, sc + S_SR_GAMMA, 0, p2p_to(0, true), vs);
         if (rc == STAN_OK) rc = exchange_sums(sc + S_SR_GAMMA, 3, &rs_sr);
     }
     // a sharded loop polls more often: what runs ahead of the stop are exchanges nobody can cut short
@@ -883,7 +943,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             const bool refresh = ctx->cg_rupdate > 0 && (k % ctx->cg_rupdate) == 0;
             if (sr) {
                 sr_args a;
-                a.n3 = n3; a.k = k; a.sc = sc; a.st = stt; a.epsf = eps_f; a.maxits = max_its;
+                a.n3 = n3; a.k = k; a.sc = sc; a.st = stt; a.epsf = eps_pass; a.maxits = max_its_pass;
                 a.its_before_restart = its_before_restart; a.merit_stop = ctx->cg_merit_stop ? 1 : 0;
                 a.refresh = refresh ? 1 : 0;
                 a.xcur = xb[(k - 1) & 1]; a.xnext = xb[k & 1];
@@ -895,22 +955,22 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
                 n_launch++;
                 if (!refresh) reduce_if_unfolded((int)vg, 1, sc + S_SR_MERIT, p2p_to(2, false), k);
                 else {   // r' = b^ - A^ x' (ALGLIB's periodic residual recomputation), then as usual
-                    rc = spmv(xb[k & 1], v, 0, nullptr, k);
+                    rc = spmv(xb[k & 1], v, 0, nullptr, k, NO_P2P, kind_refresh);
                     if (rc) break;
                     hipLaunchKernelGGL(k_refresh, dim3(vg), dim3(VEC_T), 0, st_, n3, k, (const int64_t *)stt,
                                        bh, v, xb[k & 1], r, partial, vec_fold(sc + S_SR_DELTA, p2p_to(1, false)));
                     n_launch++;
                     reduce_if_unfolded((int)vg, 2, sc + S_SR_DELTA, p2p_to(1, false), k);   // [r.r (rewritten below), merit]
                 }
-                rc = spmv(r, w, 2, sc + S_SR_GAMMA, k, p2p_to(0, true));
+                rc = spmv(r, w, 2, sc + S_SR_GAMMA, k, p2p_to(0, true), vs);
                 if (rc) break;
                 rc = exchange_sums(sc + S_SR_GAMMA, 3, &rs_sr);
                 if (rc) break;
                 continue;
             }
-            const bool fused = refresh && ctx->cg_fused_refresh;
+            const bool fused = refresh && ctx->cg_fused_refresh && !refresh64;
             rc = fused ? spmv2(p, xb[(k - 1) & 1], sc + S_VMV, k, p2p_to(0, true))
-                       : spmv(p, v, 1, sc + S_VMV, k, p2p_to(0, true));
+                       : spmv(p, v, 1, sc + S_VMV, k, p2p_to(0, true), vs);
             if (rc) break;
             rc = exchange_sums(sc + S_VMV, 1, &rs_vmv);
             if (rc) break;
@@ -931,7 +991,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             n_launch++;
             if (a.refresh == 1) {
                 // a -5/-4 stop of this iteration is caught by k_refresh/k_update (ITER_B <= k)
-                rc = spmv(xb[k & 1], v, 0, nullptr, k);
+                rc = spmv(xb[k & 1], v, 0, nullptr, k, NO_P2P, kind_refresh);
                 if (rc) break;
                 hipLaunchKernelGGL(k_refresh, dim3(vg), dim3(VEC_T), 0, st_, n3, k,
                                    (const int64_t *)stt, bh, v, xb[k & 1], r, partial, vec_fold(sc + S_R2NEW, po_r));
@@ -943,11 +1003,11 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
             const double *ux = a.defer_x ? a.xcur : nullptr;
             double *uxn = a.defer_x ? a.xnext : nullptr;
             if (ctx->vec_store_nt & 1)
-                hipLaunchKernelGGL(k_update<true>, dim3(vg), dim3(VEC_T), 0, st_, n3, k, sc, stt, eps_f,
-                                   (int64_t)max_its, its_before_restart, ctx->cg_merit_stop ? 1 : 0, r, p, ux, uxn, rs_r2, rs_vmv);
+                hipLaunchKernelGGL(k_update<true>, dim3(vg), dim3(VEC_T), 0, st_, n3, k, sc, stt, eps_pass,
+                                   (int64_t)max_its_pass, its_before_restart, ctx->cg_merit_stop ? 1 : 0, r, p, ux, uxn, rs_r2, rs_vmv);
             else
-                hipLaunchKernelGGL(k_update<false>, dim3(vg), dim3(VEC_T), 0, st_, n3, k, sc, stt, eps_f,
-                                   (int64_t)max_its, its_before_restart, ctx->cg_merit_stop ? 1 : 0, r, p, ux, uxn, rs_r2, rs_vmv);
+                hipLaunchKernelGGL(k_update<false>, dim3(vg), dim3(VEC_T), 0, st_, n3, k, sc, stt, eps_pass,
+                                   (int64_t)max_its_pass, its_before_restart, ctx->cg_merit_stop ? 1 : 0, r, p, ux, uxn, rs_r2, rs_vmv);
             n_launch++;
         }
         if (rc) break;
@@ -967,6 +1027,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         }
         chunk_id++;
     }
+    n_enqueued += k - 1;
     if (p2p) {   // never a blocking wait on a stream that may sit in front of a peer that is gone
         if (rc == STAN_OK) rc = cg_wait(ctx, true, st_, nullptr);
         else stan_p2p_release_own(ctx);
@@ -975,23 +1036,94 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     if (rc) return rc;
     if (e != hipSuccess) { ctx->err = std::string("cg: ") + hipGetErrorString(e); return STAN_E_HIP; }
     HIPCHK(ctx, hipMemcpyAsync(h_st, stt, T_NSTAT * 8, hipMemcpyDeviceToHost, st_));
-    double *h_sc = (double *)(ctx->h_status + SS_H_CG_SCALARS);
-    HIPCHK(ctx, hipMemcpyAsync(h_sc, sc, 16 * 8, hipMemcpyDeviceToHost, st_));
+    HIPCHK(ctx, hipMemcpyAsync(h_sc, sc, S_NSCAL * 8, hipMemcpyDeviceToHost, st_));
     HIPCHK(ctx, hipStreamSynchronize(st_));
-    int type = (int)h_st[T_TYPE];
-    int64_t its = h_st[T_ITERS];
-    if (type == 0) { type = 5; its = k - 1; h_st[T_XSEL] = (k - 1) & 1; }  // hard cap
-    const double *xfin = xb[h_st[T_XSEL] & 1];
+    pass_type = (int)h_st[T_TYPE];
+    pass_its = h_st[T_ITERS];
+    if (pass_type == 0) { pass_type = 5; pass_its = k - 1; h_st[T_XSEL] = (k - 1) & 1; }  // hard cap
+    xfin = xb[h_st[T_XSEL] & 1];
+    return STAN_OK;
+}
 
+int cg_run::pass(bool from_F, double eps_pass, int32_t max_its_pass) {
+    bool done = false;
+    STANCHK(begin_pass(from_F, eps_pass, &done));
+    if (done) {   // the first residual test ended it (b = 0, or eps >= 1): no iteration
+        HIPCHK(ctx, hipMemcpyAsync(h_sc, sc, S_NSCAL * 8, hipMemcpyDeviceToHost, st_));
+        HIPCHK(ctx, hipStreamSynchronize(st_));
+        pass_type = (int)h_st[T_TYPE];
+        pass_its = h_st[T_ITERS];
+        xfin = xb[h_st[T_XSEL] & 1];
+        return STAN_OK;
+    }
+    STANCHK(iterate(eps_pass, max_its_pass));
+    account_pass();
+    return STAN_OK;
+}
+
+// profile: the launch times of the pass that has just ended (its stream is synchronised).  Only launches that did
+// work count: the host runs up to two chunks ahead of the status it polls, so a converged solve is followed by a few
+// dozen launches that return at once (3-4 us each); averaging those in made the SpMV look ~3 % faster than it is.
+void cg_run::account_pass() {
+    if (!ctx->profiling) return;
+    for (size_t i = 0; i + 1 < spmv_ev.size(); i += 2) {
+        if (spmv_k[i / 2] > pass_its) continue;
+        float t = 0;
+        hipEventElapsedTime(&t, spmv_ev[i], spmv_ev[i + 1]);
+        prof_spmv_ms += t;
+        prof_spmv_n++;
+    }
+    for (size_t i = 0; i + 1 < spmv2_ev.size(); i += 2) {
+        if (spmv2_k[i / 2] > pass_its) continue;
+        float t = 0;
+        hipEventElapsedTime(&t, spmv2_ev[i], spmv2_ev[i + 1]);
+        prof_spmv2_ms += t;
+        prof_spmv2_n++;
+    }
+    spmv_ev.clear(); spmv_k.clear(); spmv2_ev.clear(); spmv2_k.clear();
+}
+
+// ---- the fp64 check of a reduced-precision solve ----------------------------------------------------------------
+// r_t = b - A^64 xg with the fp64 values of the scaled matrix (xg: a gather vector -- one of the vectors the peers know,
+// cg_run::setup -- holding the iterate on the owned rows); r_t stays in r, *r2_out = ||r_t||^2 over all ranks.
+int cg_run::fp64_check(double *xg, const double *b, double *r2_out) {
+    STANCHK(spmv(xg, v, 0, nullptr, 0, NO_P2P, STAN_PREC_FP64));
+    const p2p_out po = p2p_to(0, true);
+    hipLaunchKernelGGL(k_refresh, dim3(vg), dim3(VEC_T), 0, st_, n3, (int64_t)0, (const int64_t *)stt, b, v,
+                       (const double *)xg, r, partial, vec_fold(sc + S_CHK_R2, po));
+    n_launch++;
+    reduce_if_unfolded((int)vg, 2, sc + S_CHK_R2, po);
+    red_src rs;
+    STANCHK(exchange_sums(sc + S_CHK_R2, 2, &rs));
+    if (rs.mb) hipLaunchKernelGGL(k_land_sums, dim3(1), dim3(64), 0, st_, sc + S_CHK_R2, rs);   // peer to peer: the mailbox's sums into the local scalars
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(h_sc, sc, S_NSCAL * 8, hipMemcpyDeviceToHost, st_));
+    STANCHK(cg_wait(ctx, p2p, st_, nullptr));
+    *r2_out = h_sc[S_CHK_R2];
+    if (ctx->profiling) {
+        for (size_t i = 0; i + 1 < spmv64_ev.size(); i += 2) {
+            float t = 0;
+            hipEventElapsedTime(&t, spmv64_ev[i], spmv64_ev[i + 1]);
+            prof_spmv64_ms += t;
+            prof_spmv64_n++;
+        }
+        spmv64_ev.clear();
+    }
+    return STAN_OK;
+}
+
+// ---- epilogue ------------------------------------------------------------------------------------------------
+int cg_run::finish(const double *x_result, int type, int64_t its, double rel_rec, double rel64, int passes,
+                   int32_t *term_out, int32_t *iters_out, double *rel_res_out) {
     // U = S x^ on the free DOFs (a rank of a one-process group leaves only ITS entries [u0, u1) of U: the
     // group copies every rank's segment into the caller's buffer, nothing is gathered on the devices)
     if (!dist || ctx->result_segment) {
         hipLaunchKernelGGL(k_result, dim3(vg), dim3(VEC_T), 0, st_, n3, dof0, K->d_red, K->d_scale,
-                           xfin, d_U);
+                           x_result, d_U);
     } else {
         double *full;
         STANCHK(alloc(ctx, bufs, &full, (size_t)K->n_dof));
-        hipLaunchKernelGGL(k_result_full, dim3(vg), dim3(VEC_T), 0, st_, n3, K->d_scale, xfin,
+        hipLaunchKernelGGL(k_result_full, dim3(vg), dim3(VEC_T), 0, st_, n3, K->d_scale, x_result,
                            full + dof0);
         STANCHK(stan_comm_allgather_rows(ctx, K, full));
         hipLaunchKernelGGL(k_compress, dim3(vec_grid(K->n_dof)), dim3(VEC_T), 0, st_, K->n_dof,
@@ -1002,77 +1134,132 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
     HIPCHK(ctx, hipStreamSynchronize(st_));
 
     if (term_out) *term_out = type;
-    if (iters_out) *iters_out = (int32_t)its;
-    if (rel_res_out) *rel_res_out = h_sc[S_BNORM] > 0 ? std::sqrt(h_sc[S_R2OUT]) / h_sc[S_BNORM] : 0.0;
-    if (ctx->profiling) {
-        float ms = 0;
-        hipEventElapsedTime(&ms, ev0, ev1);
-        ctx->prof.cg_ms = ms;
-        // Only launches that did work count: the host runs up to two chunks ahead of the status
-        // it polls, so a converged solve is followed by a few dozen launches that return at once
-        // (3-4 us each); averaging those in made the SpMV look ~3 % faster than it is.
-        double tot = 0;
-        int64_t nwork = 0;
-        for (size_t i = 0; i + 1 < spmv_ev.size(); i += 2) {
-            if (spmv_k[i / 2] > its) continue;
-            float t = 0;
-            hipEventElapsedTime(&t, spmv_ev[i], spmv_ev[i + 1]);
-            tot += t;
-            nwork++;
-        }
-        ctx->prof.spmv_ms_total = tot;
-        ctx->prof.spmv_launches = nwork;
-        double tot2 = 0;
-        int64_t nwork2 = 0;
-        for (size_t i = 0; i + 1 < spmv2_ev.size(); i += 2) {
-            if (spmv2_k[i / 2] > its) continue;
-            float t = 0;
-            hipEventElapsedTime(&t, spmv2_ev[i], spmv2_ev[i + 1]);
-            tot2 += t;
-            nwork2++;
-        }
-        ctx->prof.spmv2_ms_total = tot2;
-        ctx->prof.spmv2_launches = nwork2;
-        ctx->prof.iterations = (int32_t)its;
-        ctx->prof.termination_type = type;
-        const int64_t blk_bytes = vs == STAN_PREC_FIXED48 ? 60 : vs == STAN_PREC_MIXED ? 40 : 76;
-        // bytes of the format actually streamed: a block of a packed slice carries a 2-B column offset
-        // instead of a 4-B index (+ 4 B per slot for its base, shared by 64 rows)
-        const bool packed = ctx->cols16 && K->d_cols16;
-        const double packed_frac = packed && K->nslots > 0 ? (double)K->slots_packed / (double)K->nslots : 0.0;
-        ctx->prof.spmv_bytes = K->nblocks * blk_bytes + 3 * K->nloc * 16 + K->nloc * 4
-                               - (int64_t)(packed_frac * (double)K->nblocks * 2.0) + (packed ? (K->slots_packed + K->slots_packed2) * 4 : 0);
-        const bool folded = ctx->row_folding != 0 && (vs == STAN_PREC_FIXED48 ? K->d_fold_vals48 != nullptr : vs == STAN_PREC_MIXED ? K->d_fold_vals32 != nullptr
-                                                                                                                                    : K->d_fold_vals != nullptr);
-        if (folded) {   // its own packed column stream, 4 B of plan per row
-            const bool fp = ctx->cols16 && K->d_fold_cols16;
-            const double ff = fp && K->nfslots > 0 ? (double)K->fold_slots_packed / (double)K->nfslots : 0.0;
-            ctx->prof.spmv_bytes = K->nblocks * blk_bytes + 3 * K->nloc * 16 + K->nloc * 8 - (int64_t)(ff * (double)K->nblocks * 2.0) +
-                                   (fp ? K->fold_slots_packed * 4 : 0);
-            ctx->prof.col_slots_packed = fp ? K->fold_slots_packed : 0;
-        }
-        ctx->prof.repacked_streams = folded ? 1 : 0;
-        ctx->prof.col_slots_packed = packed ? K->slots_packed : 0;
-        ctx->prof.value_stream = vs;
-        // vector passes of one classic iteration: k_step reads r, v (+ p, x unless deferred; + b^ for the
-        // merit sum) and writes r (+ x); k_update reads r, p (+ x when deferred) and writes p (+ x)
-        ctx->prof.cg_iteration_vector_bytes = 3 * K->nloc * 8 * ((ctx->cg_defer_x && !ctx->cg_merit_stop ? 8 : 9) + (ctx->cg_merit_stop ? 1 : 0));
-        ctx->prof.loop_kernel_launches = n_launch;
-        ctx->prof.loop_collectives = n_coll;
-        ctx->prof.loop_stream_waits = n_wait;
-        ctx->prof.loop_iterations_enqueued = k - 1;
-        // what the stream spent in the exchanges (RCCL launches, or peer-to-peer waits): events around each
-        auto sum_pairs = [](const std::vector<hipEvent_t> &ev, double *tot, int64_t *cnt) {
-            *tot = 0; *cnt = 0;
-            for (size_t i = 0; i + 1 < ev.size(); i += 2) {
-                float t = 0;
-                if (hipEventElapsedTime(&t, ev[i], ev[i + 1]) == hipSuccess) { *tot += t; (*cnt)++; }
-            }
-        };
-        sum_pairs(red_ev, &ctx->prof.comm_reduce_ms_total, &ctx->prof.comm_reduce_calls);
-        sum_pairs(halo_ev, &ctx->prof.comm_halo_ms_total, &ctx->prof.comm_halo_calls);
+    if (iters_out) *iters_out = (int32_t)(its > hard_cap ? hard_cap : its);
+    if (rel_res_out) *rel_res_out = rel64 >= 0 ? rel64 : rel_rec;
+    if (!ctx->profiling) return STAN_OK;
+    float ms = 0;
+    hipEventElapsedTime(&ms, ev0, ev1);
+    stan_profile &pf = ctx->prof;
+    pf.cg_ms = ms;
+    pf.spmv_ms_total = prof_spmv_ms;
+    pf.spmv_launches = prof_spmv_n;
+    pf.spmv2_ms_total = prof_spmv2_ms;
+    pf.spmv2_launches = prof_spmv2_n;
+    pf.fp64_products = (int32_t)prof_spmv64_n;
+    pf.fp64_products_ms = prof_spmv64_ms;
+    pf.iterations = (int32_t)its;
+    pf.termination_type = type;
+    pf.rel_residual_recurrence = rel_rec;
+    pf.rel_residual_fp64 = rel64;
+    pf.refine_passes = passes;
+    const int64_t blk_bytes = vs == STAN_PREC_FIXED48 ? 60 : vs == STAN_PREC_MIXED ? 40 : 76;
+    // bytes of the format actually streamed: a block of a packed slice carries a 2-B column offset
+    // instead of a 4-B index (+ 4 B per slot for its base, shared by 64 rows)
+    const bool packed = ctx->cols16 && K->d_cols16;
+    const double packed_frac = packed && K->nslots > 0 ? (double)K->slots_packed / (double)K->nslots : 0.0;
+    pf.spmv_bytes = K->nblocks * blk_bytes + 3 * K->nloc * 16 + K->nloc * 4
+                    - (int64_t)(packed_frac * (double)K->nblocks * 2.0) + (packed ? (K->slots_packed + K->slots_packed2) * 4 : 0);
+    const bool folded = ctx->row_folding != 0 && (vs == STAN_PREC_FIXED48 ? K->d_fold_vals48 != nullptr : vs == STAN_PREC_MIXED ? K->d_fold_vals32 != nullptr
+                                                                                                                                : K->d_fold_vals != nullptr);
+    if (folded) {   // its own packed column stream, 4 B of plan per row
+        const bool fp = ctx->cols16 && K->d_fold_cols16;
+        const double ff = fp && K->nfslots > 0 ? (double)K->fold_slots_packed / (double)K->nfslots : 0.0;
+        pf.spmv_bytes = K->nblocks * blk_bytes + 3 * K->nloc * 16 + K->nloc * 8 - (int64_t)(ff * (double)K->nblocks * 2.0) +
+                        (fp ? K->fold_slots_packed * 4 : 0);
+        pf.col_slots_packed = fp ? K->fold_slots_packed : 0;
     }
+    pf.repacked_streams = folded ? 1 : 0;
+    pf.col_slots_packed = packed ? K->slots_packed : 0;
+    pf.value_stream = vs;
+    // vector passes of one classic iteration: k_step reads r, v (+ p, x unless deferred; + b^ for the
+    // merit sum) and writes r (+ x); k_update reads r, p (+ x when deferred) and writes p (+ x)
+    pf.cg_iteration_vector_bytes = 3 * K->nloc * 8 * ((ctx->cg_defer_x && !ctx->cg_merit_stop ? 8 : 9) + (ctx->cg_merit_stop ? 1 : 0));
+    pf.loop_kernel_launches = n_launch;
+    pf.loop_collectives = n_coll;
+    pf.loop_stream_waits = n_wait;
+    pf.loop_iterations_enqueued = n_enqueued;
+    // what the stream spent in the exchanges (RCCL launches, or peer-to-peer waits): events around each
+    auto sum_pairs = [](const std::vector<hipEvent_t> &ev, double *tot, int64_t *cnt) {
+        *tot = 0; *cnt = 0;
+        for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, ev[i], ev[i + 1]) == hipSuccess) { *tot += t; (*cnt)++; }
+        }
+    };
+    sum_pairs(red_ev, &pf.comm_reduce_ms_total, &pf.comm_reduce_calls);
+    sum_pairs(halo_ev, &pf.comm_halo_ms_total, &pf.comm_halo_calls);
     return STAN_OK;
+}
+
+}  // namespace
+
+int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_f,
+                   int32_t max_its, int32_t precision_mode, double *d_U, int32_t *term_out,
+                   int32_t *iters_out, double *rel_res_out) {
+    if (precision_mode != STAN_PREC_FP64 && precision_mode != STAN_PREC_MIXED &&
+        precision_mode != STAN_PREC_FIXED48) {
+        ctx->err = "cg_solve: unknown precision_mode";
+        return STAN_E_UNSUPPORTED;
+    }
+    if (eps_f < 0 || max_its < 0) {
+        ctx->err = "cg_solve: eps_f and max_its must be >= 0";
+        return STAN_E_ARG;
+    }
+    if (eps_f == 0 && max_its == 0) eps_f = 1.0e-6;  // lincgsetcond
+    // no hipFree while the peers' streams wait for this rank's future exchanges (stan_ctx::defer_frees); the guard
+    // outlives the run object, whose buffers are released into the deferred list
+    struct free_later { stan_ctx *c; ~free_later() { if (c->defer_frees) { stan_flush_deferred(c); stan_p2p_ipc_trim(c); } } } free_guard{ctx};
+    cg_run R{ctx, K, d_F, eps_f, max_its, precision_mode, d_U};
+    STANCHK(R.setup());
+
+    constexpr int MAX_PASSES = 8;
+    int type = 0, passes = 0;
+    int64_t its = 0;
+    double bnorm0 = 0, rel_rec = 0, rel64 = -1.0, prev_rel64 = 0, eps_pass = eps_f;
+    const double *x_result = nullptr;
+    for (;;) {
+        const int64_t left = max_its > 0 ? (int64_t)max_its - its : 0;
+        STANCHK(R.pass(passes == 0, eps_pass, (int32_t)left));
+        passes++;
+        its += R.pass_its;
+        type = R.pass_type;
+        if (passes == 1) bnorm0 = R.h_sc[S_BNORM];
+        // ||r|| / ||b|| of the loop's own recurrence, against the ORIGINAL right-hand side (what alglib reports)
+        rel_rec = bnorm0 > 0 ? std::sqrt(R.h_sc[S_R2OUT]) / bnorm0 : 0.0;
+        x_result = R.xfin;
+        if (R.vs == STAN_PREC_FP64) break;
+        // ---- a reduced-precision stream: what was delivered, in fp64 ----
+        double *xg = const_cast<double *>(R.xfin);
+        if (passes > 1) {   // the passes' iterates add up: x = x_1 + d_2 + ...; gathered from p (a vector the peers know)
+            hipLaunchKernelGGL(k_accumulate, dim3(R.vg), dim3(VEC_T), 0, R.st_, R.n3, R.xacc, R.xfin, R.p);
+            xg = R.p;
+            x_result = R.xacc;
+        }
+        double r2 = 0;
+        STANCHK(R.fp64_check(xg, passes > 1 ? R.b0 : R.bh, &r2));
+        rel64 = bnorm0 > 0 ? std::sqrt(r2) / bnorm0 : 0.0;
+        const bool met = rel64 <= eps_f || bnorm0 == 0;
+        if (type != 1) break;                       // 5, 7, -4, -5: reported as the loop ended, with the fp64 residual
+        if (met) break;
+        // the recurrence says converged, the fp64 residual does not: another pass on r_t (iterative refinement) ...
+        const bool out_of_its = max_its > 0 && its >= max_its;
+        const bool stalled = passes > 1 && !(rel64 < 0.5 * prev_rel64);
+        if (R.refine == 0 || passes >= MAX_PASSES || out_of_its || stalled || !std::isfinite(rel64)) {
+            type = out_of_its ? 5 : 7;             // ... or the truth: no further progress at this precision (alglib's 7)
+            break;
+        }
+        if (passes == 1) {
+            STANCHK(alloc(ctx, R.bufs, &R.xacc, (size_t)(R.n3 > 0 ? R.n3 : 1)));
+            STANCHK(alloc(ctx, R.bufs, &R.b0, (size_t)(R.n3 > 0 ? R.n3 : 1)));
+            HIPCHK(ctx, hipMemcpyAsync(R.xacc, R.xfin, (size_t)R.n3 * 8, hipMemcpyDeviceToDevice, R.st_));
+            HIPCHK(ctx, hipMemcpyAsync(R.b0, R.bh, (size_t)R.n3 * 8, hipMemcpyDeviceToDevice, R.st_));
+        }
+        prev_rel64 = rel64;
+        eps_pass = eps_f / rel64;                   // ||r|| <= eps ||b0|| with ||b_pass|| = ||r_t|| = rel64 ||b0||
+        HIPCHK(ctx, hipMemsetAsync(R.sc, 0, S_NSCAL * 8, R.st_));
+        if (R.sr) HIPCHK(ctx, hipMemsetAsync(R.sv, 0, (size_t)R.n3 * 8, R.st_));
+    }
+    return R.finish(x_result, type, its, rel_rec, rel64, passes, term_out, iters_out, rel_res_out);
 }
 
 // y = K x on the reduced system (test helper; single rank)
@@ -1095,6 +1282,23 @@ int stan_spmv_reduced(stan_ctx *ctx, stan_matrix *K, const double *d_x, double *
     launch_spmv<double, 0>(ctx, K, K->d_vals, xf, yf, nullptr, stt, 1);
     // compress (and undo the row scaling)
     hipLaunchKernelGGL(k_compress_div, dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, n3, K->d_red, sdiv, yf, d_y);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(st_));
+    return STAN_OK;
+}
+
+// diag[d - red[d]] = K_dd on the free DOFs (single rank)
+int stan_matrix_diagonal(stan_ctx *ctx, stan_matrix *K, double *d_diag) {
+    if (ctx->nranks != 1) { ctx->err = "matrix_diagonal: single-rank contexts only"; return STAN_E_UNSUPPORTED; }
+    hipStream_t st_ = ctx->stream;
+    const int64_t n3 = 3 * K->nloc;
+    dev_bufs bufs;
+    double *full;
+    STANCHK(alloc(ctx, bufs, &full, (size_t)(n3 > 0 ? n3 : 1)));
+    if (K->nloc > 0)
+        hipLaunchKernelGGL(k_diag_get, dim3(nblk(K->nloc, 256)), dim3(256), 0, st_, K->nloc, K->d_rowlen, K->d_posof,
+                           K->d_slot_ptr, K->d_cols, K->d_vals, K->scaled ? K->d_scale : (const double *)nullptr, full);
+    hipLaunchKernelGGL(k_compress_div, dim3(vec_grid(n3)), dim3(VEC_T), 0, st_, n3, K->d_red, (const double *)nullptr, full, d_diag);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(st_));
     return STAN_OK;

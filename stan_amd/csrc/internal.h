@@ -236,6 +236,7 @@ struct stan_ctx {
     bool cols16 = true;            // SpMV reads the packed column stream where a slice allows it
     int vec_store_nt = 3;          // bit 0: p (k_update), bit 1: r (k_step) leave through non-temporal stores
     bool cg_fold_reduce = true;    // reductions finished by the producing kernel's last block
+    int cg_refine = 1;             // STAN_OPT_CG_REFINE: reduced-precision streams -- 0 fp64 check only, 1 + refinement passes, 2 + fp64 refresh products
     bool overlap_halo = true;  // interior SpMV on a side stream while the halo is exchanged
     hipStream_t side = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
@@ -357,6 +358,7 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
                    int32_t max_its, int32_t precision_mode, double *d_U, int32_t *term,
                    int32_t *iters, double *rel_res);
 int stan_spmv_reduced(stan_ctx *ctx, stan_matrix *K, const double *d_x, double *d_y);
+int stan_matrix_diagonal(stan_ctx *ctx, stan_matrix *K, double *d_diag);
 int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode, int32_t reps,
                            double *avg_ms);
 int stan_spmv_local(stan_ctx *ctx, stan_matrix *K, const double *d_x, double *d_y);

@@ -32,6 +32,7 @@ OPT_PLACEMENT_MAX_BYTES = 16
 OPT_SELL_SIGMA = 17
 OPT_COMM_P2P = 18
 OPT_ROW_FOLDING = 19
+OPT_CG_REFINE = 20
 E_HIP, E_ARG, E_ALLOC, E_DETJ, E_DOF_LAYOUT, E_VALENCE, E_COMM, E_UNSUPPORTED = (
     -1, -2, -3, -4, -5, -6, -7, -8)
 
@@ -44,7 +45,7 @@ EXPORTS = [
     "stan_hip_set_profiling", "stan_hip_get_profile", "stan_hip_set_option", "stan_hip_recover_hex8", "stan_hip_recover_hex8_dev",
     "stan_hip_nodal_forces_hex8", "stan_hip_pool_info",
     "stan_hip_matrix_plan", "stan_hip_spmv_local", "stan_hip_comm_info",
-    "stan_hip_matrix_part_info", "stan_hip_get_profile_rank", "stan_hip_device_info",
+    "stan_hip_matrix_part_info", "stan_hip_get_profile_rank", "stan_hip_device_info", "stan_hip_matrix_diagonal",
 ]
 # only in the lab build (stan_amd/csrc/lab/stan_hip_lab.h, selected with STAN_HIP_LIB)
 LAB_EXPORTS = ["stan_hip_csr_spmv_bench", "stan_hip_lab_placement_map", "stan_hip_lab_placement_variants", "stan_hip_lab_placement_alloc", "stan_hip_lab_placement_rounds", "stan_hip_lab_placement_cross", "stan_hip_lab_incg_penalty", "stan_hip_lab_placement_vecalloc", "stan_hip_lab_placement_vecshape", "stan_hip_lab_pairing_pmc"]
@@ -70,7 +71,9 @@ class Profile(C.Structure):
                 ("placement_ms_best", C.c_float), ("placement_ms_worst", C.c_float),
                 ("col_slots_packed", C.c_int64), ("placement_moved_vectors", C.c_int32), ("repacked_streams", C.c_int32),
                 ("loop_stream_waits", C.c_int64), ("comm_reduce_ms_total", C.c_double),
-                ("comm_reduce_calls", C.c_int64), ("comm_halo_ms_total", C.c_double), ("comm_halo_calls", C.c_int64)]
+                ("comm_reduce_calls", C.c_int64), ("comm_halo_ms_total", C.c_double), ("comm_halo_calls", C.c_int64),
+                ("rel_residual_recurrence", C.c_double), ("rel_residual_fp64", C.c_double), ("refine_passes", C.c_int32),
+                ("fp64_products", C.c_int32), ("fp64_products_ms", C.c_double)]
 
 
 class StanHipError(RuntimeError):
@@ -364,6 +367,20 @@ class Matrix:
         self.ctx._chk(self.ctx.lib.stan_hip_spmv(self.ctx.h, self.k, _ptr(x, C.c_double),
                                                  _ptr(y, C.c_double)))
         return y
+
+    def diagonal(self):
+        """K_ii of the reduced system (unscaled)."""
+        d = np.zeros(self.info()["n_reduced"])
+        self.ctx._chk(self.ctx.lib.stan_hip_matrix_diagonal(self.ctx.h, self.k, _ptr(d, C.c_double)))
+        return d
+
+    def scaled_residual(self, F, U):
+        """||S (F - K U)|| / ||S F|| with s_i = 1/sqrt(K_ii): the quantity stan_hip_cg_solve reports, from an
+        independent product (stan_hip_spmv) and the exported diagonal."""
+        d = self.diagonal()
+        s = np.where(d > 0, 1.0 / np.sqrt(np.where(d > 0, d, 1.0)), 1.0)
+        r = s * (np.asarray(F, dtype=np.float64) - self.spmv(U))
+        return float(np.linalg.norm(r) / np.linalg.norm(s * F))
 
     def plan(self):
         lib, h = self.ctx.lib, self.ctx.h

@@ -224,8 +224,8 @@ def test_config5_at_size_400_cubed(gpu_ctx, oracle):
       G1  400^3 HEX8_G1 assembly: block count, symmetry, the rigid-translation null vector on rows away from the clamp,
           and the three columns of an interior node against the ORACLE's columns of the same stencil (a 6^3 cube: an
           interior row of a uniform mesh does not depend on the mesh size);
-      G2  400^3 HEX8_G2, fp32 matrix / fp64 vectors (STAN_PREC_MIXED) to 1e-8, with an INDEPENDENT residual: F - K U
-          through the library's plain fp64 product on the unscaled matrix."""
+      G2  400^3 HEX8_G2, fp32 matrix / fp64 vectors (STAN_PREC_MIXED) to 1e-8 IN FP64 TERMS (refinement passes), with an
+          INDEPENDENT residual: F - K U through the library's plain fp64 product on the unscaled matrix."""
     import time
     from stan_amd import hip
     avail_gb = 0
@@ -291,20 +291,26 @@ def test_config5_at_size_400_cubed(gpu_ctx, oracle):
     gpu_ctx.set_option(hip.OPT_CG_MERIT_STOP, 0)
     try:
         K = gpu_ctx.assemble_hex8(job2.xyz, job2.node_dof, job2.conn, job2.elem_mat, job2.elem_type, job2.mat_E_nu, job2.red)
-        r_true = None
+        gpu_ctx.set_profiling(True)
         U, rep = K.cg_solve(job2.F, 1e-8, precision_mode=hip.PREC_MIXED)
     finally:
         gpu_ctx.set_option(hip.OPT_CG_MERIT_STOP, 1)
+        gpu_ctx.set_profiling(False)
+    prof = gpu_ctx.profile()
+    # Round 5: the library says what it delivered.  The loop iterates on the fp32 copy; rel_residual is the residual of
+    # the returned point under the FP64 matrix (one extra product), and the default (STAN_OPT_CG_REFINE = 1) keeps
+    # refining until THAT meets eps.  Checked against an independent figure: the library's plain product on the unscaled
+    # matrix and the exported diagonal, combined in numpy (Matrix.scaled_residual).
     assert rep["terminationtype"] == 1 and rep["rel_residual"] <= 1e-8, rep
-    # the fp32 copy of the matrix is what the CG solved; against the fp64 matrix the residual is bounded by the
-    # rounding of the entries: ||(K - K32) U|| / ||F||  ~  6e-8 ||K|| ||U|| / ||F||  (kappa-dependent: measured 1.7e-3 in U
-    # at 148^3); assert the fp64 residual is finite and of that order, not 1e-8
-    KU = K.spmv(U)     # (library's plain fp64 product, K^ unscaled internally: stan_spmv_reduced)
-    r_true = np.linalg.norm(job2.F - KU) / np.linalg.norm(job2.F)
-    print("400^3: mesh %.0f s, G1 part %.0f s, total %.0f s; mixed solve %d its, recurrence residual %.2e, fp64 residual %.2e" %
-          (t_mesh, t_g1, time.time() - t0, rep["iterations"], rep["rel_residual"], r_true))
-    assert np.isfinite(r_true) and r_true <= 1e-2
-    assert 2000 <= rep["iterations"] <= 6000
+    r_true = K.scaled_residual(job2.F, U)
+    print("400^3: mesh %.0f s, G1 part %.0f s, total %.0f s; mixed solve %d its in %d pass(es), recurrence residual %.2e, "
+          "fp64 residual reported %.3e, independent %.3e" %
+          (t_mesh, t_g1, time.time() - t0, rep["iterations"], prof["refine_passes"], prof["rel_residual_recurrence"],
+           rep["rel_residual"], r_true))
+    assert abs(r_true - rep["rel_residual"]) <= 0.1 * rep["rel_residual"] + 1e-12   # (two fp64 products in different orders)
+    assert r_true <= 1.1e-8
+    assert prof["rel_residual_fp64"] == rep["rel_residual"] and prof["fp64_products"] >= 1
+    assert 2000 <= rep["iterations"] <= 12000
     K.free()
 
 
