@@ -235,10 +235,19 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
                               (S K S) d = r_t on the reduced-precision stream to ||r|| <= eps_f ||S F|| and x^ += d in fp64; at
                               most 8 passes, stopped with type 7 when a pass does not halve r_t, type 5 at max_its (counted
                               over all passes); iterations = the sum.
-                           2: as 1, and the loop's periodic residual recomputation (STAN_OPT_CG_RUPDATE, every 10th
-                              iteration) multiplies with the fp64 values ("reliable updates": the recurrence is re-anchored to
-                              the true residual while the Krylov directions are kept; costs one fp64 product per 10
-                              reduced-precision ones instead of the fused two-product pass). */
+                           2: as 1, and the loop's periodic residual recomputation multiplies with the fp64 values, every 50
+                              iterations instead of every STAN_OPT_CG_RUPDATE ("reliable updates": the recurrence is re-anchored
+                              to the true residual while the Krylov directions are kept; one pass usually suffices).  Meant for
+                              STAN_OPT_CG_MERIT_STOP = 0: the merit sum jumps at a re-anchoring and alglib's rule may read
+                              that as "no further progress".
+                           MEASURED (148^3, eps 1e-8, merit stop off; profiles/r05/mixed_refine_n148.txt): fp64 1333
+                           iterations, 1.56 s.  fp32 copy: refine 0 -- 1333 iterations, 0.96 s, fp64 residual 1.9e-4 (type 7), U
+                           off by 1.7e-3; refine 1 -- 3 passes, 2808 iterations, 2.02 s, U within 6e-9 of the oracle's; refine 2 --
+                           1 pass, 2346 iterations, 1.70 s, 6e-10.  The fp32 copy halves the bytes per product but an answer of
+                           fp64 quality costs MORE time than the fp64 stream: kappa amplifies the 6e-8 rounding of the entries
+                           four orders above eps, and a restarted or re-anchored CG pays for it in iterations.  FIXED-48
+                           (absolute entry error 7e-15) passes its check at once: 1333 iterations, 1.27 s -- that is the
+                           reduced-byte mode that keeps the answer. */
 #define STAN_OPT_POOL 7 /* 1 (default): device blocks >= 8 MB freed by the library stay with the
                            context and are reused by its next allocations (a hipMalloc of tens of GB
                            costs 0.4-1.8 s here); 0: release them now, plain hipMalloc/hipFree from then on */

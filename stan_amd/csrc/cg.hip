@@ -638,8 +638,10 @@ struct cg_run {
     event_bag events;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool dist = false, p2p = false, sr = false, foldr = false, split = false;
-    int vs = STAN_PREC_FP64;          // the stream the loop's products read
-    int refine = 0;                   // STAN_OPT_CG_REFINE, reduced-precision streams only
+    int vs = STAN_PREC_FP64;          // the stream the loop's products read on THIS rank (FIXED-48 falls back to fp64 on a rank that owns no
+                                      // rows or whose shard is not representable: never a base for decisions the ranks must share)
+    bool reduced = false;             // the caller asked for a reduced-precision stream: fp64 check + refinement (every rank alike)
+    int refine = 0;                   // STAN_OPT_CG_REFINE, reduced-precision modes only
     int64_t n3 = 0, npad = 0, ng = 0, dof0 = 0;
     dev_bufs bufs;
     double *xb[2] = {nullptr, nullptr}, *p = nullptr, *r = nullptr, *v = nullptr, *w = nullptr, *bh = nullptr;
@@ -715,8 +717,8 @@ struct cg_run {
     // y = A^ x (x gets its halo filled first when sharded) with `dot` sums (k_spmv's DOT) reduced into out[0..dot):
     // folded into the last launch of the product, or by k_reduce.  kind: the value stream (the loop's own, or
     // STAN_PREC_FP64 for the check / refresh products of a reduced-precision solve).
-    int spmv(double *x, double *y, int dot, double *out, int64_t k, p2p_out po, int kind) {
-        const bool own = kind == vs;
+    int spmv(double *x, double *y, int dot, double *out, int64_t k, p2p_out po, int kind, bool extra = false) {
+        const bool own = !extra;   // extra: an fp64 product inside a reduced-precision solve (check, refresh): timed apart
         if (ctx->profiling) {
             hipEvent_t a = events.make(), b = events.make();
             hipEventRecord(a, st_);
@@ -839,7 +841,8 @@ int cg_run::setup() {
     if (precision_mode == STAN_PREC_FIXED48) STANCHK(stan_matrix_make_fx48(ctx, K));
     // the stream the products really read (FIXED-48 falls back to fp64 when K is not SPD-scalable)
     vs = precision_mode == STAN_PREC_FIXED48 ? (K->d_vals48 ? STAN_PREC_FIXED48 : STAN_PREC_FP64) : precision_mode;
-    refine = vs == STAN_PREC_FP64 ? 0 : ctx->cg_refine;
+    reduced = precision_mode != STAN_PREC_FP64;
+    refine = reduced ? ctx->cg_refine : 0;
     if (!stan_small_system(ctx, K)) {
         const int rc_fold = stan_matrix_make_folded(ctx, K, vs);
         if (rc_fold == STAN_E_ALLOC) {   // an optimisation must not fail the solve: the padded streams serve
@@ -927,8 +930,13 @@ int cg_run::iterate(double eps_pass, int32_t max_its_pass) {
     // STAN_OPT_CG_REFINE = 2 on a reduced-precision stream: the periodic residual recomputation (alglib's
     // ItsBeforeRUpdate) multiplies with the fp64 values -- the recurrence is re-anchored to the true residual
     // ("reliable updates"), so the literal second product replaces the fused two-product pass
-    const bool refresh64 = refine >= 2 && vs != STAN_PREC_FP64;
+    const bool refresh64 = refine >= 2;
     const int kind_refresh = refresh64 ? STAN_PREC_FP64 : vs;
+    // ... and then every REFRESH64 iterations instead of every STAN_OPT_CG_RUPDATE: a refresh on the reduced stream in
+    // between would undo the anchoring, and the iteration count does not depend on the period (148^3, fp32 copy: 2346
+    // iterations with 10, 20 and 50; profiles/r05/mixed_refine_n148.txt) while every fp64 product costs two of the others
+    constexpr int REFRESH64 = 50;
+    const int rupdate = refresh64 ? (ctx->cg_rupdate > 0 ? REFRESH64 : 0) : ctx->cg_rupdate;
     if (sr) {   // w_0 = A r_0 with gamma_0, delta_0 (merit_0 = 0 sits in the zeroed scalars)
         if (p2p)         // ... or, peer to peer, is sent as this rank's zero into the slot of the first reduction
             hipLaunchKernelGGL(k_reduce<1>, dim3(1), dim3(256), 0, st_, partial, 0, sc + S_SR_MERIT, p2p_to(2, false), (const int64_t *)nullptr, (int64_t)0);
@@ -940,7 +948,7 @@ int cg_run::iterate(double eps_pass, int32_t max_its_pass) {
     while (!done && rc == STAN_OK) {
         // enqueue one chunk of iterations
         for (int c = 0; c < chunk && k < hard_cap; c++, k++) {
-            const bool refresh = ctx->cg_rupdate > 0 && (k % ctx->cg_rupdate) == 0;
+            const bool refresh = rupdate > 0 && (k % rupdate) == 0;
             if (sr) {
                 sr_args a;
                 a.n3 = n3; a.k = k; a.sc = sc; a.st = stt; a.epsf = eps_pass; a.maxits = max_its_pass;
@@ -955,7 +963,7 @@ int cg_run::iterate(double eps_pass, int32_t max_its_pass) {
                 n_launch++;
                 if (!refresh) reduce_if_unfolded((int)vg, 1, sc + S_SR_MERIT, p2p_to(2, false), k);
                 else {   // r' = b^ - A^ x' (ALGLIB's periodic residual recomputation), then as usual
-                    rc = spmv(xb[k & 1], v, 0, nullptr, k, NO_P2P, kind_refresh);
+                    rc = spmv(xb[k & 1], v, 0, nullptr, k, NO_P2P, kind_refresh, refresh64);
                     if (rc) break;
                     hipLaunchKernelGGL(k_refresh, dim3(vg), dim3(VEC_T), 0, st_, n3, k, (const int64_t *)stt,
                                        bh, v, xb[k & 1], r, partial, vec_fold(sc + S_SR_DELTA, p2p_to(1, false)));
@@ -991,7 +999,7 @@ int cg_run::iterate(double eps_pass, int32_t max_its_pass) {
             n_launch++;
             if (a.refresh == 1) {
                 // a -5/-4 stop of this iteration is caught by k_refresh/k_update (ITER_B <= k)
-                rc = spmv(xb[k & 1], v, 0, nullptr, k, NO_P2P, kind_refresh);
+                rc = spmv(xb[k & 1], v, 0, nullptr, k, NO_P2P, kind_refresh, refresh64);
                 if (rc) break;
                 hipLaunchKernelGGL(k_refresh, dim3(vg), dim3(VEC_T), 0, st_, n3, k,
                                    (const int64_t *)stt, bh, v, xb[k & 1], r, partial, vec_fold(sc + S_R2NEW, po_r));
@@ -1087,7 +1095,7 @@ void cg_run::account_pass() {
 // r_t = b - A^64 xg with the fp64 values of the scaled matrix (xg: a gather vector -- one of the vectors the peers know,
 // cg_run::setup -- holding the iterate on the owned rows); r_t stays in r, *r2_out = ||r_t||^2 over all ranks.
 int cg_run::fp64_check(double *xg, const double *b, double *r2_out) {
-    STANCHK(spmv(xg, v, 0, nullptr, 0, NO_P2P, STAN_PREC_FP64));
+    STANCHK(spmv(xg, v, 0, nullptr, 0, NO_P2P, STAN_PREC_FP64, true));
     const p2p_out po = p2p_to(0, true);
     hipLaunchKernelGGL(k_refresh, dim3(vg), dim3(VEC_T), 0, st_, n3, (int64_t)0, (const int64_t *)stt, b, v,
                        (const double *)xg, r, partial, vec_fold(sc + S_CHK_R2, po));
@@ -1227,8 +1235,8 @@ int stan_cg_device(stan_ctx *ctx, stan_matrix *K, const double *d_F, double eps_
         // ||r|| / ||b|| of the loop's own recurrence, against the ORIGINAL right-hand side (what alglib reports)
         rel_rec = bnorm0 > 0 ? std::sqrt(R.h_sc[S_R2OUT]) / bnorm0 : 0.0;
         x_result = R.xfin;
-        if (R.vs == STAN_PREC_FP64) break;
-        // ---- a reduced-precision stream: what was delivered, in fp64 ----
+        if (!R.reduced) break;
+        // ---- a reduced-precision mode: what was delivered, in fp64 ----
         double *xg = const_cast<double *>(R.xfin);
         if (passes > 1) {   // the passes' iterates add up: x = x_1 + d_2 + ...; gathered from p (a vector the peers know)
             hipLaunchKernelGGL(k_accumulate, dim3(R.vg), dim3(VEC_T), 0, R.st_, R.n3, R.xacc, R.xfin, R.p);

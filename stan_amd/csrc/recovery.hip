@@ -18,37 +18,53 @@
 
 namespace {
 
+// Round 5 (profiles/r05/k_recover.md): the first form let each of the 8 lanes of an element load all 8 nodes' coordinates
+// and displacements itself (56 gathers per lane) and store its 6 + 6 values 48 B apart: 1.73 ms at 148^3 for 3.2 GB =
+// 0.23 of the HBM peak, bound by the address pipeline.  Now lane i of an element loads node i only (7 gathers) and the
+// element's 48 values go round through LDS (one record per element, 49 doubles apart: no bank conflicts between the 8
+// elements of a wave); the node extrapolation value_i = sum_g N[i][g] value_g uses the tensor structure of
+// N[i][g] = prod_axis 1/2 (1 + s_i s_g sqrt 3) -- three butterfly stages (x: lane ^ 1, y: lane ^ 3, z: lane ^ 4 in CHEXA
+// order) instead of an 8-term sum of shuffles; the results leave through LDS as full 512-B lines.
+constexpr int REC = 49;   // doubles per element record in LDS (48 + 1: records of the 8 elements of a wave start in different banks)
+
 template <bool FORCES>
 __global__ void __launch_bounds__(256)
-k_recover(int64_t n_elem, const double *xyz, const double *disp, const int32_t *conn,
-          const int32_t *elem_mat, const uint8_t *elem_type, const double *mat_lamG,
-          double *strain, double *stress, long long *bad_elem, long long *g1_elem,
-          const int32_t *node_dof, double *elem_forces, double *R) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t e = t >> 3;
-    const int g = (int)(t & 7);
-    const int lane = threadIdx.x & 63;
+k_recover(int64_t n_elem, const double *__restrict__ xyz, const double *__restrict__ disp, const int32_t *__restrict__ conn,
+          const int32_t *__restrict__ elem_mat, const uint8_t *__restrict__ elem_type, const double *__restrict__ mat_lamG,
+          double *__restrict__ strain, double *__restrict__ stress, long long *bad_elem, long long *g1_elem,
+          const int32_t *__restrict__ node_dof, double *__restrict__ elem_forces, double *R) {
+    __shared__ double lds[4][8 * REC];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int el = lane >> 3, g = lane & 7;
+    const int64_t e0 = ((int64_t)blockIdx.x * 4 + wv) * 8;   // first element of this wave
+    const int64_t e = e0 + el;
     const bool valid = e < n_elem;
     double eps[6] = {0, 0, 0, 0, 0, 0}, sig[6] = {0, 0, 0, 0, 0, 0};
     double o[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, det = 0, px = 0, py = 0, pz = 0;
     bool live = false;  // a HEX8_G2 element of the batch
+    int type = 0;
+    int64_t nd = 0;
+    double *rec = lds[wv] + el * REC;
     if (valid) {
-        const int type = elem_type[e];
+        type = elem_type[e];
+        nd = conn[e * 8 + g];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            rec[3 * g + c] = xyz[3 * nd + c];
+            rec[24 + 3 * g + c] = disp[3 * nd + c];
+        }
+    }
+    // wave-local exchange: the LDS executes one wave's instructions in order (as in k_spmv_fold)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (valid) {
         if (type != STAN_HEX8_G2) {
             if (g == 0) atomicMin(g1_elem, (long long)e);
         } else {
             live = true;
-            double x[24], u[24];
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int64_t nd = conn[e * 8 + i];
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    x[3 * i + c] = xyz[3 * nd + c];
-                    u[3 * i + c] = disp[3 * nd + c];
-                }
-            }
-            det = hex8_gp_setup(x, type, g, o);
+            const double *u = rec + 24;   // the element's record stays in LDS: coordinates [0, 24), displacements [24, 48)
+            det = hex8_gp_setup(rec, type, g, o);
             if (det == 0.0) atomicMin(bad_elem, (long long)e);
             const double gl = hex8_gauss_loc(type);
             px = hex8_sign(HEX8_SX, g) * gl; py = hex8_sign(HEX8_SY, g) * gl;
@@ -74,27 +90,39 @@ k_recover(int64_t n_elem, const double *xyz, const double *disp, const int32_t *
             sig[3] = G * eps[3]; sig[4] = G * eps[4]; sig[5] = G * eps[5];
         }
     }
-    // node i = this lane's index within the element; N[i][k] = 1/8 prod (1 + s_i s_k sqrt 3)
+    // node i = this lane's index within the element; N[i][k] = prod over the axes of 1/2 (1 + s_i s_k sqrt 3): a when node
+    // and Gauss point lie on the same side of the axis, b otherwise (FE_Library.cs:105-116, 285-321 evaluated at
+    // xi = +-sqrt 3); the partner across an axis is lane ^ 1 (xi), ^ 3 (eta), ^ 4 (zeta) in the CHEXA order of HEX8_S*
     const int i = g;
-    const double r3 = 1.7320508075688772935;  // 1 / GaussLocation
-    double ne[6] = {0, 0, 0, 0, 0, 0}, ns[6] = {0, 0, 0, 0, 0, 0};
+    const double ca = 0.5 * (1.0 + 1.7320508075688772935), cb = 0.5 * (1.0 - 1.7320508075688772935);
+    double ne[6], ns[6];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const double N = 0.125 * (1 + hex8_sign(HEX8_SX, i) * hex8_sign(HEX8_SX, k) * r3) *
-                         (1 + hex8_sign(HEX8_SY, i) * hex8_sign(HEX8_SY, k) * r3) *
-                         (1 + hex8_sign(HEX8_SZ, i) * hex8_sign(HEX8_SZ, k) * r3);
-        const int src = (lane & ~7) | k;
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-            ne[c] += N * __shfl(eps[c], src, 64);
-            ns[c] += N * __shfl(sig[c], src, 64);
-        }
+    for (int c = 0; c < 6; c++) {
+        double a = eps[c], b = sig[c];
+        a = ca * a + cb * __shfl_xor(a, 1, 64); b = ca * b + cb * __shfl_xor(b, 1, 64);
+        a = ca * a + cb * __shfl_xor(a, 3, 64); b = ca * b + cb * __shfl_xor(b, 3, 64);
+        a = ca * a + cb * __shfl_xor(a, 4, 64); b = ca * b + cb * __shfl_xor(b, 4, 64);
+        ne[c] = a; ns[c] = b;
     }
-    if (valid && strain) {
+    if (strain) {
+        // the wave's 8 x 48 values of each array are contiguous in memory: through LDS, out as six 512-B lines
+        double *stg = lds[wv];
 #pragma unroll
-        for (int c = 0; c < 6; c++) {
-            strain[e * 48 + i * 6 + c] = ne[c];
-            stress[e * 48 + i * 6 + c] = ns[c];
+        for (int q = 0; q < 2; q++) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int c = 0; c < 6; c++) stg[lane * 6 + c] = q ? ns[c] : ne[c];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double *dst = (q ? stress : strain) + e0 * 48;
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const int idx = j * 64 + lane;
+                if (e0 + idx / 48 < n_elem) __builtin_nontemporal_store(stg[idx], dst + idx);
+            }
         }
     }
     if (FORCES) {
@@ -120,7 +148,6 @@ k_recover(int64_t n_elem, const double *xyz, const double *disp, const int32_t *
             }
         }
         if (live) {
-            const int64_t nd = conn[e * 8 + i];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 if (elem_forces) elem_forces[e * 24 + 3 * i + c] = mine[c];
@@ -148,8 +175,7 @@ int stan_recover_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz, con
     long long init[2] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL};
     hipError_t e1 = hipMemcpyAsync(d_lamG, lamG.data(), lamG.size() * 8, hipMemcpyHostToDevice, st);
     hipError_t e2 = hipMemcpyAsync(ctx->d_status + SS_BAD_ELEM, init, 16, hipMemcpyHostToDevice, st);
-    const int64_t nthreads = n_elem * 8;
-    const dim3 grid((unsigned)((nthreads + 255) / 256)), block(256);
+    const dim3 grid((unsigned)((n_elem + 31) / 32)), block(256);   // 8 lanes per element, 8 elements per wave
     if (forces)
         hipLaunchKernelGGL(k_recover<true>, grid, block, 0, st, n_elem, d_xyz, d_disp, d_conn, d_elem_mat,
                            d_elem_type, d_lamG, d_strain, d_stress, (long long *)(ctx->d_status + SS_BAD_ELEM),
