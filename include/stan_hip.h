@@ -335,12 +335,29 @@ int stan_hip_recover_hex8_dev(stan_ctx *ctx, int64_t n_nodes, const double *d_xy
                               int32_t n_mat, const double *mat_E_nu, double *d_strain,
                               double *d_stress);
 
+/* The same recovery with the results KEPT ON THE DEVICE(S): what a host that serialises them element by element needs
+ * (the console driver's ExportOutput, Solver.cs:454-462: at 148^3 the two arrays are 2.5 GB, and bringing them to the host
+ * as whole arrays before the writer starts was a tenth of the run).  stan_hip_results_map copies the rows of elements
+ * [e0, e1) into pinned staging memory of the CALLING THREAD and returns pointers to it ([ (e1-e0) * 48 ] each, valid
+ * until that thread's next map call): writer threads map the chunk they are encoding, so the download overlaps the
+ * encoding and the file writes.  Any number of threads may map concurrently.  On a multi-device handle the elements are
+ * cut into one contiguous chunk per device (as stan_hip_recover_hex8 does); a range may span chunks. */
+typedef struct stan_results stan_results;
+int stan_hip_recover_hex8_keep(stan_ctx *ctx, int64_t n_nodes, const double *xyz, const double *disp,
+                               int64_t n_elem, const int32_t *conn, const int32_t *elem_mat,
+                               const uint8_t *elem_type, int32_t n_mat, const double *mat_E_nu, stan_results **out);
+int stan_hip_results_map(stan_results *res, int64_t e0, int64_t e1, const double **strain, const double **stress);
+void stan_hip_results_free(stan_results *res);
+
 /* ---- element nodal forces: replaces Element.Compute_NodalForces + the R assembly ---------- */
 /* (Element.cs:248-255, Solver.cs:184-196).  f_e = sum_g BL[g]^T dS[g] det J_g w, where dS[g] is
  * the NODE-extrapolated stress row g that Recovery_Stress left behind -- the reference indexes
  * its node list by Gauss point number and that is kept.  elem_forces [n_elem*24] (node-major,
  * = Element.NodalForces) and/or R [n_dof] (R[DOF] += f, full numbering, before Exclude_BC_DOF);
- * either may be NULL, not both.  The linear-static driver discards R (Solver.cs:199). */
+ * either may be NULL, not both.  The linear-static driver discards R (Solver.cs:199).  R is accumulated with fp64
+ * atomics in whatever order the wavefronts arrive: it is the ONE output of this library that is not bit-reproducible
+ * from run to run (last-bit differences; the reference's own "+=" under Parallel.ForEach is an unsynchronised race,
+ * Solver.cs:194).  elem_forces is deterministic. */
 int stan_hip_nodal_forces_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz, const double *disp,
                                const int32_t *node_dof, int64_t n_elem, const int32_t *conn,
                                const int32_t *elem_mat, const uint8_t *elem_type, int32_t n_mat,

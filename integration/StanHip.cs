@@ -137,6 +137,11 @@ namespace STAN_Solver
 
         // ---- introspection / parity helpers
         [DllImport(Lib)] internal static extern int stan_hip_matrix_info(IntPtr K, out StanMatrixInfo info);
+        [DllImport(Lib)] internal static extern int stan_hip_recover_hex8_keep(
+            IntPtr ctx, long n_nodes, double[] xyz, double[] disp, long n_elem, int[] conn, int[] elem_mat, byte[] elem_type,
+            int n_mat, double[] mat_E_nu, out IntPtr results);
+        [DllImport(Lib)] internal static extern int stan_hip_results_map(IntPtr results, long e0, long e1, out IntPtr strain, out IntPtr stress);
+        [DllImport(Lib)] internal static extern void stan_hip_results_free(IntPtr results);
         [DllImport(Lib)] internal static extern int stan_hip_matrix_diagonal(IntPtr ctx, IntPtr K, [Out] double[] diag);
         [DllImport(Lib)] internal static extern int stan_hip_matrix_part_info(IntPtr K, int part, out StanMatrixInfo info);
         [DllImport(Lib)] internal static extern int stan_hip_ke_hex8(IntPtr ctx, double[] xyz8, double E, double nu, int type, [Out] double[] ke576);

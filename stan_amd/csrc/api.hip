@@ -426,6 +426,129 @@ int stan_hip_recover_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz, con
     return STAN_OK;
 }
 
+// ---- results kept on the device(s) (stan_hip_recover_hex8_keep) ------------------------------------------------------
+}  // extern "C"
+struct stan_results {
+    struct part { int device; int64_t e0, e1; double *d_strain, *d_stress; };
+    std::vector<part> parts;
+    int64_t n_elem = 0;
+};
+namespace {
+// pinned staging of one host thread (stan_hip_results_map): grown on demand, released when the thread ends
+struct map_stage {
+    double *p = nullptr;
+    size_t cap = 0;   // doubles
+    ~map_stage() { if (p) hipHostFree(p); }
+};
+thread_local map_stage g_stage;
+int recover_keep_one(stan_ctx *ctx, int64_t n_nodes, const double *xyz, const double *disp, int64_t n_elem, const int32_t *conn,
+                     const int32_t *elem_mat, const uint8_t *elem_type, int32_t n_mat, const double *mat_E_nu, int64_t e_base,
+                     stan_results::part *out) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (int64_t e = 0; e < n_elem; e++) {
+        if (elem_mat[e] < 0 || elem_mat[e] >= n_mat) { ctx->err = "recover_hex8: elem_mat out of range"; return STAN_E_ARG; }
+        for (int a = 0; a < 8; a++)
+            if (conn[e * 8 + a] < 0 || conn[e * 8 + a] >= n_nodes) { ctx->err = "recover_hex8: node index out of range"; return STAN_E_ARG; }
+    }
+    dbuf<double> dx, du; dbuf<int32_t> dc, dm; dbuf<uint8_t> dt;
+    STANCHK(dx.upload(ctx, xyz, (size_t)n_nodes * 3));
+    STANCHK(du.upload(ctx, disp, (size_t)n_nodes * 3));
+    STANCHK(dc.upload(ctx, conn, (size_t)n_elem * 8));
+    STANCHK(dm.upload(ctx, elem_mat, (size_t)n_elem));
+    STANCHK(dt.upload(ctx, elem_type, (size_t)n_elem));
+    // plain device memory, owned by the results object (it may outlive the context's pool)
+    double *de = nullptr, *ds = nullptr;
+    const size_t bytes = (size_t)(n_elem > 0 ? n_elem : 1) * 48 * 8;
+    if (hipMalloc((void **)&de, bytes) != hipSuccess || hipMalloc((void **)&ds, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        if (de) hipFree(de);
+        ctx->err = "recover_hex8_keep: device allocation failed";
+        return STAN_E_ALLOC;
+    }
+    int rc = stan_recover_device(ctx, n_nodes, dx.p, du.p, n_elem, dc.p, dm.p, dt.p, n_mat, mat_E_nu, de, ds, nullptr, nullptr, nullptr);
+    if (rc == STAN_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = STAN_E_HIP;
+    if (rc != STAN_OK) { hipFree(de); hipFree(ds); return rc; }
+    *out = stan_results::part{ctx->device, e_base, e_base + n_elem, de, ds};
+    return STAN_OK;
+}
+}  // namespace
+extern "C" {
+
+int stan_hip_recover_hex8_keep(stan_ctx *ctx, int64_t n_nodes, const double *xyz, const double *disp,
+                               int64_t n_elem, const int32_t *conn, const int32_t *elem_mat,
+                               const uint8_t *elem_type, int32_t n_mat, const double *mat_E_nu, stan_results **out) {
+    if (!ctx || !out || !xyz || !disp || !mat_E_nu || n_nodes <= 0 || n_mat <= 0 || n_elem < 0 ||
+        (n_elem > 0 && (!conn || !elem_mat || !elem_type)))
+        return STAN_E_ARG;
+    *out = nullptr;
+    stan_results *res = new stan_results();
+    res->n_elem = n_elem;
+    int rc = STAN_OK;
+    if (ctx->group) {
+        const int n = stan_group_size(ctx);
+        res->parts.assign((size_t)n, stan_results::part{0, 0, 0, nullptr, nullptr});
+        rc = stan_group_ctx_call_ranked(ctx, [&](stan_ctx *c, int r) {
+            const int64_t e0 = n_elem * r / n, e1 = n_elem * (r + 1) / n;
+            res->parts[(size_t)r] = stan_results::part{c->device, e0, e0, nullptr, nullptr};
+            if (e1 <= e0) return (int)STAN_OK;
+            const int e = recover_keep_one(c, n_nodes, xyz, disp, e1 - e0, conn + 8 * e0, elem_mat + e0, elem_type + e0, n_mat,
+                                           mat_E_nu, e0, &res->parts[(size_t)r]);
+            if (e == STAN_E_UNSUPPORTED || e == STAN_E_DETJ) {   // element numbers of the whole model
+                ctx->bad_elem = c->bad_elem + e0;
+                c->err = (e == STAN_E_DETJ ? "det J == 0 in element " : "stress recovery: HEX8_G1 element ") + std::to_string(ctx->bad_elem) +
+                         (e == STAN_E_DETJ ? "" : " (the reference throws: N has one row, Element.cs:242)");
+            }
+            return e;
+        });
+    } else {
+        res->parts.assign(1, stan_results::part{ctx->device, 0, 0, nullptr, nullptr});
+        if (n_elem > 0) rc = recover_keep_one(ctx, n_nodes, xyz, disp, n_elem, conn, elem_mat, elem_type, n_mat, mat_E_nu, 0, &res->parts[0]);
+    }
+    if (rc != STAN_OK) { stan_hip_results_free(res); return rc; }
+    *out = res;
+    return STAN_OK;
+}
+
+int stan_hip_results_map(stan_results *res, int64_t e0, int64_t e1, const double **strain, const double **stress) {
+    if (!res || !strain || !stress || e0 < 0 || e1 < e0 || e1 > res->n_elem) return STAN_E_ARG;
+    const size_t n = (size_t)(e1 - e0) * 48;
+    map_stage &st = g_stage;
+    if (st.cap < 2 * n) {
+        if (st.p) hipHostFree(st.p);
+        st.p = nullptr; st.cap = 0;
+        const size_t want = 2 * n > (size_t)1 << 16 ? 2 * n : (size_t)1 << 16;
+        if (hipHostMalloc((void **)&st.p, want * 8, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); st.p = nullptr; return STAN_E_ALLOC; }
+        st.cap = want;
+    }
+    for (const stan_results::part &pt : res->parts) {
+        const int64_t a = e0 > pt.e0 ? e0 : pt.e0, b = e1 < pt.e1 ? e1 : pt.e1;
+        if (b <= a) continue;
+        if (hipSetDevice(pt.device) != hipSuccess) return STAN_E_HIP;
+        const size_t off = (size_t)(a - e0) * 48, cnt = (size_t)(b - a) * 48 * 8;
+        // blocking copies on the null stream of the calling thread: the kernel that produced the data was
+        // synchronised by stan_hip_recover_hex8_keep, the library's own streams are non-blocking
+        if (hipMemcpy(st.p + off, pt.d_strain + (size_t)(a - pt.e0) * 48, cnt, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(st.p + n + off, pt.d_stress + (size_t)(a - pt.e0) * 48, cnt, hipMemcpyDeviceToHost) != hipSuccess) {
+            (void)hipGetLastError();
+            return STAN_E_HIP;
+        }
+    }
+    *strain = st.p;
+    *stress = st.p + n;
+    return STAN_OK;
+}
+
+void stan_hip_results_free(stan_results *res) {
+    if (!res) return;
+    for (stan_results::part &pt : res->parts) {
+        if (!pt.d_strain && !pt.d_stress) continue;
+        hipSetDevice(pt.device);
+        if (pt.d_strain) hipFree(pt.d_strain);
+        if (pt.d_stress) hipFree(pt.d_stress);
+    }
+    delete res;
+}
+
 int stan_hip_nodal_forces_hex8(stan_ctx *ctx, int64_t n_nodes, const double *xyz, const double *disp,
                                const int32_t *node_dof, int64_t n_elem, const int32_t *conn,
                                const int32_t *elem_mat, const uint8_t *elem_type, int32_t n_mat,

@@ -472,6 +472,7 @@ void stan_set_global_error(const std::string &msg);   // api.hip: errors raised 
 void stan_group_destroy(stan_ctx *lead);
 const char *stan_group_last_error(stan_ctx *lead);
 int stan_group_ctx_call(stan_ctx *lead, const std::function<int(stan_ctx *)> &fn);
+int stan_group_ctx_call_ranked(stan_ctx *lead, const std::function<int(stan_ctx *, int)> &fn);   // fn(rank context, rank) on every worker
 int stan_group_assemble(stan_ctx *lead, int64_t n_nodes, const double *xyz, const int32_t *node_dof,
                         int64_t n_elem, const int32_t *conn, const int32_t *elem_mat,
                         const uint8_t *elem_type, int32_t n_mat, const double *mat_E_nu, int64_t n_dof,

@@ -274,6 +274,12 @@ int stan_group_ctx_call(stan_ctx *lead, const std::function<int(stan_ctx *)> &fn
     return run_all(g, [&](int r) { return fn(g->ctx[(size_t)r]); }, RUN_JOIN);
 }
 
+int stan_group_ctx_call_ranked(stan_ctx *lead, const std::function<int(stan_ctx *, int)> &fn) {
+    stan_group *g = lead->group;
+    lead->err.clear();
+    return run_all(g, [&](int r) { return fn(g->ctx[(size_t)r], r); }, RUN_JOIN);
+}
+
 // STAN_OPT_COMM_P2P on a group handle
 int stan_group_set_p2p(stan_ctx *lead, bool on) {
     stan_group *g = lead->group;

@@ -46,6 +46,7 @@ EXPORTS = [
     "stan_hip_nodal_forces_hex8", "stan_hip_pool_info",
     "stan_hip_matrix_plan", "stan_hip_spmv_local", "stan_hip_comm_info",
     "stan_hip_matrix_part_info", "stan_hip_get_profile_rank", "stan_hip_device_info", "stan_hip_matrix_diagonal",
+    "stan_hip_recover_hex8_keep", "stan_hip_results_map", "stan_hip_results_free",
 ]
 # only in the lab build (stan_amd/csrc/lab/stan_hip_lab.h, selected with STAN_HIP_LIB)
 LAB_EXPORTS = ["stan_hip_csr_spmv_bench", "stan_hip_lab_placement_map", "stan_hip_lab_placement_variants", "stan_hip_lab_placement_alloc", "stan_hip_lab_placement_rounds", "stan_hip_lab_placement_cross", "stan_hip_lab_incg_penalty", "stan_hip_lab_placement_vecalloc", "stan_hip_lab_placement_vecshape", "stan_hip_lab_pairing_pmc"]
@@ -249,6 +250,21 @@ class Context:
             _ptr(strain, C.c_double), _ptr(stress, C.c_double)))
         return strain, stress
 
+    def recover_hex8_keep(self, xyz, disp, conn, elem_mat, elem_type, mat_E_nu):
+        """Stress recovery with the results kept on the device(s): returns a Results handle (map(e0, e1), free())."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+        disp = np.ascontiguousarray(disp, dtype=np.float64)
+        conn = np.ascontiguousarray(conn, dtype=np.int32).reshape(-1, 8)
+        elem_mat = np.ascontiguousarray(elem_mat, dtype=np.int32)
+        elem_type = np.ascontiguousarray(elem_type, dtype=np.uint8)
+        mat_E_nu = np.ascontiguousarray(mat_E_nu, dtype=np.float64).reshape(-1, 2)
+        h = C.c_void_p()
+        self._chk(self.lib.stan_hip_recover_hex8_keep(
+            self.h, C.c_int64(xyz.shape[0]), _ptr(xyz, C.c_double), _ptr(disp, C.c_double),
+            C.c_int64(conn.shape[0]), _ptr(conn, C.c_int32), _ptr(elem_mat, C.c_int32),
+            _ptr(elem_type, C.c_uint8), C.c_int32(mat_E_nu.shape[0]), _ptr(mat_E_nu, C.c_double), C.byref(h)))
+        return Results(self, h, conn.shape[0])
+
     def nodal_forces_hex8(self, xyz, disp, node_dof, conn, elem_mat, elem_type, mat_E_nu):
         """Element.NodalForces [n_elem,24] and the assembled R [n_dof] (Solver.cs:184-196)."""
         xyz = np.ascontiguousarray(xyz, dtype=np.float64)
@@ -296,6 +312,37 @@ class Context:
             _dev(d_elem_type, C.c_uint8), C.c_int32(mat_E_nu.shape[0]), _ptr(mat_E_nu, C.c_double),
             C.c_int64(n_dof), _dev(d_red, C.c_int32), C.byref(k)))
         return Matrix(self, k)
+
+
+class Results:
+    """Strain / stress of a recovery kept on the device(s) (stan_results*)."""
+
+    def __init__(self, ctx, handle, n_elem):
+        self.ctx, self.h, self.n_elem = ctx, handle, n_elem
+        ctx.lib.stan_hip_results_free.restype = None
+
+    def map(self, e0, e1):
+        """(strain, stress) of elements [e0, e1) as [e1 - e0, 8, 6] arrays (copies of the thread's staging memory)."""
+        ps, pt = C.POINTER(C.c_double)(), C.POINTER(C.c_double)()
+        rc = self.ctx.lib.stan_hip_results_map(self.h, C.c_int64(e0), C.c_int64(e1), C.byref(ps), C.byref(pt))
+        if rc != 0:
+            raise StanHipError(rc, "stan_hip_results_map")
+        n = (e1 - e0) * 48
+        if n == 0:
+            return np.zeros((0, 8, 6)), np.zeros((0, 8, 6))
+        return (np.ctypeslib.as_array(ps, shape=(n,)).reshape(-1, 8, 6).copy(),
+                np.ctypeslib.as_array(pt, shape=(n,)).reshape(-1, 8, 6).copy())
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.stan_hip_results_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Matrix:

@@ -18,6 +18,7 @@
 #pragma once
 
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -210,7 +211,15 @@ struct Database {  // Database.cs:10-37
     // what Initialize_StepZero / Initialize_NewDisp / Update_Displacement / Initialize_Increment /
     // Update_StrainStress leave in the objects (Solver.cs:81-90, 171-178, 203-210), without building 13 million
     // small heap objects first (3.3 s of a 8.9 s run at 148^3).  The pointers must outlive the write.
-    struct ResultView { const double *disp = nullptr, *strain = nullptr, *stress = nullptr; } results;
+    // Round 5: the element results may stay on the device until the writer needs them -- `fetch(e0, e1, &strain, &stress)`
+    // hands the rows of elements [e0, e1) to the CALLING writer thread ([(e1 - e0) * 48] each, valid until that
+    // thread's next call; the console driver forwards it to stan_hip_results_map), so the download overlaps the
+    // encoding; strain / stress stay null then.
+    struct ResultView {
+        const double *disp = nullptr, *strain = nullptr, *stress = nullptr;
+        std::function<bool(size_t, size_t, const double **, const double **)> fetch;
+        size_t elem_base = 0;   // (writer-internal) element index that strain[0] / stress[0] belong to
+    } results;
 
     // Database.cs:39-111 (mesh only: Part objects are GUI-side and not serialized)
     bool ReadNastranMesh(const std::string &path, std::string *err);

@@ -6,13 +6,39 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <thread>
 
 namespace stan {
 
 using clk = std::chrono::steady_clock;
 static double secs(clk::time_point a) { return std::chrono::duration<double>(clk::now() - a).count(); }
 
+struct SolverFunctions::Warm {
+    std::thread th;
+    stan_ctx *ctx = nullptr;
+    int rc = 0;
+    std::string err;
+};
+SolverFunctions::~SolverFunctions() {
+    if (!warm_) return;
+    if (warm_->th.joinable()) warm_->th.join();
+    if (warm_->ctx) stan_hip_destroy(warm_->ctx);   // never picked up (the run ended before the assembly)
+    delete warm_;
+}
+void SolverFunctions::Prewarm() {
+    if (warm_) return;
+    warm_ = new Warm();
+    Warm *w = warm_;
+    const SolverOptions opt = opt_;
+    w->th = std::thread([w, opt] {
+        w->rc = opt.devices.size() > 1 ? stan_hip_init_multi((int)opt.devices.size(), opt.devices.data(), &w->ctx)
+                                       : stan_hip_init(opt.devices.empty() ? opt.device : opt.devices[0], &w->ctx);
+        if (w->rc) w->err = stan_hip_last_error(nullptr);   // (thread-local text: taken on this thread)
+    });
+}
+
 SparseMatrixHandle::~SparseMatrixHandle() {
+    if (results) stan_hip_results_free(results);
     if (K) stan_hip_matrix_free(K);
     if (ctx) stan_hip_destroy(ctx);
 }
@@ -38,10 +64,17 @@ void SolverFunctions::ParallelAssembly_K(const Database &DB, const std::vector<i
     std::string err;
     if (Flatten(DB, &K->flat, &err)) throw std::runtime_error(err);
     // several GPUs: still ONE process and the same calls -- the handle fans them out (stan_hip.h)
-    const int rc_init = opt_.devices.size() > 1
-                            ? stan_hip_init_multi((int)opt_.devices.size(), opt_.devices.data(), &K->ctx)
-                            : stan_hip_init(opt_.devices.empty() ? opt_.device : opt_.devices[0], &K->ctx);
-    if (rc_init) throw std::runtime_error(stan_hip_last_error(nullptr));
+    if (warm_) {   // the context was started while the file was read (Prewarm)
+        if (warm_->th.joinable()) warm_->th.join();
+        if (warm_->rc) throw std::runtime_error(warm_->err);
+        K->ctx = warm_->ctx;
+        warm_->ctx = nullptr;
+    } else {
+        const int rc_init = opt_.devices.size() > 1
+                                ? stan_hip_init_multi((int)opt_.devices.size(), opt_.devices.data(), &K->ctx)
+                                : stan_hip_init(opt_.devices.empty() ? opt_.device : opt_.devices[0], &K->ctx);
+        if (rc_init) throw std::runtime_error(stan_hip_last_error(nullptr));
+    }
     stan_hip_set_option(K->ctx, STAN_OPT_CG_MERIT_STOP, opt_.merit_stop ? 1 : 0);
     stan_hip_set_option(K->ctx, STAN_OPT_PLACEMENT_TRIES, opt_.placement_tries < 1 ? 1 : opt_.placement_tries);
     if (opt_.p2p && stan_hip_set_option(K->ctx, STAN_OPT_COMM_P2P, 1)) throw std::runtime_error(stan_hip_last_error(K->ctx));
@@ -144,6 +177,15 @@ void SolverFunctions::Recovery_Stress(SparseMatrixHandle &K, const std::vector<d
     if (stan_hip_recover_hex8(K.ctx, n_nodes, f.xyz.data(), dU.data(), n_elem, f.conn.data(), f.elem_mat.data(),
                               f.elem_type.data(), (int32_t)(f.mat_E_nu.size() / 2), f.mat_E_nu.data(),
                               strain->data(), stress->data()))
+        throw std::runtime_error(stan_hip_last_error(K.ctx));  // HEX8_G1: the reference throws too (Element.cs:242)
+}
+
+void SolverFunctions::Recovery_Stress_Keep(SparseMatrixHandle &K, const std::vector<double> &dU) const {
+    const FlatModel &f = K.flat;
+    const int64_t n_nodes = (int64_t)(f.xyz.size() / 3), n_elem = (int64_t)f.elem_mat.size();
+    if (K.results) { stan_hip_results_free(K.results); K.results = nullptr; }
+    if (stan_hip_recover_hex8_keep(K.ctx, n_nodes, f.xyz.data(), dU.data(), n_elem, f.conn.data(), f.elem_mat.data(),
+                                   f.elem_type.data(), (int32_t)(f.mat_E_nu.size() / 2), f.mat_E_nu.data(), &K.results))
         throw std::runtime_error(stan_hip_last_error(K.ctx));  // HEX8_G1: the reference throws too (Element.cs:242)
 }
 

@@ -26,6 +26,7 @@ class SparseMatrixHandle {
   public:
     SparseMatrixHandle() {}
     ~SparseMatrixHandle();
+    stan_results *results = nullptr;   // strain / stress kept on the device(s) until the export has encoded them
     SparseMatrixHandle(const SparseMatrixHandle &) = delete;
     SparseMatrixHandle &operator=(const SparseMatrixHandle &) = delete;
     stan_ctx *ctx = nullptr;
@@ -46,6 +47,11 @@ struct SolverOptions {  // extras of the native driver, never stored in the STdb
 class SolverFunctions {
   public:
     explicit SolverFunctions(const SolverOptions &opt = SolverOptions()) : opt_(opt) {}
+    ~SolverFunctions();
+
+    // Round 5: the device context (HIP runtime start-up, streams, the communicator of a multi-device handle) comes up
+    // on a thread of its own while the input file is read; ParallelAssembly_K waits for it.  Not calling it is fine.
+    void Prewarm();
 
     void Welcome_Messsage() const;
     bool ProtoDeserialize(const std::string &path, Database *db, std::string *err) const { return ReadStdb(path, db, err); }
@@ -65,6 +71,9 @@ class SolverFunctions {
     // Element.Recovery_Stress + Update_StrainStress for every element (Solver.cs:183-210)
     void Recovery_Stress(SparseMatrixHandle &K, const std::vector<double> &nodal_dU,
                          std::vector<double> *strain, std::vector<double> *stress) const;
+    // the same with the results left on the device(s) (K.results): the export maps them chunk by chunk
+    // (stan_hip_results_map through Database::ResultView::fetch) instead of holding 1.5 KB per element on the host
+    void Recovery_Stress_Keep(SparseMatrixHandle &K, const std::vector<double> &nodal_dU) const;
 
     std::vector<double> Include_BC_DOF(const std::vector<double> &A, const std::vector<int32_t> &nDOF_reduction) const;
     std::vector<double> Exclude_BC_DOF(const std::vector<double> &A, const std::vector<int32_t> &nDOF_reduction) const;
@@ -76,6 +85,8 @@ class SolverFunctions {
 
   private:
     SolverOptions opt_;
+    struct Warm;            // the context being created ahead of its use
+    Warm *warm_ = nullptr;
 };
 
 }  // namespace stan

@@ -31,8 +31,10 @@ def _c_kind(decl):
     toks = d.split()
     base = toks[0] if toks[0] != "struct" else toks[1]
     nptr = stars + (1 if arr else 0)
-    if base in ("stan_ctx", "stan_matrix", "void"):
+    if base in ("stan_ctx", "stan_matrix", "stan_results", "void"):
         return ("out_handle" if nptr == 2 else "handle", base)
+    if nptr == 2:      # `const double **p`: a raw pointer handed back (stan_hip_results_map) = out IntPtr
+        return ("out_handle", base)
     if base in ("stan_matrix_info", "stan_profile"):
         assert nptr == 1
         return ("struct", base)
