@@ -319,17 +319,19 @@ def run_one_process(args):
         raise SystemExit(4)
 
 
-def main():
-    ensure_built()
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", dest="n", type=int, default=148, help="cube edge in elements (148 -> ~10 M DOF)")
     ap.add_argument("--eps", type=float, default=1e-8)
-    ap.add_argument("--mixed", action="store_true", help="fp32 matrix / fp64 vectors")
+    ap.add_argument("--mixed", action="store_true", help="fp32 matrix / fp64 vectors (refined to eps in fp64 terms: STAN_OPT_CG_REFINE)")
     ap.add_argument("--fixed48", action="store_true",
                     help="fp64 arithmetic on the 48-bit fixed-point stream of the scaled matrix")
+    ap.add_argument("--refine", type=int, default=-1,
+                    help="STAN_OPT_CG_REFINE for --mixed / --fixed48: 0 fp64 check only, 1 refinement passes (library default), "
+                         "2 + fp64 refresh products")
     ap.add_argument("--etype", type=int, default=2, help="2 = HEX8_G2, 1 = HEX8_G1")
     ap.add_argument("--max-its", type=int, default=0,
                     help="LinSolverIterMax; a capped run reports per-iteration timings only (value null)")
@@ -357,7 +359,7 @@ def main():
                     help="STAN_OPT_COMM_P2P (N > 1): the CG's reductions and halo exchanges go peer to peer between the "
                          "rank processes (HIP IPC mappings; no RCCL launch in the loop) instead of over RCCL")
     ap.add_argument("--spmv-variant", type=int, default=-1,
-                    help="STAN_OPT_SPMV_VARIANT (lab): -1 = the library's choice; 0 / 9 / 12 in the product library, more in the lab build")
+                    help="STAN_OPT_SPMV_VARIANT: -1 = the library's choice; 0 / 9 / 12")
     ap.add_argument("--fold", type=int, default=-1,
                     help="STAN_OPT_ROW_FOLDING: -1 = auto (library default), 0 = never, 1 = long rows always lend their tails to the "
                          "idle slots of their slice (fold.hip)")
@@ -372,157 +374,398 @@ def main():
                          "communicator rank per device inside the library) -- the form a single-process host like the "
                          "reference's Solver.Main would use; host-pointer entries, so the copies are inside the step")
     ap.add_argument("--no-p2p-probe", action="store_true",
-                    help="N > 1: skip the short capped comparison of the two transports (RCCL / peer to peer) that is "
-                         "attached to the line as config.p2p_probe after the timed steps")
+                    help="N > 1: skip the capped comparison of the loop forms and transports ({classic, single-reduction} x "
+                         "{RCCL, peer to peer}) that is attached to the line as config.p2p_probe after the timed steps")
     ap.add_argument("--probe-its", type=int, default=200, help="iterations of each capped probe solve")
     ap.add_argument("--probe-watchdog", type=float, default=90.0,
                     help="seconds without progress after which the probe is given up (the measured line is printed "
                          "unchanged, exit code 0)")
-    args = ap.parse_args()
-    if args.one_process:
-        return run_one_process(args)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
-        raise SystemExit(launch_ranks(args, sys.argv[1:]))
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    ap.add_argument("--probe-child", action="store_true", help=argparse.SUPPRESS)   # internal: a rank of the probe's own process group
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="N = 1, default workload: skip the secondary legs (100^3, 200^3, FIXED-48, the console driver, "
+                         "k_recover) that are attached to the line as `secondary` after the timed steps")
+    ap.add_argument("--secondary-budget", type=float, default=240.0, help="seconds all secondary legs may take together")
+    return ap
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    from stan_amd import hip, problem
-    # armed after the imports: the first `import torch` on a fresh box pages the image in for a minute or two
-    dog = Watchdog(args.watchdog, rank, world, args)
 
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    # STAN_BENCH_BACKEND / STAN_BENCH_DEVICE: test hooks (tests/test_gpu_sharded.py runs this
-    # file with several ranks on ONE GPU over gloo + tests/fake_rccl); the driver uses neither
-    backend = os.environ.get("STAN_BENCH_BACKEND", "nccl")
-    dev_index = int(os.environ.get("STAN_BENCH_DEVICE", local_rank))
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    ctl = dev if backend == "nccl" else torch.device("cpu")   # where control-plane tensors live
-    dog.touch("process group")
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+def dtype_text(args):
+    return ("f32 matrix / f64 vectors (refined until the FP64 residual meets eps)" if args.mixed else
+            "f64 (matrix streamed as 48-bit fixed point)" if args.fixed48 else "f64")
 
-    # ---- synthetic job (host: mesh, Database.AssignDOF, BC tables; outside the timed region)
-    dog.touch("host set-up (mesh, AssignDOF, BC tables)")
-    job = (problem.perforated_job(args.n, args.knockout, etype=args.etype) if args.knockout > 0
-           else problem.cube_job(args.n, etype=args.etype))
-    dog.touch("context + communicator")
-    ctx = hip.Context(dev_index)
-    if world > 1:
-        uid = torch.zeros(128, dtype=torch.uint8, device=ctl)
-        if rank == 0:
-            uid = torch.tensor(list(ctx.unique_id()), dtype=torch.uint8, device=ctl)
-        dist.broadcast(uid, 0)
-        ctx.comm_init(rank, world, bytes(uid.cpu().tolist()))
-    ctx.set_option(hip.OPT_CG_MERIT_STOP, 0)
-    ctx.set_option(hip.OPT_PLACEMENT_TRIES, max(1, min(64, args.placement_tries)))
-    # The library, living inside a foreign host process, lets its placement search hold a quarter of the free device
-    # memory at most (11 candidates at 148^3); this process owns its GPU: three quarters (the runs of one memory group
-    # can be 150 GB long, placement.hip).  The search runs in the first warm-up step, never in the timed region.
-    placement_budget = 0
-    if args.placement_fraction > 0 and not os.environ.get("STAN_BENCH_DEVICE"):   # (ranks sharing one GPU in the tests: default)
-        placement_budget = int(args.placement_fraction * torch.cuda.mem_get_info(dev)[0])
-        ctx.set_option(hip.OPT_PLACEMENT_MAX_BYTES, placement_budget)
-    if args.pool_fraction > 0 and not os.environ.get("STAN_BENCH_DEVICE"):
-        ctx.set_option(hip.OPT_POOL_MAX_BYTES, int(args.pool_fraction * torch.cuda.mem_get_info(dev)[0]))
-    if args.single_reduce:
-        ctx.set_option(hip.OPT_CG_SINGLE_REDUCE, 1)
-    if args.sell_sigma > 0:
-        ctx.set_option(hip.OPT_SELL_SIGMA, args.sell_sigma)
-    if args.fold != -1:
-        ctx.set_option(hip.OPT_ROW_FOLDING, args.fold)
-    if args.spmv_variant >= 0:
-        ctx.set_option(hip.OPT_SPMV_VARIANT, args.spmv_variant)
-    if args.p2p and world > 1:
-        ctx.set_option(hip.OPT_COMM_P2P, 1)
-    ctx.set_profiling(True)
-    comm = ctx.comm_info()   # which transport the sharded loop runs over (a SCALE line should say)
 
-    # inputs resident in HBM before the timed region; a rank of a sharded run holds only the elements
-    # that touch its rows (the node arrays stay whole: any node may be a halo column)
-    conn, emat, etyp = job.conn, job.elem_mat, job.elem_type
-    if world > 1:
-        from stan_amd import host
-        mine = host.partition_elements(job.node_index, job.conn, world, rank)
-        conn, emat, etyp = job.conn[mine], job.elem_mat[mine], job.elem_type[mine]
-    d_xyz = torch.from_numpy(job.xyz).to(dev)
-    d_dof = torch.from_numpy(job.node_dof).to(dev)
-    d_conn = torch.from_numpy(np.ascontiguousarray(conn)).to(dev)
-    d_mat = torch.from_numpy(np.ascontiguousarray(emat)).to(dev)
-    d_typ = torch.from_numpy(np.ascontiguousarray(etyp)).to(dev)
-    d_red = torch.from_numpy(job.red).to(dev)
-    d_F = torch.from_numpy(job.F).to(dev)
-    d_U = torch.zeros(job.n_red, dtype=torch.float64, device=dev)
-    torch.cuda.synchronize()
-    prec = hip.PREC_MIXED if args.mixed else hip.PREC_FIXED48 if args.fixed48 else hip.PREC_FP64
+class RankRun:
+    """What one rank of a measured run holds: device, control plane, synthetic job, library context (with its
+    communicator when sharded), the inputs resident in HBM, and `step()` = one pass of the hot path."""
 
-    def step(max_its=None):
-        K = ctx.assemble_hex8_dev(job.xyz.shape[0], d_xyz.data_ptr(), d_dof.data_ptr(),
-                                  conn.shape[0], d_conn.data_ptr(), d_mat.data_ptr(),
-                                  d_typ.data_ptr(), job.mat_E_nu, job.n_dof, d_red.data_ptr())
-        rep = K.cg_solve_dev(d_F.data_ptr(), d_U.data_ptr(), args.eps, args.max_its if max_its is None else max_its, prec)
-        prof = ctx.profile()
+    def __init__(self, args, dog):
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        from stan_amd import hip, problem
+        self.args, self.dog, self.torch, self.dist, self.hip, self.np = args, dog, torch, dist, hip, np
+        self.rank = rank = int(os.environ.get("RANK", "0"))
+        self.world = world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+        # STAN_BENCH_BACKEND / STAN_BENCH_DEVICE: test hooks (tests/test_gpu_sharded.py runs this
+        # file with several ranks on ONE GPU over gloo + tests/fake_rccl); the driver uses neither
+        backend = os.environ.get("STAN_BENCH_BACKEND", "nccl")
+        self.dev_index = dev_index = int(os.environ.get("STAN_BENCH_DEVICE", local_rank))
+        torch.cuda.set_device(dev_index)
+        self.dev = dev = torch.device("cuda", dev_index)
+        self.ctl = ctl = dev if backend == "nccl" else torch.device("cpu")   # where control-plane tensors live
+        dog.touch("process group")
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
+        # ---- synthetic job (host: mesh, Database.AssignDOF, BC tables; outside the timed region)
+        dog.touch("host set-up (mesh, AssignDOF, BC tables)")
+        self.job = job = (problem.perforated_job(args.n, args.knockout, etype=args.etype) if args.knockout > 0
+                          else problem.cube_job(args.n, etype=args.etype))
+        dog.touch("context + communicator")
+        self.ctx = ctx = hip.Context(dev_index)
+        if world > 1:
+            uid = torch.zeros(128, dtype=torch.uint8, device=ctl)
+            if rank == 0:
+                uid = torch.tensor(list(ctx.unique_id()), dtype=torch.uint8, device=ctl)
+            dist.broadcast(uid, 0)
+            ctx.comm_init(rank, world, bytes(uid.cpu().tolist()))
+        ctx.set_option(hip.OPT_CG_MERIT_STOP, 0)
+        ctx.set_option(hip.OPT_PLACEMENT_TRIES, max(1, min(64, args.placement_tries)))
+        # The library, living inside a foreign host process, lets its placement search hold a quarter of the free device
+        # memory at most (11 candidates at 148^3); this process owns its GPU: three quarters (the runs of one memory group
+        # can be 150 GB long, placement.hip).  The search runs in the first warm-up step, never in the timed region.
+        self.placement_budget = 0
+        shared_gpu = bool(os.environ.get("STAN_BENCH_DEVICE"))   # (ranks sharing one GPU in the tests: library defaults)
+        if args.placement_fraction > 0 and not shared_gpu:
+            self.placement_budget = int(args.placement_fraction * torch.cuda.mem_get_info(dev)[0])
+            ctx.set_option(hip.OPT_PLACEMENT_MAX_BYTES, self.placement_budget)
+        if args.pool_fraction > 0 and not shared_gpu:
+            ctx.set_option(hip.OPT_POOL_MAX_BYTES, int(args.pool_fraction * torch.cuda.mem_get_info(dev)[0]))
+        if args.single_reduce:
+            ctx.set_option(hip.OPT_CG_SINGLE_REDUCE, 1)
+        if args.sell_sigma > 0:
+            ctx.set_option(hip.OPT_SELL_SIGMA, args.sell_sigma)
+        if args.fold != -1:
+            ctx.set_option(hip.OPT_ROW_FOLDING, args.fold)
+        if args.spmv_variant >= 0:
+            ctx.set_option(hip.OPT_SPMV_VARIANT, args.spmv_variant)
+        if args.refine >= 0:
+            ctx.set_option(hip.OPT_CG_REFINE, args.refine)
+        if args.p2p and world > 1:
+            ctx.set_option(hip.OPT_COMM_P2P, 1)
+        ctx.set_profiling(True)
+        self.comm = ctx.comm_info()   # which transport the sharded loop runs over (a SCALE line should say)
+        # inputs resident in HBM before the timed region; a rank of a sharded run holds only the elements
+        # that touch its rows (the node arrays stay whole: any node may be a halo column)
+        conn, emat, etyp = job.conn, job.elem_mat, job.elem_type
+        if world > 1:
+            from stan_amd import host
+            mine = host.partition_elements(job.node_index, job.conn, world, rank)
+            conn, emat, etyp = job.conn[mine], job.elem_mat[mine], job.elem_type[mine]
+        self.conn = conn
+        self.d_xyz = torch.from_numpy(job.xyz).to(dev)
+        self.d_dof = torch.from_numpy(job.node_dof).to(dev)
+        self.d_conn = torch.from_numpy(np.ascontiguousarray(conn)).to(dev)
+        self.d_mat = torch.from_numpy(np.ascontiguousarray(emat)).to(dev)
+        self.d_typ = torch.from_numpy(np.ascontiguousarray(etyp)).to(dev)
+        self.d_red = torch.from_numpy(job.red).to(dev)
+        self.d_F = torch.from_numpy(job.F).to(dev)
+        self.d_U = torch.zeros(job.n_red, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        self.prec = hip.PREC_MIXED if args.mixed else hip.PREC_FIXED48 if args.fixed48 else hip.PREC_FP64
+
+    def step(self, max_its=None):
+        job, args = self.job, self.args
+        K = self.ctx.assemble_hex8_dev(job.xyz.shape[0], self.d_xyz.data_ptr(), self.d_dof.data_ptr(),
+                                       self.conn.shape[0], self.d_conn.data_ptr(), self.d_mat.data_ptr(),
+                                       self.d_typ.data_ptr(), job.mat_E_nu, job.n_dof, self.d_red.data_ptr())
+        rep = K.cg_solve_dev(self.d_F.data_ptr(), self.d_U.data_ptr(), args.eps,
+                             args.max_its if max_its is None else max_its, self.prec)
+        prof = self.ctx.profile()
         info = K.info()
         K.free()
         return rep, prof, info
 
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def sync(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
 
-    def transport_probe():
-        """The sharded loop over RCCL (2 all-reduce launches + 1 grouped send/recv per iteration) and peer to
-        peer (STAN_OPT_COMM_P2P: mailboxes + arrival counters through HIP IPC, no collective launch in the loop)
-        on the same capped solve (--probe-its iterations, one warm-up solve each): ms per iteration (slowest rank),
-        stream time per reduction point and halo exchange, launches / collectives / stream waits per iteration."""
-        legs = {}
-        for name, flag in (("rccl", 0), ("p2p", 1)):
-            if os.environ.get("STAN_BENCH_TEST_HANG_PROBE", "") == str(rank) and flag:   # test hook
-                time.sleep(3600)
-            dog.touch("transport probe: %s set-up" % name)
-            ctx.set_option(hip.OPT_COMM_P2P, flag)      # (a collective call: every rank makes it)
-            for i in range(2):
-                dog.touch("transport probe: %s capped solve %d" % (name, i + 1))
-                rep_, prof_, _ = step(max_its=args.probe_its)
-            sync()
-            its = max(1, rep_["iterations"])
-            mine = torch.tensor([prof_["cg_ms"] / its,
-                                 prof_["comm_reduce_ms_total"] / max(prof_["comm_reduce_calls"], 1) * 1e3,
-                                 prof_["comm_halo_ms_total"] / max(prof_["comm_halo_calls"], 1) * 1e3,
-                                 prof_["loop_kernel_launches"] / max(prof_["loop_iterations_enqueued"], 1),
-                                 prof_["loop_collectives"] / max(prof_["loop_iterations_enqueued"], 1),
-                                 prof_["loop_stream_waits"] / max(prof_["loop_iterations_enqueued"], 1),
-                                 float(rep_["iterations"]), rep_["rel_residual"]], dtype=torch.float64, device=ctl)
-            allr = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(allr, mine)
-            rows = [[float(v) for v in a.cpu().tolist()] for a in allr]
-            legs[name] = {"ms_per_iteration": max(r_[0] for r_ in rows),
-                          "ms_per_iteration_per_rank": [r_[0] for r_ in rows],
-                          "reduction_us_per_call": [r_[1] for r_ in rows],
-                          "halo_us_per_call": [r_[2] for r_ in rows],
-                          "kernel_launches_per_iteration": rows[0][3],
-                          "collectives_per_iteration": rows[0][4],
-                          "stream_waits_per_iteration": rows[0][5],
-                          "iterations": int(rows[0][6]), "rel_residual": rows[0][7]}
-        dog.touch("transport probe: back to RCCL")
-        ctx.set_option(hip.OPT_COMM_P2P, 0)
-        a, b = legs["rccl"]["ms_per_iteration"], legs["p2p"]["ms_per_iteration"]
-        same = legs["rccl"]["rel_residual"] == legs["p2p"]["rel_residual"]   # rank-ordered sums on both: same bits
-        return {"capped_at_iterations": args.probe_its, "rccl": legs["rccl"], "p2p": legs["p2p"],
-                "same_residual_bits": bool(same),
-                # what a host should select on THIS node: peer to peer when it is measurably faster and agrees
-                "recommended": ("p2p (STAN_OPT_COMM_P2P=1)" if same and b < 0.97 * a else "rccl (library default)"),
-                "p2p_over_rccl_time": b / a if a > 0 else None}
+    def gather(self, values):
+        """one row of floats per rank -> list of rows (every rank gets all)"""
+        t = self.torch.tensor(values, dtype=self.torch.float64, device=self.ctl)
+        allr = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(allr, t)
+        return [[float(v) for v in a.cpu().tolist()] for a in allr]
+
+    def close(self):
+        self.ctx.close()
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+# ---- N > 1: the loop forms and transports side by side, in a process group of their own -------------------------------------
+PROBE_LEGS = (("classic_rccl", 0, 0), ("classic_p2p", 0, 1), ("single_reduce_rccl", 1, 0), ("single_reduce_p2p", 1, 1))
+
+
+def probe_child_main(args):
+    """One rank of the probe's own process group (started by run_probe_children as a fresh child of a measured rank):
+    the sharded loop as {classic, single-reduction} x {RCCL: 2 / 1 all-reduce launches + 1 grouped send/recv per iteration,
+    peer to peer: STAN_OPT_COMM_P2P, mailboxes + arrival counters through HIP IPC, no collective launch in the loop}
+    on the same capped solve (--probe-its iterations, one warm-up solve each): ms per iteration (slowest rank), stream
+    time per reduction point and halo exchange, launches / collectives / stream waits per iteration.  Rank 0 prints one
+    line {"probe_result": ...}.  A crash or a stall here costs the parent nothing but the probe."""
+    dog = Watchdog(args.probe_watchdog, int(os.environ.get("RANK", "0")), args.gpus, args)
+    dog.optional = True          # a stall ends this child quietly (code 0, no line): the parent sees no result
+    args.p2p = False
+    R = RankRun(args, dog)
+    hip = R.hip
+    legs = {}
+    for name, sr, p2p in PROBE_LEGS:
+        if os.environ.get("STAN_BENCH_TEST_HANG_PROBE", "") == str(R.rank) and p2p:   # test hooks
+            time.sleep(3600)
+        if os.environ.get("STAN_BENCH_TEST_CRASH_PROBE", "") == str(R.rank) and p2p:
+            os.abort()
+        dog.touch("transport probe: %s set-up" % name)
+        R.ctx.set_option(hip.OPT_CG_SINGLE_REDUCE, sr)
+        R.ctx.set_option(hip.OPT_COMM_P2P, p2p)      # (a collective call: every rank makes it)
+        for i in range(2):
+            dog.touch("transport probe: %s capped solve %d" % (name, i + 1))
+            rep_, prof_, _ = R.step(max_its=args.probe_its)
+        R.sync()
+        its = max(1, rep_["iterations"])
+        enq = max(prof_["loop_iterations_enqueued"], 1)
+        rows = R.gather([prof_["cg_ms"] / its,
+                         prof_["comm_reduce_ms_total"] / max(prof_["comm_reduce_calls"], 1) * 1e3,
+                         prof_["comm_halo_ms_total"] / max(prof_["comm_halo_calls"], 1) * 1e3,
+                         prof_["loop_kernel_launches"] / enq, prof_["loop_collectives"] / enq, prof_["loop_stream_waits"] / enq,
+                         float(rep_["iterations"]), rep_["rel_residual"]])
+        legs[name] = {"ms_per_iteration": max(r_[0] for r_ in rows),
+                      "ms_per_iteration_per_rank": [r_[0] for r_ in rows],
+                      "reduction_us_per_call": [r_[1] for r_ in rows],
+                      "halo_us_per_call": [r_[2] for r_ in rows],
+                      "kernel_launches_per_iteration": rows[0][3],
+                      "collectives_per_iteration": rows[0][4],
+                      "stream_waits_per_iteration": rows[0][5],
+                      "iterations": int(rows[0][6]), "rel_residual": rows[0][7],
+                      "every_rank_same_residual_bits": len(set(r_[7] for r_ in rows)) == 1}
+    dog.touch("transport probe: report")
+    if R.rank == 0:
+        base = legs["classic_rccl"]
+
+        def agrees(leg, tol):   # a capped solve: same iteration count, residual within tol (NOT bit equality: RCCL's
+            return (leg["iterations"] == base["iterations"] and           # ring / tree order is not rank order for N >= 3)
+                    abs(leg["rel_residual"] - base["rel_residual"]) <= tol * abs(base["rel_residual"]))
+        best = min(legs, key=lambda k: legs[k]["ms_per_iteration"])
+        ok = {k: agrees(v, 1e-9 if k.startswith("classic") else 1e-3) for k, v in legs.items()}
+        opts = {"classic_rccl": "library defaults", "classic_p2p": "STAN_OPT_COMM_P2P=1",
+                "single_reduce_rccl": "STAN_OPT_CG_SINGLE_REDUCE=1", "single_reduce_p2p": "STAN_OPT_CG_SINGLE_REDUCE=1 + STAN_OPT_COMM_P2P=1"}
+        rec = best if ok[best] and legs[best]["ms_per_iteration"] < 0.97 * base["ms_per_iteration"] else "classic_rccl"
+        print(json.dumps({"probe_result": {
+            "capped_at_iterations": args.probe_its, "legs": legs,
+            # information, not a gate: the two classic legs add their partial sums in rank order only when peer to peer
+            "same_residual_bits_classic": legs["classic_rccl"]["rel_residual"] == legs["classic_p2p"]["rel_residual"],
+            "agrees_with_classic_rccl": ok,
+            "time_over_classic_rccl": {k: v["ms_per_iteration"] / base["ms_per_iteration"] for k, v in legs.items()},
+            "fastest": best,
+            # what a host should select on THIS node: a form that is measurably (3 %) faster and agrees
+            "recommended": "%s (%s)" % (rec, opts[rec])}}), flush=True)
+    dog.stop()
+    R.ctx.set_option(hip.OPT_COMM_P2P, 0)
+    R.close()
+
+
+def run_probe_children(args, R, dog):
+    """The measured ranks start the probe as FRESH child processes (one per rank, a process group of their own on a port
+    of its own) and wait for them: whatever happens in there -- a stall, a GPU fault, a segfault in an IPC mapping,
+    an RCCL abort -- happens to the children (in-process, a hard failure took the measured line with it).
+    Returns rank 0's {"probe_result": ...} dict or None."""
+    import signal
+    import socket
+    import subprocess
+    torch, dist = R.torch, R.dist
+    port = torch.zeros(1, dtype=torch.int64, device=R.ctl)
+    if R.rank == 0:
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port[0] = sk.getsockname()[1]
+        sk.close()
+    dist.broadcast(port, 0)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC")}   # (the child ranks host their own store)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(int(port.item())))
+    keep = ["--gpus", str(args.gpus), "--size", str(args.n), "--eps", str(args.eps), "--etype", str(args.etype),
+            "--knockout", str(args.knockout), "--probe-its", str(args.probe_its), "--probe-watchdog", str(args.probe_watchdog),
+            "--placement-tries", "1", "--steps", "1", "--warmup", "0", "--no-cpu"]
+    if args.mixed:
+        keep.append("--mixed")
+    if args.fixed48:
+        keep.append("--fixed48")
+    cmd = [sys.executable, os.path.abspath(__file__), "--probe-child"] + keep
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE if R.rank == 0 else subprocess.DEVNULL, text=True, env=env,
+                            cwd=ROOT, start_new_session=True)
+    bound = args.probe_watchdog * (len(PROBE_LEGS) + 1) + 240.0     # backstop; the children carry their own watchdog
+    t0 = time.time()
+    out = ""
+    try:
+        while True:
+            try:
+                out, _ = proc.communicate(timeout=1.0)
+                break
+            except subprocess.TimeoutExpired:
+                dog.touch("transport probe (child processes)")
+                if time.time() - t0 > bound:
+                    raise
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)     # the child started above, nothing else
+        except OSError:
+            pass
+        proc.wait()
+        sys.stderr.write("bench.py: rank %d: probe child did not end within %.0f s and was killed\n" % (R.rank, bound))
+        return None
+    if proc.returncode != 0:
+        sys.stderr.write("bench.py: rank %d: probe child ended with code %d; the measured line stands\n" % (R.rank, proc.returncode))
+    if R.rank != 0:
+        return None
+    for ln in (out or "").splitlines():
+        if ln.startswith("{") and '"probe_result"' in ln:
+            try:
+                return json.loads(ln)["probe_result"]
+            except ValueError:
+                return None
+    return None
+
+
+# ---- N = 1: the other single-GPU configurations behind the headline, each in a process of its own ----------------------------
+def _child_json(cmd, timeout, env=None, marker='"metric"'):
+    import signal
+    import subprocess
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env,
+                            start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        proc.wait()
+        return None, "timed out after %.0f s" % timeout
+    for ln in out.splitlines():
+        if ln.startswith("{") and marker in ln:
+            try:
+                return json.loads(ln), None
+            except ValueError:
+                pass
+    return None, "rc %d, no line; stderr tail: %s" % (proc.returncode, (err or "")[-300:].replace("\n", " | "))
+
+
+def _bench_leg(extra, timeout):
+    d, why = _child_json([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu",
+                          "--no-secondary"] + extra, timeout)
+    if d is None:
+        return {"error": why}
+    c, r = d["config"], d["roofline"]
+    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "workload": c["workload"],
+            "cg_iterations": c["cg_iterations"], "termination_type": c["termination_type"], "rel_residual": c["rel_residual"],
+            "assemble_ms": c["assemble_ms"], "cg_ms": c["cg_ms"],
+            "roofline": {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_reduced_system_bytes",
+                                           "bytes_per_launch", "avg_launch_ms", "launches")},
+            "speedup_vs_cpu_at_workload": d.get("speedup_vs_cpu_at_workload")}
+
+
+def _console_leg(n, timeout):
+    """stan_solver --json on a generated n^3 STdb (GUI defaults: CG, tol 1e-6, alglib's merit stop on): the reference's
+    console entry point end to end -- read, AssignDOF, BC tables, assembly + CG on the GPU, stress recovery, export of
+    the results into the file (Solver.cs:18-217, 454-462) -- with its phase times."""
+    import tempfile
+    import numpy as np
+    from stan_amd import host
+    from stan_amd.cube import cube_bcs, cube_mesh
+    xyz, conn = cube_mesh(n)
+    d = host.Db()
+    ne = conn.shape[0]
+    d.set_mesh(np.arange(1, xyz.shape[0] + 1), xyz, np.arange(1, ne + 1), np.ones(ne), conn + 1, "HEX8_G2")
+    d.add_material(1, "Steel", 210000.0, 0.3)
+    d.assign_part(1, 1, "HEX8_G2")
+    spc, ld, f = cube_bcs(n)
+    d.add_bc(1, "fix", "SPC", spc + 1, np.ones((len(spc), 3)))
+    d.add_bc(2, "load", "PointLoad", ld + 1, np.tile(f, (len(ld), 1)))
+    d.set_analysis(tol=1e-6)
+    tmp = tempfile.mkdtemp(prefix="stan_bench_")
+    path = os.path.join(tmp, "cube%d.STdb" % n)
+    try:
+        d.write_stdb(path)
+        size_in = os.path.getsize(path)
+        del d
+        exe = os.path.join(ROOT, "stan_amd", "bin", "stan_solver")
+        t0 = time.perf_counter()
+        line, why = _child_json([exe, "--json", path], timeout, marker='"t_wall_s"')
+        wall = time.perf_counter() - t0
+        if line is None:
+            return {"error": why}
+        line.update(workload="stan_solver --json on a generated %d^3 HEX8_G2 STdb (CG, tol 1e-6, merit stop on)" % n,
+                    process_wall_s=wall, input_MB=size_in / 1e6, output_MB=os.path.getsize(path) / 1e6)
+        return line
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def secondary_legs(args, dog):
+    """BASELINE.json's other single-GPU configurations, measured by the driver's own run: each leg is a
+    fresh child process with a bound of its own; a leg that fails leaves {"error": ...} and the headline untouched."""
+    t_end = time.time() + args.secondary_budget
+    legs = []
+
+    def left():
+        return max(5.0, t_end - time.time())
+    plan = [("config 2: 100^3 fp64", lambda: _bench_leg(["--size", "100"], min(90.0, left()))),
+            ("config 3: 200^3 fp64 (HBM-roofline SpMV run)", lambda: _bench_leg(["--size", "200"], min(150.0, left()))),
+            ("148^3, FIXED-48 value stream", lambda: _bench_leg(["--size", "148", "--fixed48"], min(90.0, left()))),
+            ("console driver end to end, 148^3", lambda: _console_leg(148, min(120.0, left()))),
+            ("k_recover (stress recovery) at 148^3",
+             lambda: (lambda d, why: d if d is not None else {"error": why})(
+                 *_child_json([sys.executable, os.path.join(ROOT, "tools", "recover_time.py"), "148", "10"], min(60.0, left()),
+                              marker='"kernel"')))]
+    for name, fn in plan:
+        dog.touch("secondary leg: " + name)
+        if time.time() > t_end:
+            legs.append({"leg": name, "error": "skipped: the secondary budget (%.0f s) was spent" % args.secondary_budget})
+            continue
+        t0 = time.time()
+        try:
+            res = fn()
+        except Exception as e:   # noqa: BLE001  (an optional extra must not cost the line)
+            res = {"error": "%s: %s" % (type(e).__name__, e)}
+        res = dict(leg=name, seconds=time.time() - t0, **res)
+        legs.append(res)
+    return legs
+
+
+def main():
+    ensure_built()
+    args = build_parser().parse_args()
+    if args.one_process:
+        return run_one_process(args)
+    if args.probe_child:
+        return probe_child_main(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
+
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
+    # armed after the imports: the first `import torch` on a fresh box pages the image in for a minute or two
+    dog = Watchdog(args.watchdog, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), args)
+    R = RankRun(args, dog)
+    rank, world, job, ctx, dev, ctl, comm, conn = R.rank, R.world, R.job, R.ctx, R.dev, R.ctl, R.comm, R.conn
+    step, sync, placement_budget = R.step, R.sync, R.placement_budget
 
     # STAN_BENCH_TEST_HANG_RANK: test hook (tests/test_gpu_sharded.py): that rank never starts its steps
     if os.environ.get("STAN_BENCH_TEST_HANG_RANK", "") == str(rank):
@@ -559,13 +802,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # what every rank measured on its own shard: SpMV rate against ITS bytes, exchange times per call
-        mine = torch.tensor([prof["spmv_bytes"] / (spmv_ms / max(spmv_n, 1) * 1e-3) / 1e9 if spmv_ms > 0 else 0.0,
+        per_rank = R.gather([prof["spmv_bytes"] / (spmv_ms / max(spmv_n, 1) * 1e-3) / 1e9 if spmv_ms > 0 else 0.0,
                              spmv_ms / max(spmv_n, 1), red_ms / max(red_n, 1) * 1e3, halo_ms / max(halo_n, 1) * 1e3,
-                             float(info["n_halo"]), float(info["row_end"] - info["row_begin"])],
-                            dtype=torch.float64, device=ctl)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        per_rank = [[float(v) for v in a.cpu().tolist()] for a in allr]
+                             float(info["n_halo"]), float(info["row_end"] - info["row_begin"])])
+        # which physical device every rank drove and what its communicator says (a SCALE line must show that the
+        # N ranks sat on N different GPUs of one communicator): HIP ordinal, PCI bus id, ncclCommCount / UserRank
+        ordinal, bus = ctx.device_info()
+        mine_txt = json.dumps({"rank": rank, "hip_device": ordinal, "pci_bus_id": bus, "comm_ranks": comm["comm_ranks"],
+                               "comm_rank": comm["comm_rank"], "pid": os.getpid()}).encode()
+        buf = torch.zeros(256, dtype=torch.uint8, device=ctl)
+        buf[:len(mine_txt)] = torch.tensor(list(mine_txt), dtype=torch.uint8)
+        allb = [torch.zeros_like(buf) for _ in range(world)]
+        dist.all_gather(allb, buf)
+        rank_devices = [json.loads(bytes(b.cpu().tolist()).rstrip(b"\0").decode()) for b in allb]
     dog.touch("report")
 
     # sanity of the timed work (rank 0): converged to eps, true residual through an
@@ -619,8 +868,7 @@ def main():
             "vs_baseline": None,
             # non-default library options this number depends on (DESIGN.md sections 3, 4)
             "merit_stop": False, "placement_tries": args.placement_tries, "placement_max_bytes": placement_budget,
-            "dtype": ("f32 matrix / f64 vectors" if args.mixed else
-                      "f64 (matrix streamed as 48-bit fixed point)" if args.fixed48 else "f64"),
+            "dtype": dtype_text(args),
             "data": "synthetic",
             "config": {"workload": "%d^3 HEX8_G%d cube%s, %d DOF, clamp %s, PointLoad (0,0,50) on "
                                    "x=n; fp64 Jacobi-scaled CG to %.0e" %
@@ -636,6 +884,10 @@ def main():
                        "blocks_3x3_rank0": info["n_blocks"], "cg_iterations": rep["iterations"],
                        "termination_type": rep["terminationtype"],
                        "rel_residual": rep["rel_residual"], "converged": bool(ok),
+                       # reduced-precision streams: rel_residual is the FP64 residual of the returned point (one product
+                       # on the fp64 values); the loop's own recurrence, the passes and the fp64 products it took
+                       "rel_residual_recurrence": prof["rel_residual_recurrence"], "refine_passes": prof["refine_passes"],
+                       "fp64_products_per_step": prof["fp64_products"],
                        "assemble_ms": asm_ms / args.steps, "cg_ms": cg_ms / args.steps,
                        "matrix_format": "BSELL-64 3x3 blocks (%s values + block cols as 16-bit offsets from per-slot "
                                         "bases -- one, or two where a slice mixes row lengths -- in %.1f %% of the slots, int32 in the rest)" %
@@ -697,6 +949,8 @@ def main():
                                          "allreduces_per_step": red_n / args.steps, "halo_exchanges_per_step": halo_n / args.steps,
                                          "halo_block_rows": [int(p[4]) for p in per_rank],
                                          "owned_block_rows": [int(p[5]) for p in per_rank]}
+            out["config"]["ranks"] = rank_devices
+            out["config"]["distinct_devices"] = len(set(d["pci_bus_id"] for d in rank_devices))
         if not args.no_cpu and world == 1:
             dog.stop()   # the CPU sample is bounded by its size, not by the watchdog
             base, base_all = cpu_baseline(args.cpu_n, args.eps)
@@ -715,17 +969,19 @@ def main():
             out["error"] = "CG ended with type %d at %.3e (> eps %.0e): no DOF/s reported" % (
                 rep["terminationtype"], rep["rel_residual"], args.eps)
         dog.touch("cpu baseline done")
-    # N > 1: the two transports of the sharded loop side by side on a capped solve, behind the measurement.
-    # Optional by construction: whatever happens in here, the line measured above is printed (rc 0).
+    # N > 1: the loop forms and transports side by side on a capped solve, behind the measurement, in child processes:
+    # whatever happens in there (a stall, a GPU fault, an abort inside RCCL or an IPC mapping), the line measured above is
+    # printed (rc 0).
     line = json.dumps(out) if rank == 0 else None
     if world > 1 and not args.no_p2p_probe and not args.p2p and ok:
-        dog.held_line, dog.optional, dog.bound, dog.enabled = line, True, float(args.probe_watchdog), True
+        dog.held_line, dog.optional, dog.enabled = line, True, True
+        dog.bound = float(args.probe_watchdog) * (len(PROBE_LEGS) + 1) + 300.0   # (the children carry the real bound)
         if args.watchdog <= 0:   # the probe is bounded even when the run was not
             import threading
             threading.Thread(target=dog._run, daemon=True).start()
         probe = None
         try:
-            probe = transport_probe()
+            probe = run_probe_children(args, R, dog)
         except Exception as e:   # noqa: BLE001  (an optional extra must not cost the line)
             sys.stderr.write("bench.py: rank %d: transport probe given up: %s\n" % (rank, e))
         if rank == 0 and probe is not None:
@@ -733,14 +989,25 @@ def main():
             out["config"]["recommended_transport"] = probe["recommended"]
             line = json.dumps(out)
         dog.held_line = line
+    # N = 1, the default workload: BASELINE.json's other single-GPU configurations behind the headline (child processes)
+    if (world == 1 and rank == 0 and ok and not args.no_secondary and args.n == 148 and args.etype == 2 and args.knockout == 0
+            and not args.mixed and not args.fixed48 and args.max_its == 0):
+        dog.held_line, dog.optional, dog.enabled = line, True, True
+        dog.bound = args.secondary_budget + 120.0
+        try:
+            # the context's pool gives its parked blocks back first: the legs are processes of their own on this GPU
+            ctx.set_option(R.hip.OPT_POOL_MAX_BYTES, 0)
+            out["secondary"] = secondary_legs(args, dog)
+            line = json.dumps(out)
+        except Exception as e:   # noqa: BLE001
+            sys.stderr.write("bench.py: secondary legs given up: %s\n" % e)
+        dog.held_line = line
     if rank == 0:
         print(line, flush=True)
     # the measurement is out: a teardown that stalls (a peer that is gone) ends quietly with code 0, never a second line
     dog.held_line, dog.optional = None, True
     dog.touch("teardown")
-    ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
+    R.close()
     dog.stop()
     if rank == 0 and not ok:
         raise SystemExit(4)

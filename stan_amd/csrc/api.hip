@@ -3,7 +3,6 @@
 
 #include "internal.h"
 
-int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K);
 
 namespace {
 thread_local std::string g_err;  // errors raised before a context exists
@@ -150,12 +149,8 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
     else if (option == STAN_OPT_PLACEMENT_TRIES && value >= 1 && value <= 64) ctx->placement_tries = (int)value;
     else if (option == STAN_OPT_PLACEMENT_MAX_BYTES && value >= 0) ctx->placement_max_bytes = value;
     else if (option == STAN_OPT_ROW_FOLDING && value >= -1 && value <= 1) ctx->row_folding = (int)value;
-#ifdef STAN_LAB
-    else if (option == STAN_OPT_SPMV_VARIANT && value >= -1 && value <= 18) ctx->spmv_variant = (int)value;
-#else   // the product library carries the three variants that give right answers (cg.hip)
     else if (option == STAN_OPT_SPMV_VARIANT && (value == -1 || value == 0 || value == 9 || value == 12))
         ctx->spmv_variant = (int)value;
-#endif
     else { ctx->err = "set_option: unknown option or bad value"; return STAN_E_ARG; }
     return STAN_OK;
 }
@@ -649,8 +644,12 @@ int stan_hip_matrix_to_csr(stan_ctx *ctx, stan_matrix *K, int32_t upper_only, in
     STAN_NO_GROUP(ctx, "matrix_to_csr");
     if (ctx->nranks != 1) { ctx->err = "matrix_to_csr: single-rank contexts only"; return STAN_E_UNSUPPORTED; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    STANCHK(stan_matrix_unscale(ctx, K));  // export K itself, not S K S
+    // export K itself, not S K S: the values are divided by s_row s_col on the way out.  The matrix is brought into its
+    // scaled form first if no solve has done so, so that every export of a matrix takes the same path and yields the
+    // same bits (within 1 ulp of the assembled entry: (a t) / t).
+    STANCHK(stan_matrix_ensure_scaled(ctx, K));
     const int64_t nloc = K->nloc;
+    std::vector<double> scale((size_t)3 * (size_t)K->nslices * 64);
     std::vector<int32_t> slot_ptr((size_t)K->nslices + 1), rowlen((size_t)K->nslices * 64),
         posof((size_t)K->nslices * 64), cols((size_t)K->nslots * 64), red((size_t)K->n_dof);
     std::vector<double> vals((size_t)K->nslots * 9 * 64);
@@ -661,6 +660,7 @@ int stan_hip_matrix_to_csr(stan_ctx *ctx, stan_matrix *K, int32_t upper_only, in
     if (!cols.empty()) HIPCHK(ctx, hipMemcpyAsync(cols.data(), K->d_cols, cols.size() * 4, hipMemcpyDeviceToHost, st));
     if (!vals.empty()) HIPCHK(ctx, hipMemcpyAsync(vals.data(), K->d_vals, vals.size() * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(red.data(), K->d_red, red.size() * 4, hipMemcpyDeviceToHost, st));
+    if (!scale.empty()) HIPCHK(ctx, hipMemcpyAsync(scale.data(), K->d_scale, scale.size() * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     int64_t count = 0;
     for (int pass = 0; pass < 2; pass++) {
@@ -682,7 +682,7 @@ int stan_hip_matrix_to_csr(stan_ctx *ctx, stan_matrix *K, int32_t upper_only, in
                         if (upper_only && dc < d) continue;
                         if (pass == 1) {
                             col[q] = (int32_t)(dc - red[dc]);
-                            val[q] = vals[(slot * 9 + 3 * m + n) * 64 + lane];
+                            val[q] = vals[(slot * 9 + 3 * m + n) * 64 + lane] / (scale[(size_t)d] * scale[(size_t)dc]);
                         }
                         q++;
                     }

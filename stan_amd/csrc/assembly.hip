@@ -478,12 +478,8 @@ struct numeric_args {
     const int32_t *wide_slices;   // k_numeric_wide: the slices wider than wmax
 };
 
-// tuning macros of k_numeric (tools/asm_lab.sh builds variants with -D; profiles/r04/k_numeric_ablations_2_and_tuning.txt)
-// STAN_ABL: timing-only ablations -- 1 no block arithmetic, 2 no accumulation, 3 no write-out, 4 no slot search, 5 no Jacobians,
-// 6 no incidence chunks at all
-#ifndef STAN_ABL
-#define STAN_ABL 0
-#endif
+// tuning constants of k_numeric (profiles/r04/k_numeric_ablations_2_and_tuning.txt; the timing-only ablations behind that
+// file are the lab build's: lab/lab_hooks.patch)
 #ifndef STAN_NUM_WAVES
 #define STAN_NUM_WAVES 3   // workgroups of k_numeric per CU the register budget must allow (168 VGPRs)
 #endif
@@ -594,7 +590,7 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
         const int64_t p0 = cur.p0;
         const int deg = cur.deg;
         const int rl = cur.rl;
-        for (int c0 = 0; c0 < (STAN_ABL == 6 ? 0 : deg); c0 += 8) {
+        for (int c0 = 0; c0 < deg; c0 += 8) {
             const bool valid = c0 + s < deg;
             int32_t e = 0, a = 0, type = STAN_HEX8_G2, colg = 0;
             double lam = 0, G = 0;
@@ -630,12 +626,7 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
                 // phase A: this lane = Gauss point b of incidence s: J^-1, c = det J w, and -- once for the eight lanes
                 // that will need it -- c * grad N_a of the row's own node a
                 double o[10], wa[3];
-#if STAN_ABL == 5
-                double det = 1.0;
-                for (int j = 0; j < 10; j++) o[j] = xsw[s * XS + j];
-#else
                 const double det = hex8_gp_setup(xsw + s * XS, type, b, o);
-#endif
                 if (det == 0.0 && hex8_gauss_weight(type, b) != 0.0)
                     atomicMin(A.bad_elem, (long long)e);
                 {
@@ -655,9 +646,6 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
             if (valid) {
                 // phase B: block (a, b) of element e in the M-form (hex8_device.h): per Gauss point J^-1 and c grad N_a
                 // from LDS, grad N_b = J^-1 dnb[g] from the lane's constants, nine fused multiply-adds into M
-#if STAN_ABL == 1
-                for (int j = 0; j < 9; j++) kb[j] = gpw[s * GS + j];
-#else
                 const double glt = hex8_gauss_loc(type);   // (HEX8_G1: 0 -- every point at the origin, c = 0 beyond the first)
                 const double fxp = 1.0 + sxb * glt, fxm = 1.0 - sxb * glt, fyp = 1.0 + syb * glt, fym = 1.0 - syb * glt,
                              fzp = 1.0 + szb * glt, fzm = 1.0 - szb * glt;
@@ -671,22 +659,17 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
                     hex8_m_accum(q, q + 9, d, M);
                 }
                 hex8_k_from_m(M, lam, G, kb);
-#endif
                 // phase C: slot of column colg in this row.  The row's columns ascend in GLOBAL
                 // index (the symbolic phase sorted them), so a binary search over the global
                 // indices staged in LDS finds it in log2(rl) steps, the same for every lane
                 // (a linear scan made the wave wait for its slowest lane: 3.6 -> 0.9 ms at 148^3).
                 const int32_t *cl = colsl + r16 * W;
-#if STAN_ABL == 4
-                pos = (lane * 7) % rl; (void)cl;
-#else
                 int lo = 0, hi = rl;  // invariant: cl[lo-1] < colg <= cl[hi]
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
                     if (cl[mid] < colg) lo = mid + 1; else hi = mid;
                 }
                 pos = (lo < rl && cl[lo] == colg) ? lo : -1;
-#endif
             }
             // phase D: ordered accumulation, incidence by incidence (ascending element index)
             int isdup = 0;
@@ -698,9 +681,7 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
                 }
             }
             const bool anydup = __ballot(isdup) != 0ull;
-            if (STAN_ABL == 2) {
-                if (pos == 12345) acc[0] = kb[0];
-            } else {
+            {
                 // One incidence after the other (ascending element index, then local node: the fixed order that makes K
                 // bit-reproducible), each lane adding its block to its slot with LDS fp64 adds (ds_add_f64, no return
                 // value): the eight lanes of one incidence hit eight different slots unless the element lists a node
@@ -747,7 +728,7 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
         int kc = tid / NR;                 // = k * 9 + comp
         int k = kc / 9, comp = kc - 9 * k;
         double *out = A.vals + (int64_t)k0 * 9 * 64 + q * NR + r16;
-        const int kc_end = STAN_ABL == 3 ? 1 : sw * 9;
+        const int kc_end = sw * 9;
         for (; kc < kc_end; kc += STEP) {
             double v = 0.0;
             if (k < rlen) {
@@ -1181,9 +1162,6 @@ int stan_assemble_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz,
         const size_t lds = (size_t)STAN_NUM_ROWS * A.wmax * 9 * 8 + (size_t)4 * 8 * STAN_NUM_XS * 8 +
                            (size_t)4 * 8 * 8 * STAN_NUM_GS * 8 + (size_t)2 * STAN_NUM_ROWS * A.wmax * 4;
         size_t lds_launch = lds;
-#ifdef STAN_LAB_LDS_PAD   // lab: occupancy experiment (more LDS per workgroup -> fewer workgroups per CU)
-        if (const char *pad_ = getenv("STAN_NUM_LDS_PAD")) lds_launch += (size_t)atoi(pad_);
-#endif
         if (lds_launch > 64 * 1024)
             HIPCHK(ctx, hipFuncSetAttribute((const void *)k_numeric,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch));

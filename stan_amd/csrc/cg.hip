@@ -25,22 +25,8 @@
 #include "internal.h"
 #include "p2p_device.h"
 
-// lab switches (tools/lib_lab.sh): non-temporal policy of the vector traffic
-#ifndef STAN_VEC_NT
-#define STAN_VEC_NT 1
-#endif
-#ifndef STAN_Y_NT
-#define STAN_Y_NT 1
-#endif
-// loads of the vector kernels (k_step, k_update): operands a kernel only READS (v in k_step; r, x in k_update) and operands
-// it rewrites in place (r in k_step, p in k_update).  1 = non-temporal, 0 = plain.
-#ifndef STAN_VLD_RO_NT
-#define STAN_VLD_RO_NT 1
-#endif
-#ifndef STAN_VLD_RMW_NT
-#define STAN_VLD_RMW_NT 1
-#endif
-// round 2 (tools/fold_ab.py, profiles/r02/fold_ab_incg_*.txt): the in-CG penalty of the SpMV is the
+// Cache policy of the vector traffic (measured in round 2, tools/fold_ab.py, profiles/r02/fold_ab_incg_*.txt; the
+// compile-time switches behind those runs are the lab build's, lab/lab_hooks.patch): the in-CG penalty of the SpMV is the
 // REWRITING of its gather vector between two products, nothing else (a k_step pass in between costs
 // nothing).  Rewritten by plain stores the following product ran 1.5 / 1.6 / 2.7 / 3.9 / 11 %
 // slower than back to back on five boxes; by non-temporal stores (no load of the line before)
@@ -52,16 +38,12 @@
 // Writing the new p into the OTHER of two buffers (no line of it in any cache) was tried as well:
 // +1.2 % against +1.3 % for the in-place form with non-temporal loads and stores: not built.
 // (STAN_OPT_VEC_STORE_NT: bit 0 = k_update stores p non-temporally, bit 1 = k_step stores r so.)
-#ifndef STAN_R_NT
-#define STAN_R_NT 1   // k_refresh: the new residual stored non-temporally
-#endif
+// The vector kernels' own loads -- operands a kernel only reads (v in k_step; r, x in k_update) and operands it rewrites
+// in place (r in k_step, p in k_update) -- and the products' stores of y are non-temporal too.
 
 namespace {
 
-#ifndef STAN_VEC_BLOCKS
-#define STAN_VEC_BLOCKS 2048
-#endif
-constexpr int VEC_BLOCKS = STAN_VEC_BLOCKS;  // grid of the streaming vector kernels (2048 = 8 blocks per CU)
+constexpr int VEC_BLOCKS = 2048;  // grid of the streaming vector kernels (8 blocks per CU; 1024 ... 16384 measured: profiles/r04/vector_grid_ab_in_cg.txt)
 constexpr int VEC_T = 256;
 constexpr int CHUNK = 32;         // iterations enqueued between two status polls
 constexpr int CHUNK_DIST = 8;     // ... of a sharded loop
@@ -307,11 +289,6 @@ unsigned launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double
     const int variant = ctx->spmv_variant >= 0 ? ctx->spmv_variant : vstream<VT>::FX ? 12 : 9;
     switch (variant) {
         SPMV_CASE(9) SPMV_CASE(12)
-#ifdef STAN_LAB
-        SPMV_CASE(1) SPMV_CASE(2) SPMV_CASE(3) SPMV_CASE(4) SPMV_CASE(5) SPMV_CASE(6) SPMV_CASE(7)
-        SPMV_CASE(8) SPMV_CASE(10) SPMV_CASE(11) SPMV_CASE(13) SPMV_CASE(14) SPMV_CASE(15) SPMV_CASE(16)
-        SPMV_CASE(17) SPMV_CASE(18)
-#endif
         default:
         SPMV_CASE(0)
     }
@@ -1433,21 +1410,8 @@ int stan_spmv_probe(stan_ctx *ctx, stan_matrix *K, const void *vals, size_t byte
     return STAN_OK;
 }
 
-#ifdef STAN_LAB
-#include "lab/cg_lab.inc"   // lab-only host entry points
-#endif
 
-// un-scale on export
-int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K) {
-    if (!K->scaled) return STAN_OK;
-    if (K->nslices > 0)
-        hipLaunchKernelGGL(k_scale_matrix, dim3(nblk(K->nslices, 4)), dim3(256), 0, ctx->stream,
-                           K->nslices, K->d_slot_ptr, K->d_rowof, K->d_cols, K->d_vals, K->d_scale, 1);
-    HIPCHK(ctx, hipGetLastError());
-    K->scaled = false;
-    if (K->d_vals32) { stan_dfree(ctx, K->d_vals32); K->d_vals32 = nullptr; }
-    if (K->d_vals48) { stan_dfree(ctx, K->d_vals48); K->d_vals48 = nullptr; }
-    stan_matrix_drop_folded_values(ctx, K);
-    K->fx48_refused = false;
-    return STAN_OK;
-}
+// the matrix carries S K S from its first solve on -- or from its first export: stan_hip_matrix_to_csr divides the
+// scaled values on the way out, whether or not a solve has happened, so an export before a solve and one after it are
+// the same bits (rounds 1-4 un-scaled the values in place for an export and re-scaled them for the next solve)
+int stan_matrix_ensure_scaled(stan_ctx *ctx, stan_matrix *K) { return ensure_scaled(ctx, K); }

@@ -372,7 +372,7 @@ int stan_matrix_make_cols16(stan_ctx *ctx, stan_matrix *K);
 int stan_pack_columns(stan_ctx *ctx, int32_t nslices, int64_t nslots, const int32_t *d_slot_ptr, const int32_t *d_cols,
                       uint32_t **packed_out, int32_t **base_out, int32_t **pair_ptr_out, uint8_t **ok_out, int64_t *slots_packed,
                       int64_t nloc = 0, const int32_t *d_rowof = nullptr, const int32_t *d_rowlen = nullptr, int64_t *slots_packed2 = nullptr);
-int stan_matrix_unscale(stan_ctx *ctx, stan_matrix *K);
+int stan_matrix_ensure_scaled(stan_ctx *ctx, stan_matrix *K);   // S K S in place (once per matrix)
 int stan_cg_workspace(stan_ctx *ctx, const stan_matrix *K);  // (re)allocates ctx->ws for K's sizes
 void stan_cg_workspace_free(stan_ctx *ctx);
 int stan_cg_workspace_move(stan_ctx *ctx, const stan_matrix *K, bool commit, stan_cg_ws *saved);

@@ -136,9 +136,6 @@ int stan_dmalloc_streamed(stan_ctx *ctx, void **p, size_t bytes,
         if (t_self > worst) worst = t_self;
         if (t > worst) worst = t;
         clear = t_self > 0 && t <= 0.97f * t_self;   // t_self == 0: the candidate is too small to hold its own reference
-#ifdef STAN_LAB   // exercise the long-run path on any box: the first N candidates count as not clear
-        if (const char *fm = getenv("STAN_LAB_PLACEMENT_FORCE_MISSES")) clear = clear && i >= atoi(fm);
-#endif
     }
     if (cand.empty()) return stan_dmalloc_bytes(ctx, p, bytes);  // reports the allocation failure
     size_t ibest = cand.size() - 1;   // the clear one, if the loop ended on it

@@ -32,6 +32,14 @@ def test_product_library_carries_no_lab_code(built_libs):
         assert not hasattr(lib, n), n
     api = open(os.path.join(ROOT, "stan_amd", "csrc", "api.hip")).read()
     assert "value == -1 || value == 0 || value == 9 || value == 12" in api
+    # round 5: the product SOURCES carry no lab switch either -- ablations, A/B kernel variants and compile-time policy
+    # macros are a patch applied to copies (stan_amd/csrc/lab/lab_hooks.patch, `make lab`)
+    csrc = os.path.join(ROOT, "stan_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".inc", ".h")):
+            src = open(os.path.join(csrc, f)).read()
+            for word in ("STAN_LAB", "STAN_ABL", "STAN_VEC_NT", "STAN_Y_NT", "STAN_VLD_RO_NT", "STAN_VLD_RMW_NT", '#include "lab/'):
+                assert word not in src, (f, word)
 
 
 def test_host_library_exports(built_libs):

@@ -217,13 +217,34 @@ def test_bench_gpus_2_without_a_launcher(built_libs):
     assert d["n_gpus"] == 2 and d["config"]["converged"] and d["value"] > 0
     assert d["config"]["parallelism"] == "rows sharded x2"
     pr = d["config"]["p2p_probe"]
-    assert pr["capped_at_iterations"] == 40 and pr["rccl"]["iterations"] == pr["p2p"]["iterations"] == 40
-    assert pr["same_residual_bits"]                                   # rank-ordered sums on both transports
-    assert pr["rccl"]["collectives_per_iteration"] >= 2 and pr["p2p"]["collectives_per_iteration"] == 0
-    assert pr["p2p"]["stream_waits_per_iteration"] >= 2 and pr["rccl"]["stream_waits_per_iteration"] == 0
-    assert pr["rccl"]["ms_per_iteration"] > 0 and pr["p2p"]["ms_per_iteration"] > 0
+    legs = pr["legs"]
+    assert pr["capped_at_iterations"] == 40 and sorted(legs) == ["classic_p2p", "classic_rccl", "single_reduce_p2p", "single_reduce_rccl"]
+    assert all(v["iterations"] == 40 and v["ms_per_iteration"] > 0 and v["every_rank_same_residual_bits"] for v in legs.values())
+    assert pr["same_residual_bits_classic"]                           # (the test transport adds in rank order, like peer to peer)
+    assert all(pr["agrees_with_classic_rccl"].values())
+    assert legs["classic_rccl"]["collectives_per_iteration"] >= 2 and legs["classic_p2p"]["collectives_per_iteration"] == 0
+    assert 1 <= legs["single_reduce_rccl"]["collectives_per_iteration"] < 1.5 and legs["single_reduce_p2p"]["collectives_per_iteration"] == 0
+    assert legs["classic_p2p"]["stream_waits_per_iteration"] >= 2 and legs["classic_rccl"]["stream_waits_per_iteration"] == 0
     assert d["config"]["recommended_transport"] == pr["recommended"]
-    assert pr["recommended"].split()[0] in ("rccl", "p2p")
+    assert pr["recommended"].split()[0] in legs and pr["fastest"] in legs
+    # round 5: the line says which physical device every rank drove (here: both on the one GPU of the test box)
+    ranks = d["config"]["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and all(r["comm_ranks"] == 2 and r["pci_bus_id"] for r in ranks)
+    assert d["config"]["distinct_devices"] == 1 and ranks[0]["pid"] != ranks[1]["pid"]
+
+
+def test_bench_probe_that_crashes_leaves_the_line_alone(built_libs):
+    """a HARD failure inside the probe -- here rank 1's probe process aborts (test hook) in front of its
+    first peer-to-peer leg, as a GPU fault or an abort inside RCCL / an IPC mapping would -- must not cost the measurement:
+    the probe runs in child processes, the measured ranks print their line unchanged and end with code 0."""
+    out = _bench_no_launcher(["--gpus", "2", "--steps", "1", "--warmup", "1", "--size", "12", "--no-cpu",
+                              "--probe-its", "20", "--probe-watchdog", "10"], {"STAN_BENCH_TEST_CRASH_PROBE": "1"})
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["converged"] and d["value"] > 0
+    assert "p2p_probe" not in d["config"] and "error" not in d
 
 
 def test_bench_probe_that_stalls_leaves_the_line_alone(built_libs):
