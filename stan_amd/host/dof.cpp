@@ -1,11 +1,24 @@
 // dof.cpp -- host-side integer steps around the GPU hot path (include/stan_host.h).
 #include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/stan_host.h"
 
-extern "C" {
+namespace stan {
+int HostThreads();
+namespace {
+template <typename F>
+void par_ranges(int64_t n, int threads, F fn) {
+    if (threads <= 1 || n < 65536) { fn((int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < threads; t++) th.emplace_back([=] { fn(n * t / threads, n * (t + 1) / threads); });
+    fn((int64_t)0, n / threads);
+    for (std::thread &x : th) x.join();
+}
+}  // namespace
 
 // Database.AssignDOF (Database.cs:140-234).
 //
@@ -17,32 +30,48 @@ extern "C" {
 // same numbering with a queue of exactly n_nodes entries and no stored neighbour lists:
 // neighbours are enumerated on the fly from the node->element incidence (EList order =
 // element order with duplicates removed, Node.cs:202-205).
-int stan_host_assign_dof(int64_t n_nodes, int64_t n_elem, const int32_t *conn,
-                         int32_t *node_index_out, int32_t *node_dof_out) {
+// Round 5: the incidence table (EList as CSR) is built on the host threads -- counted and filled with atomic cursors in
+// whatever order the threads arrive, then every node's few entries sorted: ascending element index IS the ElemLib order the
+// serial fill produced -- and handed to the caller (eptr_out / elist_out), who needs the same lists for Node.EList.  The
+// walk itself stays serial: its order is the result.
+int AssignDofCore(int64_t n_nodes, int64_t n_elem, const int32_t *conn, int32_t *node_index_out, int32_t *node_dof_out,
+                  std::vector<int64_t> *eptr_out, std::vector<int32_t> *elist_out) {
     if (n_nodes <= 0 || n_elem < 0 || !conn || !node_index_out) return STAN_HOST_E_ARG;
-    for (int64_t t = 0; t < n_elem * 8; t++)
-        if (conn[t] < 0 || conn[t] >= n_nodes) return STAN_HOST_E_ARG;
+    const int threads = HostThreads();
+    std::atomic<int> bad{0};
+    par_ranges(n_elem * 8, threads, [&](int64_t a, int64_t b) {
+        for (int64_t t = a; t < b; t++)
+            if (conn[t] < 0 || conn[t] >= n_nodes) { bad.store(1); return; }
+    });
+    if (bad.load()) return STAN_HOST_E_ARG;
     // EList (CSR), distinct per node: Element.AddElem2Nodes (Element.cs:474-480) in ElemLib order
+    std::vector<std::atomic<int32_t>> cnt((size_t)n_nodes);
+    par_ranges(n_nodes, threads, [&](int64_t a, int64_t b) { for (int64_t i = a; i < b; i++) cnt[(size_t)i].store(0, std::memory_order_relaxed); });
+    auto first_listing = [&](int64_t e, int a) {
+        const int32_t nd = conn[e * 8 + a];
+        for (int b = 0; b < a; b++) if (conn[e * 8 + b] == nd) return false;
+        return true;
+    };
+    par_ranges(n_elem, threads, [&](int64_t e0, int64_t e1) {
+        for (int64_t e = e0; e < e1; e++)
+            for (int a = 0; a < 8; a++)
+                if (first_listing(e, a)) cnt[(size_t)conn[e * 8 + a]].fetch_add(1, std::memory_order_relaxed);
+    });
     std::vector<int64_t> eptr((size_t)n_nodes + 1, 0);
-    for (int64_t e = 0; e < n_elem; e++)
-        for (int a = 0; a < 8; a++) {
-            const int32_t nd = conn[e * 8 + a];
-            bool dup = false;
-            for (int b = 0; b < a; b++) dup |= conn[e * 8 + b] == nd;
-            if (!dup) eptr[(size_t)nd + 1]++;
-        }
-    for (int64_t i = 0; i < n_nodes; i++) eptr[(size_t)i + 1] += eptr[(size_t)i];
+    for (int64_t i = 0; i < n_nodes; i++) eptr[(size_t)i + 1] = eptr[(size_t)i] + cnt[(size_t)i].load(std::memory_order_relaxed);
     std::vector<int32_t> elist((size_t)eptr[(size_t)n_nodes]);
-    {
-        std::vector<int64_t> fill(eptr.begin(), eptr.end() - 1);
-        for (int64_t e = 0; e < n_elem; e++)
-            for (int a = 0; a < 8; a++) {
-                const int32_t nd = conn[e * 8 + a];
-                bool dup = false;
-                for (int b = 0; b < a; b++) dup |= conn[e * 8 + b] == nd;
-                if (!dup) elist[(size_t)fill[(size_t)nd]++] = (int32_t)e;
-            }
-    }
+    par_ranges(n_nodes, threads, [&](int64_t a, int64_t b) { for (int64_t i = a; i < b; i++) cnt[(size_t)i].store(0, std::memory_order_relaxed); });
+    par_ranges(n_elem, threads, [&](int64_t e0, int64_t e1) {
+        for (int64_t e = e0; e < e1; e++)
+            for (int a = 0; a < 8; a++)
+                if (first_listing(e, a)) {
+                    const int32_t nd = conn[e * 8 + a];
+                    elist[(size_t)(eptr[(size_t)nd] + cnt[(size_t)nd].fetch_add(1, std::memory_order_relaxed))] = (int32_t)e;
+                }
+    });
+    par_ranges(n_nodes, threads, [&](int64_t a, int64_t b) {
+        for (int64_t i = a; i < b; i++) std::sort(elist.begin() + eptr[(size_t)i], elist.begin() + eptr[(size_t)i + 1]);
+    });
     // Database.cs:178-196: first node (NodeLib order) contained in exactly 1, else 2 ... 6 elements
     int64_t first = -1;
     for (int c = 1; c < 7 && first < 0; c++)
@@ -76,12 +105,25 @@ int stan_host_assign_dof(int64_t n_nodes, int64_t n_elem, const int32_t *conn,
         push_neighbours(nid);
     }
     if (node_dof_out)
-        for (int64_t i = 0; i < n_nodes; i++) {  // Node.SetDOF, Node.cs:218-223
-            node_dof_out[3 * i + 0] = 3 * node_index_out[i];
-            node_dof_out[3 * i + 1] = 3 * node_index_out[i] + 1;
-            node_dof_out[3 * i + 2] = 3 * node_index_out[i] + 2;
-        }
+        par_ranges(n_nodes, threads, [&](int64_t a, int64_t b) {
+            for (int64_t i = a; i < b; i++) {  // Node.SetDOF, Node.cs:218-223
+                node_dof_out[3 * i + 0] = 3 * node_index_out[i];
+                node_dof_out[3 * i + 1] = 3 * node_index_out[i] + 1;
+                node_dof_out[3 * i + 2] = 3 * node_index_out[i] + 2;
+            }
+        });
+    if (eptr_out) *eptr_out = std::move(eptr);
+    if (elist_out) *elist_out = std::move(elist);
     return STAN_HOST_OK;
+}
+}  // namespace stan
+
+extern "C" {
+
+// Database.AssignDOF (Database.cs:140-234): stan::AssignDofCore above.
+int stan_host_assign_dof(int64_t n_nodes, int64_t n_elem, const int32_t *conn,
+                         int32_t *node_index_out, int32_t *node_dof_out) {
+    return stan::AssignDofCore(n_nodes, n_elem, conn, node_index_out, node_dof_out, nullptr, nullptr);
 }
 
 // Solver.cs:104-132

@@ -77,27 +77,32 @@ int Database::AssignDOF() {
             for (std::thread &x : th) x.join();
         }
         if (bad.load()) return STAN_HOST_E_ARG;
-        auto prep = [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) { nodes[i].second.EList.clear(); nodes[i].second.EList.reserve(8); } };
-        if (nt <= 1 || nodes.size() < 4096) prep(0, nodes.size());
+    }
+    // the walk, and with it the node -> element incidence it builds anyway (CSR, ElemLib order)
+    std::vector<int32_t> index((size_t)nn);
+    std::vector<int64_t> eptr;
+    std::vector<int32_t> elist;
+    const int rc = AssignDofCore(nn, ne, conn.data(), index.data(), nullptr, &eptr, &elist);
+    if (rc != STAN_HOST_OK) return rc;
+    {   // Element.AddElem2Nodes in ElemLib order (Element.cs:474-480) and Node.SetDOF (Node.cs:218-223), per node on the host threads
+        const size_t nt = (size_t)HostThreads();
+        auto fill = [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; i++) {
+                Node &n = nodes[i].second;
+                n.EList.clear();
+                n.EList.reserve((size_t)(eptr[i + 1] - eptr[i]));
+                for (int64_t q = eptr[i]; q < eptr[i + 1]; q++) n.EList.push_back(elems[(size_t)elist[(size_t)q]].second.ID);
+                n.SetDOF(index[i]);
+            }
+        };
+        if (nt <= 1 || nodes.size() < 4096) fill(0, nodes.size());
         else {
             std::vector<std::thread> th;
-            for (size_t t = 0; t < nt; t++) th.emplace_back(prep, nodes.size() * t / nt, nodes.size() * (t + 1) / nt);
+            for (size_t t = 0; t < nt; t++) th.emplace_back(fill, nodes.size() * t / nt, nodes.size() * (t + 1) / nt);
             for (std::thread &x : th) x.join();
         }
     }
-    for (size_t e = 0; e < elems.size(); e++) {   // Element.AddElem2Nodes in ElemLib order (Element.cs:474-480)
-        const int id = elems[e].second.ID;
-        for (int k = 0; k < 8; k++) {
-            std::vector<int> &el_list = nodes[(size_t)conn[e * 8 + (size_t)k]].second.EList;
-            if (el_list.empty() || el_list.back() != id) el_list.push_back(id);
-        }
-    }
-    std::vector<int32_t> index((size_t)nn);
-    const int rc = stan_host_assign_dof(nn, ne, conn.data(), index.data(), nullptr);
-    if (rc != STAN_HOST_OK) return rc;
     conn_index = std::move(conn);   // Flatten needs the same 8 lookups per element again
-    int64_t i = 0;
-    for (auto &kv : NodeLib.Items()) kv.second.SetDOF(index[(size_t)i++]);
     return STAN_HOST_OK;
 }
 

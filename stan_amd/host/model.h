@@ -228,6 +228,10 @@ struct Database {  // Database.cs:10-37
     std::string Database_Summary() const;                  // Database.cs:123-133
 };
 
+// dof.cpp: stan_host_assign_dof with the node -> element incidence (CSR, ElemLib order) it builds handed out as well
+int AssignDofCore(int64_t n_nodes, int64_t n_elem, const int32_t *conn, int32_t *node_index_out, int32_t *node_dof_out,
+                  std::vector<int64_t> *eptr_out, std::vector<int32_t> *elist_out);
+
 // ---- STdb (protobuf-net 3.0.73 wire format) --------------------------
 // packed=false writes repeated scalars unpacked (protobuf-net default without IsPacked);
 // the reader accepts both encodings and both orders of map key/value.

@@ -194,7 +194,10 @@ def test_bench_mode_against_the_oracle_at_56_cubed(gpu_ctx, oracle):
             assert r8["terminationtype"] == r12["terminationtype"] == 1
             assert r8["rel_residual"] <= 1e-8 and r12["rel_residual"] <= 1e-12
             assert abs(r8["iterations"] - ro8["iterations"]) <= max(2, ro8["iterations"] // 50), (r8, ro8)
-            assert abs(r12["iterations"] - ro12["iterations"]) <= max(2, ro12["iterations"] // 50), (r12, ro12)
+            if prec == hip.PREC_FP64:
+                assert abs(r12["iterations"] - ro12["iterations"]) <= max(2, ro12["iterations"] // 50), (r12, ro12)
+            else:   # 1e-12 is below what the quantised entries carry (7e-15 * kappa): the fp64 check asks for a refinement pass
+                assert ro12["iterations"] <= r12["iterations"] <= 2 * ro12["iterations"], (r12, ro12)
             d8 = np.abs(U8 - Uo8).max() / np.abs(Uo8).max()
             d12 = np.abs(U12 - Uo12).max() / np.abs(Uo12).max()
             print("56^3 bench mode, value stream %d: its %d/%d (oracle %d/%d), |U-Uo| %.2e at 1e-8, %.2e at 1e-12"
@@ -278,13 +281,15 @@ def test_config5_g1_mixed_precision_three_face_clamp(gpu_ctx, oracle):
         gpu_ctx.set_option(hip.OPT_CG_MERIT_STOP, 1)
     assert rm["terminationtype"] == r64["terminationtype"] == ro["terminationtype"] == 1
     assert abs(r64["iterations"] - ro["iterations"]) <= max(3, ro["iterations"] // 50)
-    assert abs(rm["iterations"] - ro["iterations"]) <= max(5, ro["iterations"] // 10)
+    # round 5: the fp32 copy is refined until the FP64 residual meets 1e-8 (STAN_OPT_CG_REFINE): more iterations than the
+    # fp64 stream, and an answer of its quality instead of one that is off by kappa * 6e-8
+    assert ro["iterations"] <= rm["iterations"] <= 3 * ro["iterations"] and rm["rel_residual"] <= 1e-8
     d64 = np.abs(U64 - Uo).max() / np.abs(Uo).max()
     dm = np.abs(Um - Uo).max() / np.abs(Uo).max()
     print("G1 + mixed at 16^3: its %d (fp64 %d, oracle %d), |U-Uo| mixed %.2e, fp64 %.2e"
           % (rm["iterations"], r64["iterations"], ro["iterations"], dm, d64))
     assert d64 <= kappa * 1e-8
-    assert dm <= kappa * 6e-8
+    assert dm <= kappa * 1e-8
     K.free()
 
 

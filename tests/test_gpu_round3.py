@@ -378,7 +378,10 @@ def test_folded_rows_give_the_same_product(gpu_ctx, oracle, mesh, prec):
     assert same > (0.3 if mesh != "cube" else 0.9), same           # unfolded rows keep their bits
     for r in (a[1], b[1]):
         assert r["terminationtype"] in (1, 7)
-    assert abs(a[1]["iterations"] - b[1]["iterations"]) <= max(3, a[1]["iterations"] // 20)
+    if prec == 0:
+        assert abs(a[1]["iterations"] - b[1]["iterations"]) <= max(3, a[1]["iterations"] // 20)
+    else:   # a reduced-precision stream may need a refinement pass on one layout and pass its fp64 check on the other
+        assert max(a[1]["iterations"], b[1]["iterations"]) <= 2 * min(a[1]["iterations"], b[1]["iterations"]) + 3
     rc, A = oracle.assemble(*args)
     Uo, repo = oracle.cg(A, job.F, 1e-12)
     tol = 1e-6 if prec == 0 else 1e-4
