@@ -173,7 +173,9 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
                            are allocated one after the other, the real pairing timed with the two vectors the
                            products WRITE carved out of each, and the best place kept -- block and all -- if it
                            is 1 % better than the pairing so far and 3 % clear of the reference: the place of
-                           the written vector alone decides.  Environment, diagnosis only:
+                           the written vector alone decides.  The kept block (up to 4 GB for
+                           2 x 8 B x nDOF) stays allocated until the context's vectors are re-sized or it is destroyed.
+                           Environment, diagnosis only:
                            STAN_PLACEMENT_TRACE=1 prints every probe on stderr, =sweep walks the blocks
                            whatever the first stage found and keeps nothing.
                            Only blocks of 256 MB and more are searched for; ~10 ms per candidate once

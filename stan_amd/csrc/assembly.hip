@@ -706,6 +706,10 @@ __global__ void __launch_bounds__(256, STAN_NUM_WAVES) k_numeric(numeric_args A)
                             }
                         }
                     }
+                    // the rounds must stay eight separate groups of DS instructions in this order (the summation order of a
+                    // slot is the order of the rounds): no instruction moves across this point (per-thread
+                    // semantics alone would let a compiler merge the predicated adds of different rounds)
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -349,7 +349,11 @@ int stan_cg_workspace(stan_ctx *ctx, const stan_matrix *K) {
 }
 void stan_cg_workspace_free(stan_ctx *ctx) {
     stan_cg_ws &ws = ctx->ws;
-    if (ws.vw_owner) { stan_dfree(ctx, ws.vw_owner); ws.vw_owner = ws.v = ws.w = nullptr; }   // v, w carved out of one block
+    if (ws.vw_owner) {   // v, w carved out of one block (placement.hip, second stage): plain device memory, not the pool's
+        stan_dfree(ctx, ws.vw_owner);
+        ws.vw_owner = ws.v = ws.w = nullptr;
+        ctx->prof_placement_moved_vectors = 0;   // the next matrix of another size searches afresh
+    }
     for (double **q : {&ws.xb[0], &ws.xb[1], &ws.p, &ws.r, &ws.v, &ws.w, &ws.bh, &ws.sv}) {
         if (*q) stan_dfree(ctx, *q);
         *q = nullptr;
@@ -424,7 +428,9 @@ void stan_cg_products_adopt(stan_ctx *ctx, double *block, size_t bytes, double *
     if (saved[2]) { ctx->pool.live.erase((void *)saved[2]); hipFree(saved[2]); }
     else for (int i = 0; i < 2; i++) if (saved[i]) { ctx->pool.live.erase((void *)saved[i]); hipFree(saved[i]); }
     ws.v = block; ws.w = block + vw_stride(ws); ws.vw_owner = block;
-    if (ctx->pool.enabled && bytes >= stan_pool::MIN_BYTES) ctx->pool.live[(void *)block] = bytes;
+    // NOT a pooled block: 1-4 GB that hold 2 x n3 doubles would sit in the pool for the context's life once
+    // the workspace is re-sized, matching no later request; stan_cg_workspace_free gives it straight back to the driver
+    (void)bytes;
     saved[0] = saved[1] = saved[2] = nullptr;
 }
 

@@ -241,3 +241,42 @@ def test_flat_result_writer_writes_the_object_path_bytes(built_libs, tmp_path):
     r = host.Db.read_stdb(a)
     d1, e1, s1 = r.results(1)
     assert np.array_equal(d1, disp + 0.0) and np.array_equal(e1, strain) and np.array_equal(s1, stress)
+
+
+def test_mapped_export_writes_the_bytes_of_the_write_calls(built_libs, tmp_path):
+    """Round 5: large result files are written through a shared mapping of an upper-bound length that is cut to the true
+    length at the end (buffered write calls to ONE file serialise on its inode lock whatever the thread count:
+    stdb.cpp Sink).  STAN_STDB_WRITE forces either path on a small model: same bytes, packed and unpacked, with and
+    without results."""
+    import subprocess
+    import sys
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+from stan_amd import host
+from stan_amd.cube import cube_mesh, cube_bcs
+n = 9
+xyz, conn = cube_mesh(n)
+d = host.Db()
+ne = conn.shape[0]
+d.set_mesh(np.arange(1, xyz.shape[0] + 1), xyz, np.arange(1, ne + 1), np.ones(ne), conn + 1, "HEX8_G2")
+d.add_material(1, "Steel", 210000.0, 0.3); d.assign_part(1, 1, "HEX8_G2")
+spc, ld, f = cube_bcs(n)
+d.add_bc(1, "fix", "SPC", spc + 1, np.ones((len(spc), 3)))
+d.add_bc(2, "load", "PointLoad", ld + 1, np.tile(f, (len(ld), 1)))
+d.set_analysis(tol=1e-6)
+rng = np.random.default_rng(5)
+disp, strain, stress = rng.standard_normal((xyz.shape[0], 3)), rng.standard_normal((ne, 8, 6)), rng.standard_normal((ne, 8, 6))
+for packed in (False, True):
+    d.write_stdb(sys.argv[1] + "_plain_%%d" %% packed, packed=packed)
+    d.write_stdb_with_results(sys.argv[1] + "_res_%%d" %% packed, disp, strain, stress, packed=packed)
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for mode in ("pwrite", "map"):
+        base = str(tmp_path / mode)
+        p = subprocess.run([sys.executable, "-c", code, base], env=dict(os.environ, STAN_STDB_WRITE=mode, STAN_HOST_THREADS="4"),
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out[mode] = {k: open(base + k, "rb").read() for k in ("_plain_0", "_plain_1", "_res_0", "_res_1")}
+    for k in out["map"]:
+        assert len(out["map"][k]) > 10000 and out["map"][k] == out["pwrite"][k], k
