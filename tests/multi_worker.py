@@ -31,6 +31,14 @@ assert repp == rep and np.array_equal(Up, U), "packed column stream changed the 
 # per-element stress recovery split over the devices
 disp = np.zeros(job.n_dof); disp[job.red != -1] = U
 strain, stress = ctx.recover_hex8(job.xyz, disp[job.node_dof], job.conn, job.elem_mat, job.elem_type, job.mat_E_nu)
+# ... and the same with the results kept on the devices, mapped across the chunk boundaries
+res = ctx.recover_hex8_keep(job.xyz, disp[job.node_dof], job.conn, job.elem_mat, job.elem_type, job.mat_E_nu)
+ne = job.conn.shape[0]
+keep_equal = True
+for a, b in ((0, ne), (3, ne - 2), (ne // nranks - 1, ne // nranks + 2), (ne - 1, ne)):
+    e2, s2 = res.map(a, b)
+    keep_equal = keep_equal and np.array_equal(e2, strain[a:b]) and np.array_equal(s2, stress[a:b])
+res.free()
 unsupported = 0
 try:
     K.to_csr()
@@ -38,7 +46,7 @@ except hip.StanHipError as e:
     unsupported = e.code
 np.savez(out, U=U, Ux=Ux, Us=Us, its=rep["iterations"], term=rep["terminationtype"], its_s=reps["iterations"],
          term_s=reps["terminationtype"], its_x=repx["iterations"], strain=strain, stress=stress,
-         n_blocks=info["n_blocks"], n_halo=info["n_halo"], n_elem_dev=info["n_elements_on_device"], unsupported=unsupported,
+         n_blocks=info["n_blocks"], n_halo=info["n_halo"], n_elem_dev=info["n_elements_on_device"], unsupported=unsupported, keep_equal=keep_equal,
          coll_per_it=prof["loop_collectives"] / max(prof["loop_iterations_enqueued"], 1),
          coll_per_it_s=profs["loop_collectives"] / max(profs["loop_iterations_enqueued"], 1))
 K.free()

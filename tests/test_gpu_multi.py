@@ -41,6 +41,7 @@ def test_one_process_several_ranks_matches_oracle(built_libs, oracle, tmp_path, 
     # every rank uploads and scans only the elements that touch its rows (boundary ones twice)
     assert n ** 3 < int(d["n_elem_dev"]) < 0.8 * nranks * n ** 3
     assert int(d["unsupported"]) == -8                                        # single-rank helper on a group handle
+    assert bool(d["keep_equal"])      # results kept on the devices, mapped across the devices' chunk boundaries: the same bits
     # the classic loop reduces twice per iteration, the single-reduction loop once
     assert 1.9 <= float(d["coll_per_it"]) <= 2.1 and 1.0 <= float(d["coll_per_it_s"]) <= 1.1
     # stress recovery (elements cut into one chunk per device) against the oracle

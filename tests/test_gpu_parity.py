@@ -444,6 +444,40 @@ def test_stress_recovery_parity(gpu_ctx, oracle):
         assert np.abs(stress[e] - so).max() <= 1e-12 * np.abs(so).max()
 
 
+def test_recovery_results_kept_on_the_device_and_mapped_by_threads(gpu_ctx):
+    """stan_hip_recover_hex8_keep + stan_hip_results_map (what the console driver's export uses): any element range, from
+    several host threads at once, gives the rows stan_hip_recover_hex8 returns -- bit for bit; 7^3 = 343 elements is not a
+    multiple of the 8 elements a wavefront handles (the kernel's ragged tail)."""
+    import threading
+    job = problem.cube_job(7, jitter=0.1)
+    disp = np.random.default_rng(11).standard_normal(job.xyz.shape) * 1e-3
+    strain, stress = gpu_ctx.recover_hex8(job.xyz, disp, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu)
+    res = gpu_ctx.recover_hex8_keep(job.xyz, disp, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu)
+    ne = job.conn.shape[0]
+    assert res.n_elem == ne == 343
+    for a, b in ((0, ne), (0, 0), (5, 17), (ne - 3, ne), (100, 101)):
+        e, s = res.map(a, b)
+        assert np.array_equal(e, strain[a:b]) and np.array_equal(s, stress[a:b]), (a, b)
+    bad = []
+
+    def worker(t):
+        rng = np.random.default_rng(t)
+        for _ in range(50):
+            a = int(rng.integers(0, ne))
+            b = int(rng.integers(a, ne + 1))
+            e, s = res.map(a, b)
+            if not (np.array_equal(e, strain[a:b]) and np.array_equal(s, stress[a:b])):
+                bad.append((t, a, b))
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not bad, bad[:3]
+    from stan_amd import hip
+    with pytest.raises(hip.StanHipError):
+        res.map(0, ne + 1)
+    res.free()
+
+
 def test_nodal_forces_parity(gpu_ctx, oracle):
     """Element.Compute_NodalForces + the R assembly of Solver.cs:184-196 against the oracle."""
     job = problem.cube_job(5, jitter=0.1)
