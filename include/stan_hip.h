@@ -253,9 +253,13 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
 #define STAN_OPT_POOL 7 /* 1 (default): device blocks >= 8 MB freed by the library stay with the
                            context and are reused by its next allocations (a hipMalloc of tens of GB
                            costs 0.4-1.8 s here); 0: release them now, plain hipMalloc/hipFree from then on */
-#define STAN_OPT_POOL_MAX_BYTES 9 /* byte budget of the parked blocks (default: half the device memory; the oldest are released
-                           beyond it).  Setting it trims at once: 0 releases everything parked now and keeps
-                           nothing afterwards, without switching the reuse of live blocks' sizes off. */
+#define STAN_OPT_POOL_MAX_BYTES 9 /* byte budget of the parked blocks (default: half the device memory -- a library inside a
+                           foreign host must not sit on the device; the oldest are released beyond it).  Setting it trims
+                           at once: 0 releases everything parked now and keeps nothing afterwards, without switching the
+                           reuse of live blocks' sizes off.  -1: "this process owns the device" -- nine tenths of the
+                           memory that is free at the call (bench.py and stan_solver do; at 400^3 the fp64 values and
+                           their fp32 copy are 126 + 63 GB: under the default one of them went back to the driver every
+                           step, 4.7 s of hipMalloc per step; with the budget the assembly is 0.24 s, its kernels' time). */
 #define STAN_OPT_SPMV_VARIANT 3 /* SpMV kernel variant (cg.hip): -1 = auto (default: 9 for fp64/fp32 streams,
                            12 for FIXED-48), 0 = plain loads + identity mapping, 9 = non-temporal matrix
                            stream + XCD-chunked workgroup mapping, 12 = 9 unrolled by 4.  Every accepted

@@ -134,9 +134,14 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
             ctx->pool.flush();
         }
     }
-    else if (option == STAN_OPT_POOL_MAX_BYTES && value >= 0) {
-        ctx->pool.max_bytes = (size_t)value;
+    else if (option == STAN_OPT_POOL_MAX_BYTES && value >= -1) {
         hipSetDevice(ctx->device);
+        if (value == -1) {   // "this process owns the device": nine tenths of what is free now
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); ctx->err = "set_option: hipMemGetInfo failed"; return STAN_E_HIP; }
+            value = (int64_t)(free_b - free_b / 10 + ctx->pool.bytes_avail);   // (parked blocks are not "free" to the driver)
+        }
+        ctx->pool.max_bytes = (size_t)value;
         hipStreamSynchronize(ctx->stream);  // parked blocks may still be in use by queued work
         while (!ctx->pool.avail.empty() && ctx->pool.bytes_avail > ctx->pool.max_bytes) {
             hipFree(ctx->pool.avail.front().p);

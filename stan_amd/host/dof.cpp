@@ -1,7 +1,11 @@
 // dof.cpp -- host-side integer steps around the GPU hot path (include/stan_host.h).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -38,6 +42,12 @@ int AssignDofCore(int64_t n_nodes, int64_t n_elem, const int32_t *conn, int32_t 
                   std::vector<int64_t> *eptr_out, std::vector<int32_t> *elist_out) {
     if (n_nodes <= 0 || n_elem < 0 || !conn || !node_index_out) return STAN_HOST_E_ARG;
     const int threads = HostThreads();
+    const bool trace = getenv("STAN_HOST_TRACE") != nullptr;   // stage times on stderr (diagnosis)
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (trace) fprintf(stderr, "[stan host] AssignDOF %-28s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        t0 = std::chrono::steady_clock::now();
+    };
     std::atomic<int> bad{0};
     par_ranges(n_elem * 8, threads, [&](int64_t a, int64_t b) {
         for (int64_t t = a; t < b; t++)
@@ -72,6 +82,7 @@ int AssignDofCore(int64_t n_nodes, int64_t n_elem, const int32_t *conn, int32_t 
     par_ranges(n_nodes, threads, [&](int64_t a, int64_t b) {
         for (int64_t i = a; i < b; i++) std::sort(elist.begin() + eptr[(size_t)i], elist.begin() + eptr[(size_t)i + 1]);
     });
+    lap("incidence table (threads)");
     // Database.cs:178-196: first node (NodeLib order) contained in exactly 1, else 2 ... 6 elements
     int64_t first = -1;
     for (int c = 1; c < 7 && first < 0; c++)
@@ -79,31 +90,119 @@ int AssignDofCore(int64_t n_nodes, int64_t n_elem, const int32_t *conn, int32_t 
             if (eptr[(size_t)i + 1] - eptr[(size_t)i] == c) { first = i; break; }
     if (first < 0) return STAN_HOST_E_NO_START;
 
-    std::vector<uint8_t> pushed((size_t)n_nodes, 0);
+    // The walk.  The queue is the result: node k of it gets index k.  Serial form: pop u, scan its elements (EList order) and
+    // their nodes (NList order), append every node seen for the first time.  The queue is a sequence of LEVELS (level k + 1 =
+    // what the scan of level k discovers), and within a level the order is "first occurrence in the concatenated scans of
+    // the level's nodes" -- which threads can produce without walking one node after the other (round 5): every thread
+    // scans a contiguous piece of the level and claims each unseen node with the key (position of the scanning node in the
+    // level, offset inside its scan) by an atomic minimum; the smallest key of a node is its first occurrence; a second
+    // scan keeps the candidates whose key won, and the pieces' winners, concatenated in piece order, ARE the serial order.
+    // Levels narrower than `par_min` nodes are walked serially (the first and last levels of a cube, every level of a small
+    // mesh); STAN_HOST_BFS_PAR_MIN overrides (tests: 1).
     std::vector<int32_t> queue((size_t)n_nodes);
+    constexpr uint64_t UNSEEN = ~(uint64_t)0;
+    std::vector<std::atomic<uint64_t>> state((size_t)n_nodes);   // UNSEEN, a claim key of the level being scanned, or 0 = in the queue
+    par_ranges(n_nodes, threads, [&](int64_t a, int64_t b) { for (int64_t i = a; i < b; i++) state[(size_t)i].store(UNSEEN, std::memory_order_relaxed); });
+    int64_t par_min = 4096;
+    if (const char *e = getenv("STAN_HOST_BFS_PAR_MIN")) par_min = atoll(e) > 0 ? atoll(e) : par_min;
     int64_t head = 0, tail = 0;
-    int32_t index = 0;
-    auto push_neighbours = [&](int64_t nid) {
-        for (int64_t q = eptr[(size_t)nid]; q < eptr[(size_t)nid + 1]; q++) {
-            const int32_t *nl = conn + (int64_t)elist[(size_t)q] * 8;
-            for (int a = 0; a < 8; a++) {
-                const int32_t n = nl[a];
-                if (!pushed[(size_t)n]) {
-                    pushed[(size_t)n] = 1;
-                    queue[(size_t)tail++] = n;
+    queue[(size_t)tail++] = (int32_t)first;   // Database.cs:209-211; NextNode = Neighbors[FirstNode]
+    state[(size_t)first].store(0, std::memory_order_relaxed);
+    // persistent workers for the wide levels (a thread per level would cost more than the level)
+    struct Pool {
+        int n;
+        std::vector<std::thread> th;
+        std::atomic<int> phase{0}, arrived{0};
+        std::atomic<bool> quit{false};
+        std::function<void(int)> job;
+        void run(const std::function<void(int)> &f) {   // f(t) on every worker, the caller is worker 0
+            job = f;
+            arrived.store(0, std::memory_order_relaxed);
+            phase.fetch_add(1, std::memory_order_release);
+            f(0);
+            while (arrived.load(std::memory_order_acquire) < n - 1) std::this_thread::yield();
+        }
+    } pool;
+    pool.n = threads;
+    auto start_pool = [&] {
+        for (int t = 1; t < pool.n; t++)
+            pool.th.emplace_back([&pool, t] {
+                int seen = 0;
+                for (;;) {
+                    while (pool.phase.load(std::memory_order_acquire) == seen) {
+                        if (pool.quit.load(std::memory_order_relaxed)) return;
+                        std::this_thread::yield();
+                    }
+                    seen++;
+                    pool.job(t);
+                    pool.arrived.fetch_add(1, std::memory_order_release);
+                }
+            });
+    };
+    std::vector<int64_t> cnt_t((size_t)threads + 1, 0);
+    while (tail < n_nodes) {
+        if (head >= tail) { pool.quit.store(true); for (std::thread &x : pool.th) x.join(); return STAN_HOST_E_DISCONNECTED; }
+        const int64_t l0 = head, l1 = tail;   // the level to scan
+        if (threads <= 1 || l1 - l0 < par_min) {
+            for (int64_t h = l0; h < l1; h++) {
+                const int32_t nid = queue[(size_t)h];
+                for (int64_t q = eptr[(size_t)nid]; q < eptr[(size_t)nid + 1]; q++) {
+                    const int32_t *nl = conn + (int64_t)elist[(size_t)q] * 8;
+                    for (int a = 0; a < 8; a++) {
+                        const int32_t n = nl[a];
+                        if (state[(size_t)n].load(std::memory_order_relaxed) != 0) {
+                            state[(size_t)n].store(0, std::memory_order_relaxed);
+                            queue[(size_t)tail++] = n;
+                        }
+                    }
                 }
             }
+            head = l1;
+            continue;
         }
-    };
-    node_index_out[first] = index++;  // Database.cs:209-211
-    pushed[(size_t)first] = 1;
-    push_neighbours(first);           // NextNode = Neighbors[FirstNode]
-    while (index < n_nodes) {
-        if (head >= tail) return STAN_HOST_E_DISCONNECTED;
-        const int32_t nid = queue[(size_t)head++];
-        node_index_out[nid] = index++;
-        push_neighbours(nid);
+        if (pool.th.empty()) start_pool();
+        const int64_t m = l1 - l0;
+        auto piece = [&](int t, int64_t *a, int64_t *b) { *a = l0 + m * t / threads; *b = l0 + m * (t + 1) / threads; };
+        auto scan = [&](int t, int pass, int64_t out) {   // pass 0: claim; 1: count the winners; 2: write them from `out` on
+            int64_t a, b, won = 0;
+            piece(t, &a, &b);
+            for (int64_t h = a; h < b; h++) {
+                const int32_t nid = queue[(size_t)h];
+                uint64_t key = ((uint64_t)(h - l0) << 32) + 1;   // (position in the level, offset in the scan) + 1: never 0
+                for (int64_t q = eptr[(size_t)nid]; q < eptr[(size_t)nid + 1]; q++) {
+                    const int32_t *nl = conn + (int64_t)elist[(size_t)q] * 8;
+                    for (int a2 = 0; a2 < 8; a2++, key++) {
+                        std::atomic<uint64_t> &st = state[(size_t)nl[a2]];
+                        uint64_t cur = st.load(std::memory_order_relaxed);
+                        if (pass == 0) {
+                            while (cur > key && !st.compare_exchange_weak(cur, key, std::memory_order_relaxed)) {}
+                        } else if (cur == key) {
+                            if (pass == 2) queue[(size_t)(out + won)] = nl[a2];
+                            won++;
+                        }
+                    }
+                }
+            }
+            return won;
+        };
+        pool.run([&](int t) { scan(t, 0, 0); });
+        pool.run([&](int t) { cnt_t[(size_t)t + 1] = scan(t, 1, 0); });
+        cnt_t[0] = 0;
+        for (int t = 0; t < threads; t++) cnt_t[(size_t)t + 1] += cnt_t[(size_t)t];
+        const int64_t base = tail;
+        pool.run([&](int t) { scan(t, 2, base + cnt_t[(size_t)t]); });
+        tail = base + cnt_t[(size_t)threads];
+        // the winners are in the queue: 0 from now on (a loser's key never equals a winner's, so late readers cannot be confused)
+        pool.run([&](int t) {
+            for (int64_t i = base + (tail - base) * t / threads; i < base + (tail - base) * (t + 1) / threads; i++)
+                state[(size_t)queue[(size_t)i]].store(0, std::memory_order_relaxed);
+        });
+        head = l1;
     }
+    pool.quit.store(true);
+    for (std::thread &x : pool.th) x.join();
+    par_ranges(n_nodes, threads, [&](int64_t a, int64_t b) { for (int64_t i = a; i < b; i++) node_index_out[queue[(size_t)i]] = (int32_t)i; });
+    lap("breadth-first walk");
     if (node_dof_out)
         par_ranges(n_nodes, threads, [&](int64_t a, int64_t b) {
             for (int64_t i = a; i < b; i++) {  // Node.SetDOF, Node.cs:218-223

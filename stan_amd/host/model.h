@@ -17,8 +17,11 @@
 // order drives AssignDOF and the element order.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
+#include <cstring>
 #include <functional>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -61,10 +64,59 @@ class FlatIndex {
         return true;
     }
     void Clear() { slots_.clear(); count_ = 0; }
+    // Round 5: a whole library at once on `threads` threads (6.5 M keys at 148^3: the serial build was a fifth of the
+    // file's read time).  Every key takes a slot of the linear-probing table with a compare-and-swap on the 8-byte slot;
+    // a key that is already there keeps the SMALLER position (the first entry in wire order, whichever thread came
+    // first).  Returns the number of distinct keys; Get works as after the serial build (probe sequences are the same
+    // sets of slots, lookups never depend on insertion order).
+    template <typename KeyAt>
+    size_t BuildParallel(size_t n, int threads, KeyAt key_at) {
+        Clear();
+        Reserve(n);
+        if (slots_.empty()) return 0;
+        std::atomic<size_t> distinct{0};
+        const size_t mask = slots_.size() - 1;
+        unsigned long long *raw = reinterpret_cast<unsigned long long *>(slots_.data());
+        auto pack = [](int key, uint32_t pos) { Slot s{key, pos}; unsigned long long v; memcpy(&v, &s, 8); return v; };
+        const unsigned long long empty = pack(0, EMPTY);
+        auto work = [&](size_t a, size_t b) {
+            size_t mine = 0;
+            for (size_t i = a; i < b; i++) {
+                const int key = key_at(i);
+                for (size_t h = Hash(key);; h = (h + 1) & mask) {
+                    unsigned long long cur = __atomic_load_n(raw + h, __ATOMIC_RELAXED);
+                    Slot cs; memcpy(&cs, &cur, 8);
+                    if (cs.pos == EMPTY) {
+                        unsigned long long expect = empty;
+                        if (__atomic_compare_exchange_n(raw + h, &expect, pack(key, (uint32_t)i), false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { mine++; break; }
+                        cur = expect; memcpy(&cs, &cur, 8);   // somebody took the slot: look at what is there now
+                    }
+                    if (cs.key == key) {   // a repeated key: the smaller position stays
+                        while (cs.pos > (uint32_t)i) {
+                            unsigned long long expect = cur;
+                            if (__atomic_compare_exchange_n(raw + h, &expect, pack(key, (uint32_t)i), false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
+                            cur = expect; memcpy(&cs, &cur, 8);
+                        }
+                        break;
+                    }
+                }
+            }
+            distinct.fetch_add(mine);
+        };
+        if (threads <= 1 || n < 65536) work(0, n);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 1; t < threads; t++) th.emplace_back(work, n * (size_t)t / (size_t)threads, n * (size_t)(t + 1) / (size_t)threads);
+            work(0, n / (size_t)threads);
+            for (std::thread &x : th) x.join();
+        }
+        count_ = distinct.load();
+        return count_;
+    }
 
   private:
     static constexpr uint32_t EMPTY = 0xffffffffu;
-    struct Slot { int key; uint32_t pos; };
+    struct alignas(8) Slot { int key; uint32_t pos; };
     size_t Hash(int key) const { return (size_t)(((uint64_t)(uint32_t)key * 0x9E3779B97F4A7C15ull) >> shift_); }
     void Put(int key, uint32_t pos) {
         const size_t mask = slots_.size() - 1;
@@ -87,8 +139,12 @@ class OrderedDict {  // Dictionary<int, T> with insertion-order enumeration
     }
     // A whole library at once (the parallel STdb reader decodes the entries first): wire order is kept, a
     // repeated key keeps its first entry, like Add.
-    void Adopt(std::vector<std::pair<int, T>> &&items) {
+    void Adopt(std::vector<std::pair<int, T>> &&items, int threads = 1) {
         items_ = std::move(items);
+        if (threads > 1 && items_.size() >= 65536) {   // the index on the host threads; no repeated key (any sane file): done
+            const std::vector<std::pair<int, T>> &it = items_;
+            if (index_.BuildParallel(it.size(), threads, [&it](size_t i) { return it[i].first; }) == it.size()) return;
+        }
         index_.Clear();
         index_.Reserve(items_.size());
         size_t w = 0;

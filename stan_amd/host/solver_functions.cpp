@@ -76,6 +76,7 @@ void SolverFunctions::ParallelAssembly_K(const Database &DB, const std::vector<i
         if (rc_init) throw std::runtime_error(stan_hip_last_error(nullptr));
     }
     stan_hip_set_option(K->ctx, STAN_OPT_CG_MERIT_STOP, opt_.merit_stop ? 1 : 0);
+    stan_hip_set_option(K->ctx, STAN_OPT_POOL_MAX_BYTES, -1);   // this process owns its device(s)
     stan_hip_set_option(K->ctx, STAN_OPT_PLACEMENT_TRIES, opt_.placement_tries < 1 ? 1 : opt_.placement_tries);
     if (opt_.p2p && stan_hip_set_option(K->ctx, STAN_OPT_COMM_P2P, 1)) throw std::runtime_error(stan_hip_last_error(K->ctx));
     if (opt_.profile) stan_hip_set_profiling(K->ctx, 1);

@@ -18,6 +18,7 @@
 // the serial writer (tests/test_stdb_pin.py, tests/test_stdb.py).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -437,10 +438,13 @@ void SerializeStdb(const Database &db, bool packed, std::string *out) {
 }
 
 namespace {
-// Where the encoded chunks go.  pwrite: fine for small files, but buffered writes to ONE file take the inode's lock one at a
-// time, whatever the number of threads (measured: 6.4 GB in 1.2-1.3 s with 1 or 16 writers).  map: the file is given an
-// upper-bound length, mapped shared, the chunks are copied into the mapping by the threads that encoded them (their page
-// faults fill the page cache in parallel) and the file is cut to its true length at the end.
+// Where the encoded chunks go.  pwrite (default): every chunk at its own offset by the thread that encoded it.  Buffered
+// writes to ONE file take the inode's lock one at a time whatever the number of threads, so the export of a large model
+// runs at what one writer reaches (measured at 148^3: 6.4 GB in 1.17-1.33 s with 1 or 16 writers, 5.4 GB/s) -- the
+// encoding is hidden behind it.  map (STAN_STDB_WRITE=map, kept for file systems where it pays): the file gets an
+// upper-bound length, is mapped shared, the chunks are copied into the mapping (page faults instead of write calls) and
+// the file is cut to its true length at the end.  On the GPU boxes of round 5 that was SLOWER: 2.5-3.8 s for the same 6.4 GB
+// (a write fault per 4-KB page through the file system; profiles/r05/console_driver_148.md).
 struct Sink {
     int fd = -1;
     char *map = nullptr;
@@ -563,12 +567,10 @@ bool WriteStdb(const Database &db, const std::string &path, bool packed, std::st
     }
     Sink sink;
     sink.fd = fd;
-    // large files go through a shared mapping (see Sink) when the file system has room for the bound; STAN_STDB_WRITE=pwrite
-    // keeps the write calls, =map maps whatever the size
-    const size_t bound = max_lib_size(db.NodeLib.Items(), rv, threads) + max_lib_size(db.ElemLib.Items(), rv, threads) + tail.size() + 4096;
+    // STAN_STDB_WRITE=map: through a shared mapping (see Sink) when the file system has room for the bound
     const char *mode = getenv("STAN_STDB_WRITE");
-    const bool force_map = mode && !strcmp(mode, "map");   // (tests: the mapping path on a small file)
-    if ((bound >= ((size_t)64 << 20) || force_map) && !(mode && !strcmp(mode, "pwrite"))) {
+    if (mode && !strcmp(mode, "map")) {
+        const size_t bound = max_lib_size(db.NodeLib.Items(), rv, threads) + max_lib_size(db.ElemLib.Items(), rv, threads) + tail.size() + 4096;
         struct statvfs vfs;
         const bool room = fstatvfs(fd, &vfs) == 0 && (double)vfs.f_bavail * (double)vfs.f_frsize > 1.05 * (double)bound;
         if (room && ftruncate(fd, (off_t)bound) == 0) {
@@ -614,12 +616,19 @@ bool dec_lib_parallel(const std::vector<Span> &spans, OrderedDict<T> &lib, int t
     if (threads <= 1 || spans.size() < 4 * CHUNK) work(0);
     else run_threads(threads, work);
     if (first_bad.load() != (size_t)-1) { *bad = first_bad.load(); return false; }
-    lib.Adopt(std::move(items));
+    lib.Adopt(std::move(items), threads);
     return true;
 }
 }  // namespace
 
 bool ParseStdb(const uint8_t *data, size_t size, Database *db, std::string *err) {
+    const bool trace = getenv("STAN_HOST_TRACE") != nullptr;   // stage times on stderr (diagnosis)
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = now();
+    auto lap = [&](const char *what) {
+        if (trace) fprintf(stderr, "[stan host] ParseStdb %-28s %.3f s\n", what, std::chrono::duration<double>(now() - t0).count());
+        t0 = now();
+    };
     *db = Database();
     db->has_analysis = false;  // SkipConstructor: members absent from the wire stay null
     db->has_info = false;
@@ -638,11 +647,14 @@ bool ParseStdb(const uint8_t *data, size_t size, Database *db, std::string *err)
     END_FIELDS(r)
     const uint8_t *where = r.p;
     bool ok = r.ok;
+    lap("top-level scan");
     // pass 2: the entries, in parallel (a repeated key keeps its first entry: OrderedDict::Adopt)
     const int threads = HostThreads();
     size_t bad = 0;
     if (ok && !dec_lib_parallel(lib[0], db->NodeLib, threads, &bad)) { ok = false; where = lib[0][bad].p; }
+    lap("nodes: decode + index");
     if (ok && !dec_lib_parallel(lib[1], db->ElemLib, threads, &bad)) { ok = false; where = lib[1][bad].p; }
+    lap("elements: decode + index");
     if (ok && !dec_lib_parallel(lib[2], db->MatLib, 1, &bad)) { ok = false; where = lib[2][bad].p; }
     if (ok && !dec_lib_parallel(lib[3], db->BCLib, 1, &bad)) { ok = false; where = lib[3][bad].p; }
     if (!ok && err) *err = "malformed STdb (protobuf wire error near byte " +
@@ -659,7 +671,7 @@ bool ReadStdb(const std::string &path, Database *db, std::string *err) {
     if (fstat(fd, &sb) != 0) { close(fd); if (err) *err = "cannot read " + path; return false; }
     const size_t n = (size_t)sb.st_size;
     if (n == 0) { close(fd); return ParseStdb(nullptr, 0, db, err); }
-    void *map = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    void *map = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);   // (populate: no minor fault per page in the decoding threads)
     if (map == MAP_FAILED) {   // a file system without mmap: read it
         std::string buf(n, '\0');
         size_t got = 0;

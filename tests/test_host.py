@@ -149,3 +149,28 @@ def test_partition_elements_matches_brute_force(built_libs):
             assert np.array_equal(got, want.astype(np.int32))
             seen[got] += 1
         assert seen.min() >= 1 and (nranks == 1) == (seen.max() == 1)
+
+
+def test_level_parallel_walk_gives_the_serial_numbering(built_libs, monkeypatch):
+    """Round 5: AssignDOF's breadth-first walk scans wide levels on the host threads (claims by atomic minimum of
+    (position in the level, offset in the scan): dof.cpp).  Database.cs:140-234's numbering is an ORDER, so the parallel
+    form must reproduce the serial one exactly: cube, perforated box, a solid of revolution with a high-valence axis and
+    forty fuzz meshes, every level forced through the threads (STAN_HOST_BFS_PAR_MIN=1) and with the default threshold."""
+    from stan_amd.cube import cube_mesh, perforated_mesh, revolved_mesh
+    from tests import fuzz
+    meshes = {"cube": cube_mesh(24), "perforated": perforated_mesh(20, 0.4), "revolved": revolved_mesh(24, 6, 5)}
+    for seed in range(100, 140):
+        job = fuzz.random_job(seed)
+        if job is not None:
+            meshes["fuzz%d" % seed] = (job.xyz, job.conn)
+    res = {}
+    for tag, env in (("serial", {"STAN_HOST_THREADS": "1"}), ("forced", {"STAN_HOST_THREADS": "7", "STAN_HOST_BFS_PAR_MIN": "1"}),
+                     ("default", {"STAN_HOST_THREADS": "8"})):
+        with monkeypatch.context() as m:
+            m.delenv("STAN_HOST_BFS_PAR_MIN", raising=False)
+            for k, v in env.items():
+                m.setenv(k, v)
+            res[tag] = {name: host.assign_dof(xyz.shape[0], conn)[0] for name, (xyz, conn) in meshes.items()}
+    for name in meshes:
+        assert np.array_equal(res["serial"][name], res["forced"][name]), name
+        assert np.array_equal(res["serial"][name], res["default"][name]), name

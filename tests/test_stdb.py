@@ -280,3 +280,42 @@ for packed in (False, True):
         out[mode] = {k: open(base + k, "rb").read() for k in ("_plain_0", "_plain_1", "_res_0", "_res_1")}
     for k in out["map"]:
         assert len(out["map"][k]) > 10000 and out["map"][k] == out["pwrite"][k], k
+
+
+def test_repeated_key_keeps_its_first_entry_also_on_the_parallel_index_build(built_libs, tmp_path):
+    """Dictionary semantics of the libraries (OrderedDict::Adopt): a key that appears twice on the wire keeps its FIRST
+    entry, position and all.  Round 5 builds the key index of a large library on the host threads (compare-and-swap
+    insertion, the smaller position wins); 42^3 = 79 507 nodes is above the threshold of that path."""
+    import struct
+    n = 42
+    xyz, conn = cube_mesh(n)
+    d = host.Db()
+    ne = conn.shape[0]
+    d.set_mesh(np.arange(1, xyz.shape[0] + 1), xyz, np.arange(1, ne + 1), np.ones(ne), conn + 1, "HEX8_G2")
+    d.add_material(1, "Steel", 210000.0, 0.3); d.assign_part(1, 1, "HEX8_G2")
+    d.set_analysis(tol=1e-6)
+    path = str(tmp_path / "m.STdb")
+    d.write_stdb(path)
+    base = open(path, "rb").read()
+
+    def node_entry(key, x):       # Database field 1: map entry {1: key, 2: Node{1: ID, 2: X}}
+        node = b"\x08" + bytes([key]) + b"\x11" + struct.pack("<d", x) + b"\x30\x00\x30\x01\x30\x02"    # + DOF = [0, 1, 2]
+        entry = b"\x08" + bytes([key]) + b"\x12" + bytes([len(node)]) + node
+        return b"\x0a" + bytes([len(entry)]) + entry
+    os.environ["STAN_HOST_THREADS"] = "4"
+    try:
+        late = host.Db.parse_stdb(base + node_entry(5, 777.0))      # the repeat comes last: dropped
+        early = host.Db.parse_stdb(node_entry(5, 777.0) + base)     # the repeat comes first: it is the entry
+    finally:
+        del os.environ["STAN_HOST_THREADS"]
+    ref = host.Db.parse_stdb(base)
+    nn = xyz.shape[0]
+    assert ref.sizes()["nodes"] == late.sizes()["nodes"] == early.sizes()["nodes"] == nn
+    fr, fl, fe = ref.flat(), late.flat(), early.flat()
+    assert np.array_equal(fl["node_ids"], fr["node_ids"]) and np.array_equal(fl["xyz"], fr["xyz"])
+    assert fe["node_ids"][0] == 5 and fe["xyz"][0, 0] == 777.0 and fe["xyz"][0, 1] == 0.0
+    assert np.array_equal(np.delete(fe["node_ids"], 0), np.delete(fr["node_ids"], 4))
+    # lookups go through the index either way: AssignDOF resolves 8 node IDs per element
+    late.assign_dof()
+    ref.assign_dof()
+    assert np.array_equal(late.flat()["node_dof"], ref.flat()["node_dof"])

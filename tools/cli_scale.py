@@ -26,7 +26,7 @@ d.write_stdb(path)
 print("model %d^3 written: %.1f MB in %.1f s" % (n, os.path.getsize(path) / 1e6, time.time() - t0))
 t0 = time.time()
 out = subprocess.run([os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "stan_amd", "bin", "stan_solver"), "--json"] + sys.argv[3:] + [path], capture_output=True, text=True)
-print(out.stdout[-900:], out.stderr[-300:])
+print(out.stdout[-900:], out.stderr[-3000:])
 print("stan_solver wall %.1f s, result file %.1f MB" % (time.time() - t0, os.path.getsize(path) / 1e6))
 r = host.Db.read_stdb(path)
 disp, e, s = r.results(1)
