@@ -61,10 +61,17 @@ def test_device_memory_does_not_grow_over_many_jobs():
     one_life()                                      # whatever the runtime keeps for itself is taken here
     one_life()
     before = free_mb()
-    for _ in range(40):
+    marks_l = []
+    for i in range(40):
         one_life()
-    after = free_mb()
-    assert before - after < 8, "40 context lives cost %.1f MB of device memory" % (before - after)
+        if i in (9, 39):
+            marks_l.append(free_mb())
+    after = marks_l[1]
+    print("free device memory: before %.1f MB, after 10 lives %.1f, after 40 lives %.1f" % (before, marks_l[0], after))
+    # a leak grows with the lives: 30 more lives must not cost anything (the first few may still settle the driver's own
+    # sub-allocators, whose state depends on what ran in this process before: seen as 22 MB once, in a full-suite run)
+    assert marks_l[0] - after < 8, "lives 11 -> 40 cost %.1f MB of device memory" % (marks_l[0] - after)
+    assert before - after < 64, "40 context lives cost %.1f MB of device memory" % (before - after)
 
     ctx = hip.Context(0)
     marks = []
