@@ -25,7 +25,7 @@ namespace {
 // elements of a wave); the node extrapolation value_i = sum_g N[i][g] value_g uses the tensor structure of
 // N[i][g] = prod_axis 1/2 (1 + s_i s_g sqrt 3) -- three butterfly stages (x: lane ^ 1, y: lane ^ 3, z: lane ^ 4 in CHEXA
 // order) instead of an 8-term sum of shuffles; the results leave through LDS as full 512-B lines.
-constexpr int REC = 49;   // doubles per element record in LDS (48 + 1: records of the 8 elements of a wave start in different banks)
+constexpr int REC = 50;   // doubles per element record in LDS (48 + 2: the 8 records of a wave start 36 banks apart -- no conflicts between them, and a record stays 16-B aligned: the reads pair up into ds_read_b128)
 
 template <bool FORCES>
 __global__ void __launch_bounds__(256)
@@ -33,7 +33,7 @@ k_recover(int64_t n_elem, const double *__restrict__ xyz, const double *__restri
           const int32_t *__restrict__ elem_mat, const uint8_t *__restrict__ elem_type, const double *__restrict__ mat_lamG,
           double *__restrict__ strain, double *__restrict__ stress, long long *bad_elem, long long *g1_elem,
           const int32_t *__restrict__ node_dof, double *__restrict__ elem_forces, double *R) {
-    __shared__ double lds[4][8 * REC];
+    __shared__ __attribute__((aligned(16))) double lds[4][8 * REC];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int el = lane >> 3, g = lane & 7;
     const int64_t e0 = ((int64_t)blockIdx.x * 4 + wv) * 8;   // first element of this wave

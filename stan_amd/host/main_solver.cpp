@@ -147,7 +147,9 @@ int main(int argc, char **argv) {
         t0 = clk::now();
         const std::vector<double> Ufull = Functions.Include_BC_DOF(U, nDOF_reduction);
         std::vector<double> disp((size_t)n_nodes * 3);
-        for (size_t k = 0; k < disp.size(); k++) disp[k] = Ufull[(size_t)K.flat.node_dof[k]];
+        parallel_ranges(disp.size(), [&](size_t a, size_t b) {
+            for (size_t k = a; k < b; k++) disp[k] = Ufull[(size_t)K.flat.node_dof[k]];
+        });
         t_disp = secs(t0);
 
         printf("   Stress recovery: ");  // Solver.cs:183

@@ -24,6 +24,12 @@ rm -rf $OUT/trace
 bash tools/pmc_run.sh gpurun_out/r05_$T/pmc --no-secondary > $OUT/pmc_fetch_write_n148.txt 2>&1
 grep -E "k_numeric|k_spmv<|k_spmv2|k_update|k_step" $OUT/pmc_fetch_write_n148.txt | head
 rm -rf $OUT/pmc/FETCH_SIZE $OUT/pmc/WRITE_SIZE
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/recover_trace -o run -- python3 $R/tools/recover_time.py 148 10 > $OUT/recover_time_n148.json 2> $OUT/recover_trace.err
+cd $R
+python3 tools/trace_summary.py $OUT/recover_trace/run_kernel_trace.csv > $OUT/k_recover_n148_kernel_trace_summary.txt 2>&1
+rm -rf $OUT/recover_trace
+for i in a b; do timeout 600 python3 tools/cli_scale.py 148 > $OUT/cli_scale_n148_$i.txt 2>&1; done
 export STAN_RCCL_LIB=$R/tests/fake_rccl/libfake_rccl.so STAN_BENCH_BACKEND=gloo STAN_BENCH_DEVICE=0 GPU_MAX_HW_QUEUES=20
 timeout 900 python3 bench.py --gpus 2 --steps 1 --warmup 1 --no-cpu > $OUT/bench_gpus2_dry_run_on_one_gpu.json 2> $OUT/bench_gpus2.err
 timeout 1200 python3 bench.py --gpus 8 --steps 1 --warmup 1 --no-cpu > $OUT/bench_gpus8_dry_run_on_one_gpu.json 2> $OUT/bench_gpus8.err
