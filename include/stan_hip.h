@@ -110,6 +110,7 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
  *   18 STAN_OPT_COMM_P2P             0     sharded CG exchanges peer to peer instead of over RCCL
  *   19 STAN_OPT_ROW_FOLDING          -1    folded rows on irregular meshes (auto)
  *   20 STAN_OPT_CG_REFINE            1     reduced-precision streams: 0 fp64 check only, 1 + refinement passes, 2 + fp64 refresh
+ *   21 STAN_OPT_CG_LAZY_SCALING      1     the loop's first product brings K into its Jacobi-scaled form (no pass of its own)
  * The descriptions follow in the order the options were added.
  *   STAN_OPT_CG_MERIT_STOP  1 (default): stop with type 7 when the merit function x'Ax-2b'x
  *                           no longer decreases (rounding floor, ~1e-7 relative residual on
@@ -250,6 +251,12 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
                            four orders above eps, and a restarted or re-anchored CG pays for it in iterations.  FIXED-48
                            (absolute entry error 7e-15) passes its check at once: 1333 iterations, 1.27 s -- that is the
                            reduced-byte mode that keeps the answer. */
+#define STAN_OPT_CG_LAZY_SCALING 21 /* 1 (default): alglib's lincg iterates on S K S; the fp64 loop of a single rank lets its
+                           FIRST product multiply every block by s_row s_col on the way, write it back and go on with the scaled
+                           block (k_spmv_first) instead of a scaling pass of its own before the first iteration (6.4 GB read +
+                           6.4 GB written, 2.7 ms at 148^3).  Same expression: the stored values and every result keep their
+                           bits.  0: the separate pass, which every other case keeps anyway (several ranks, the reduced-precision
+                           streams, the small-system kernel, a folded copy, an export before the first solve). */
 #define STAN_OPT_POOL 7 /* 1 (default): device blocks >= 8 MB freed by the library stay with the
                            context and are reused by its next allocations (a hipMalloc of tens of GB
                            costs 0.4-1.8 s here); 0: release them now, plain hipMalloc/hipFree from then on */

@@ -87,7 +87,7 @@ namespace STAN_Solver
                            STAN_OPT_CG_SINGLE_REDUCE = 10, STAN_OPT_CG_FOLD_REDUCE = 11, STAN_OPT_VEC_STORE_NT = 12,
                            STAN_OPT_PACKED_COLUMNS = 13, STAN_OPT_CG_DEFER_X = 14, STAN_OPT_SPMV_SMALL = 15,
                            STAN_OPT_PLACEMENT_MAX_BYTES = 16, STAN_OPT_SELL_SIGMA = 17, STAN_OPT_COMM_P2P = 18,
-                           STAN_OPT_ROW_FOLDING = 19, STAN_OPT_CG_REFINE = 20;
+                           STAN_OPT_ROW_FOLDING = 19, STAN_OPT_CG_REFINE = 20, STAN_OPT_CG_LAZY_SCALING = 21;
 
         // ---- context
         [DllImport(Lib)] internal static extern int stan_hip_init(int device, out IntPtr ctx);

@@ -122,6 +122,7 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
     else if (option == STAN_OPT_CG_SINGLE_REDUCE) ctx->cg_single_reduce = value != 0;
     else if (option == STAN_OPT_CG_FOLD_REDUCE) ctx->cg_fold_reduce = value != 0;
     else if (option == STAN_OPT_CG_REFINE && value >= 0 && value <= 2) ctx->cg_refine = (int)value;
+    else if (option == STAN_OPT_CG_LAZY_SCALING) ctx->cg_lazy_scaling = value != 0;
     else if (option == STAN_OPT_VEC_STORE_NT && value >= 0 && value <= 3) ctx->vec_store_nt = (int)value;
     else if (option == STAN_OPT_PACKED_COLUMNS) ctx->cols16 = value != 0;
     else if (option == STAN_OPT_CG_DEFER_X) ctx->cg_defer_x = value != 0;

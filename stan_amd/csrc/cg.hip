@@ -434,9 +434,10 @@ void stan_cg_products_adopt(stan_ctx *ctx, double *block, size_t bytes, double *
     saved[0] = saved[1] = saved[2] = nullptr;
 }
 
-// Diagonal scaling of the matrix (once per matrix): A^ = S K S.
-static int ensure_scaled(stan_ctx *ctx, stan_matrix *K) {
-    if (K->scaled) return STAN_OK;
+// Diagonal scaling of the matrix (once per matrix): A^ = S K S.  First the vector s (ensure_scale_vector), then the values:
+// by a pass of its own (ensure_scaled), or -- the fp64 loop on one rank -- by the loop's first product (k_spmv_first,
+// cg_run::iterate), which marks the matrix scaled itself.
+static int ensure_scale_vector(stan_ctx *ctx, stan_matrix *K) {
     const int64_t npad = (int64_t)K->nslices * 64;
     const int64_t ns = 3 * (npad + K->nhalo);
     if (!K->d_scale) STANCHK(stan_dmalloc(ctx, &K->d_scale, (size_t)ns));
@@ -458,10 +459,11 @@ static int ensure_scaled(stan_ctx *ctx, stan_matrix *K) {
         }
         STANCHK(stan_comm_halo_exchange(ctx, K, K->d_scale));
     }
-    if (K->nslices > 0)
-        hipLaunchKernelGGL(k_scale_matrix, dim3(nblk(K->nslices, 4)), dim3(256), 0, ctx->stream,
-                           K->nslices, K->d_slot_ptr, K->d_rowof, K->d_cols, K->d_vals, K->d_scale, 0);
     HIPCHK(ctx, hipGetLastError());
+    return STAN_OK;
+}
+// what changes for the rest of the library once the values carry S K S
+static void mark_scaled(stan_ctx *ctx, stan_matrix *K) {
     K->scaled = true;
     // copies of the value stream made before the scaling (stan_hip_spmv_bench on a fresh matrix)
     // hold the unscaled K: a later solve must not iterate on them
@@ -469,6 +471,15 @@ static int ensure_scaled(stan_ctx *ctx, stan_matrix *K) {
     if (K->d_vals48) { stan_dfree(ctx, K->d_vals48); K->d_vals48 = nullptr; }
     stan_matrix_drop_folded_values(ctx, K);
     K->fx48_refused = false;
+}
+static int ensure_scaled(stan_ctx *ctx, stan_matrix *K) {
+    if (K->scaled) return STAN_OK;
+    STANCHK(ensure_scale_vector(ctx, K));
+    if (K->nslices > 0)
+        hipLaunchKernelGGL(k_scale_matrix, dim3(nblk(K->nslices, 4)), dim3(256), 0, ctx->stream,
+                           K->nslices, K->d_slot_ptr, K->d_rowof, K->d_cols, K->d_vals, K->d_scale, 0);
+    HIPCHK(ctx, hipGetLastError());
+    mark_scaled(ctx, K);
     return STAN_OK;
 }
 
@@ -623,6 +634,7 @@ struct cg_run {
     bool dist = false, p2p = false, sr = false, foldr = false, split = false;
     int vs = STAN_PREC_FP64;          // the stream the loop's products read on THIS rank (FIXED-48 falls back to fp64 on a rank that owns no
                                       // rows or whose shard is not representable: never a base for decisions the ranks must share)
+    bool lazy_scale = false;          // the values are still K: the loop's first product scales them (k_spmv_first)
     bool reduced = false;             // the caller asked for a reduced-precision stream: fp64 check + refinement (every rank alike)
     int refine = 0;                   // STAN_OPT_CG_REFINE, reduced-precision modes only
     int64_t n3 = 0, npad = 0, ng = 0, dof0 = 0;
@@ -709,8 +721,19 @@ struct cg_run {
             else { spmv64_ev.push_back(a); spmv64_ev.push_back(b); }
         }
         auto go = [&](int which, hipStream_t s, bool last) -> unsigned {
-            const fold_args f = (dot && last) ? fold_to(0, out, po) : NO_FOLD;
+            fold_args f = (dot && last) ? fold_to(0, out, po) : NO_FOLD;
             n_launch++;
+            if (lazy_scale) {   // the first product of this matrix (one rank, fp64 stream, all slices): scale on the way
+                lazy_scale = false;
+                const unsigned grid = nblk(K->nslices, 4);
+                f.nblocks = grid; f.np = (int)grid;
+                const colstream cs = ctx->cols16 && K->d_cols16 ? make_colstream(K->d_cols16, K->d_colbase, K->d_pair_ptr, K->d_slice_packed, K->nslots) : NO_COLSTREAM;
+                if (dot == 2) hipLaunchKernelGGL(k_spmv_first<2>, dim3(grid), dim3(256), 0, s, K->nslices, K->nloc, K->d_slot_ptr, K->d_rowof, K->d_cols, K->d_vals, K->d_scale, x, y, partial, stt, k, f, cs);
+                else if (dot == 1) hipLaunchKernelGGL(k_spmv_first<1>, dim3(grid), dim3(256), 0, s, K->nslices, K->nloc, K->d_slot_ptr, K->d_rowof, K->d_cols, K->d_vals, K->d_scale, x, y, partial, stt, k, f, cs);
+                else hipLaunchKernelGGL(k_spmv_first<0>, dim3(grid), dim3(256), 0, s, K->nslices, K->nloc, K->d_slot_ptr, K->d_rowof, K->d_cols, K->d_vals, K->d_scale, x, y, partial, stt, k, f, cs);
+                mark_scaled(ctx, K);
+                return grid;
+            }
             return dot == 2 ? launch_spmv_any<2>(ctx, K, kind, x, y, partial, stt, k, which, s, f)
                  : dot == 1 ? launch_spmv_any<1>(ctx, K, kind, x, y, partial, stt, k, which, s, f)
                             : launch_spmv_any<0>(ctx, K, kind, x, y, partial, stt, k, which, s, f);
@@ -818,7 +841,19 @@ int cg_run::setup() {
         double *const pub[5] = {ctx->ws.xb[0], ctx->ws.xb[1], ctx->ws.p, ctx->ws.r, K->d_scale};
         STANCHK(stan_p2p_publish_vectors(ctx, K, pub));
     }
-    STANCHK(ensure_scaled(ctx, K));
+    // The first product of the loop may scale the matrix on its way (k_spmv_first) instead of a pass of its own: the fp64
+    // stream of one rank, the large-system kernel in its default variant, no folded copy (its values are made from the
+    // scaled ones), a first product that is a plain one (a residual refresh at iteration 1 is a two-product pass).
+    lazy_scale = false;
+    if (!K->scaled && ctx->cg_lazy_scaling && !(ctx->comm != nullptr || ctx->nranks > 1) && precision_mode == STAN_PREC_FP64 &&
+        !stan_small_system(ctx, K) && ctx->spmv_variant < 0 && ctx->cg_rupdate != 1 && K->nslices > 0) {
+        const int rc_plan = stan_matrix_make_folded(ctx, K, STAN_PREC_FP64, true);   // (decides K->fold_state, touches no value)
+        if (rc_plan == STAN_E_ALLOC) { stan_matrix_abandon_folding(ctx, K); ctx->err.clear(); }
+        else STANCHK(rc_plan);
+        lazy_scale = ctx->row_folding == 0 || K->fold_state != 1;
+    }
+    if (lazy_scale) STANCHK(ensure_scale_vector(ctx, K));
+    else STANCHK(ensure_scaled(ctx, K));
     if (ctx->cols16) STANCHK(stan_matrix_make_cols16(ctx, K));
     if (precision_mode == STAN_PREC_MIXED) STANCHK(stan_matrix_make_fp32(ctx, K));
     if (precision_mode == STAN_PREC_FIXED48) STANCHK(stan_matrix_make_fx48(ctx, K));

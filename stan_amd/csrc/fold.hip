@@ -121,7 +121,7 @@ void stan_matrix_abandon_folding(stan_ctx *ctx, stan_matrix *K) {
 // Folded copies of the column stream and of the value stream `stream_kind`, built when STAN_OPT_ROW_FOLDING asks
 // for them (1: always; -1, the default: when the plan saves more than 5 % of the slots).  The padded streams stay: scaling,
 // export and the placement search work on them.
-int stan_matrix_make_folded(stan_ctx *ctx, stan_matrix *K, int32_t stream_kind) {
+int stan_matrix_make_folded(stan_ctx *ctx, stan_matrix *K, int32_t stream_kind, bool plan_only) {
     // -2 = declined by the AUTO threshold only: STAN_OPT_ROW_FOLDING = 1 ("always") set afterwards examines the matrix again
     if (K->fold_state == -2 && ctx->row_folding == 1) K->fold_state = 0;
     if (ctx->row_folding == 0 || K->fold_state < 0 || K->nslots <= 0 || K->nslices <= 0) return STAN_OK;
@@ -162,6 +162,7 @@ int stan_matrix_make_folded(stan_ctx *ctx, stan_matrix *K, int32_t stream_kind) 
         STANCHK(stan_dmalloc(ctx, &K->d_fold_cols, (size_t)(K->nfslots > 0 ? K->nfslots : 1) * 64));
         K->fold_state = 1;
     }
+    if (plan_only) return STAN_OK;   // the caller only wants K->fold_state decided (cg.hip: may the first product scale the matrix?)
     const size_t n = (size_t)(K->nfslots > 0 ? K->nfslots : 1) * 64;
     if (!K->fold_cols_filled) {
         // the columns first (k_fold_fill without values), then their packed stream (16-bit offsets from a per-slot

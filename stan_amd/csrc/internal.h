@@ -236,6 +236,7 @@ struct stan_ctx {
     bool cols16 = true;            // SpMV reads the packed column stream where a slice allows it
     int vec_store_nt = 3;          // bit 0: p (k_update), bit 1: r (k_step) leave through non-temporal stores
     bool cg_fold_reduce = true;    // reductions finished by the producing kernel's last block
+    bool cg_lazy_scaling = true;   // STAN_OPT_CG_LAZY_SCALING: the first product of the loop brings K into its scaled form (k_spmv_first)
     int cg_refine = 1;             // STAN_OPT_CG_REFINE: reduced-precision streams -- 0 fp64 check only, 1 + refinement passes, 2 + fp64 refresh products
     bool overlap_halo = true;  // interior SpMV on a side stream while the halo is exchanged
     hipStream_t side = nullptr;
@@ -364,7 +365,7 @@ int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode
 int stan_spmv_local(stan_ctx *ctx, stan_matrix *K, const double *d_x, double *d_y);
 int stan_matrix_make_fp32(stan_ctx *ctx, stan_matrix *K);
 // ---- fold.hip -------------------------------------------------------------------------------
-int stan_matrix_make_folded(stan_ctx *ctx, stan_matrix *K, int32_t stream_kind);
+int stan_matrix_make_folded(stan_ctx *ctx, stan_matrix *K, int32_t stream_kind, bool plan_only = false);
 void stan_matrix_drop_folded_values(stan_ctx *ctx, stan_matrix *K);
 void stan_matrix_abandon_folding(stan_ctx *ctx, stan_matrix *K);
 int stan_matrix_make_fx48(stan_ctx *ctx, stan_matrix *K);

@@ -33,6 +33,7 @@ OPT_SELL_SIGMA = 17
 OPT_COMM_P2P = 18
 OPT_ROW_FOLDING = 19
 OPT_CG_REFINE = 20
+OPT_CG_LAZY_SCALING = 21
 E_HIP, E_ARG, E_ALLOC, E_DETJ, E_DOF_LAYOUT, E_VALENCE, E_COMM, E_UNSUPPORTED = (
     -1, -2, -3, -4, -5, -6, -7, -8)
 

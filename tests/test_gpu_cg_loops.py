@@ -244,3 +244,41 @@ def test_bench_mode_against_the_oracle_fixture(gpu_ctx, name, fold):
     assert abs(np.sqrt(U @ U) - float(g["u_l2"])) <= 1e-9 * float(g["u_l2"])
     if name.startswith("p"):
         assert bool(folded) == (fold != 0)
+
+
+@pytest.mark.parametrize("n,single_reduce", [(20, 0), (40, 0), (40, 1)])
+def test_first_product_scales_the_matrix_with_the_bits_of_the_scaling_pass(gpu_ctx, n, single_reduce):
+    """Round 5: the fp64 loop of one rank lets its FIRST product bring K into the Jacobi-scaled form
+    alglib iterates on (k_spmv_first: every block times s_row s_col, written back, then multiplied) instead of a pass of
+    its own (k_scale_matrix).  Same expression, so everything downstream keeps its bits: iterations, residual, U, a second
+    solve on the same matrix, the export -- against STAN_OPT_CG_LAZY_SCALING = 0 on a freshly assembled matrix."""
+    from stan_amd import hip
+    job = problem.cube_job(n, jitter=0.05)
+    args = (job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+    out = {}
+    gpu_ctx.set_option(hip.OPT_CG_MERIT_STOP, 0)
+    gpu_ctx.set_option(hip.OPT_CG_SINGLE_REDUCE, single_reduce)
+    gpu_ctx.set_option(hip.OPT_SPMV_SMALL, 0)          # the large-system kernel at this size too (the small one keeps the pass)
+    try:
+        for lazy in (0, 1):
+            gpu_ctx.set_option(hip.OPT_CG_LAZY_SCALING, lazy)
+            K = gpu_ctx.assemble_hex8(*args)
+            assert K.info()["scaled"] == 0
+            U1, r1 = K.cg_solve(job.F, 1e-9)
+            assert K.info()["scaled"] == 1
+            U2, r2 = K.cg_solve(job.F, 1e-9)           # the matrix is scaled now: the ordinary first product
+            csr = K.to_csr() if n == 20 else None
+            out[lazy] = (U1, r1, U2, r2, csr)
+            K.free()
+    finally:
+        gpu_ctx.set_option(hip.OPT_CG_LAZY_SCALING, 1)
+        gpu_ctx.set_option(hip.OPT_CG_MERIT_STOP, 1)
+        gpu_ctx.set_option(hip.OPT_CG_SINGLE_REDUCE, 0)
+        gpu_ctx.set_option(hip.OPT_SPMV_SMALL, 1)
+    a, b = out[0], out[1]
+    assert a[1] == b[1] and a[3] == b[3] and a[1]["terminationtype"] == 1, (a[1], b[1])
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+    assert np.array_equal(a[0], a[2])                  # and a solve does not depend on who scaled the matrix
+    if a[4] is not None:
+        for x, y in zip(a[4], b[4]):
+            assert np.array_equal(x, y)
