@@ -477,7 +477,7 @@ static int ensure_scaled(stan_ctx *ctx, stan_matrix *K) {
     STANCHK(ensure_scale_vector(ctx, K));
     if (K->nslices > 0)
         hipLaunchKernelGGL(k_scale_matrix, dim3(nblk(K->nslices, 4)), dim3(256), 0, ctx->stream,
-                           K->nslices, K->d_slot_ptr, K->d_rowof, K->d_cols, K->d_vals, K->d_scale, 0);
+                           K->nslices, K->d_slot_ptr, K->d_rowof, K->d_cols, K->d_vals, K->d_scale);
     HIPCHK(ctx, hipGetLastError());
     mark_scaled(ctx, K);
     return STAN_OK;

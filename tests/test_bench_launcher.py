@@ -36,3 +36,39 @@ def test_cpu_at_workload_lookup():
         pytest.skip("no profiles/r*/cpu_at_workload.json yet")
     assert e["unit"] == "DOF/s" and e["cores"] >= 1 and e["kind"] == "port" and e["seconds"] > 60
     assert e["n_dof"] == 9923847 and e["source"].startswith("profiles/")
+
+
+def test_secondary_legs_never_cost_the_headline(monkeypatch):
+    """bench.py's `secondary` legs are child processes behind the measured line: a leg that times out,
+    crashes or raises leaves {"error": ...}; a spent budget skips the rest; a good leg is reduced to its key figures."""
+    import types
+    import bench
+
+    class Dog:
+        def touch(self, *a, **k):
+            pass
+    good = json.loads(open(os.path.join(ROOT, "profiles", "r05", "bench_default_flags_r05_final.json")).read().strip().splitlines()[-1])
+    calls = []
+
+    def fake_child(cmd, timeout, env=None, marker='"metric"'):
+        calls.append((cmd, timeout))
+        if "--size" in cmd and cmd[cmd.index("--size") + 1] == "100":
+            return good, None
+        if "--size" in cmd and cmd[cmd.index("--size") + 1] == "200":
+            return None, "timed out after %.0f s" % timeout
+        if "--fixed48" in cmd:
+            raise RuntimeError("boom")
+        return None, "rc -11, no line; stderr tail: Segmentation fault"
+    monkeypatch.setattr(bench, "_child_json", fake_child)
+    monkeypatch.setattr(bench, "_console_leg", lambda n, timeout: {"error": "no GPU here"})
+    args = types.SimpleNamespace(secondary_budget=240.0)
+    legs = bench.secondary_legs(args, Dog())
+    assert [l["leg"].split(":")[0] for l in legs][:2] == ["config 2", "config 3"] and len(legs) == 5
+    assert legs[0]["value"] == good["value"] and legs[0]["roofline"]["frac"] == good["roofline"]["frac"] and "error" not in legs[0]
+    assert "timed out" in legs[1]["error"] and "boom" in legs[2]["error"] and legs[3]["error"] == "no GPU here"
+    assert "Segmentation fault" in legs[4]["error"]
+    assert all(t <= 150.0 for _, t in calls)
+    # a spent budget: nothing is started any more
+    calls.clear()
+    legs = bench.secondary_legs(types.SimpleNamespace(secondary_budget=-1.0), Dog())
+    assert not calls and all("skipped" in l["error"] for l in legs)
