@@ -1,5 +1,5 @@
 """One PROCESS, several ranks on GPU 0 (stan_hip_init_multi), the CG's exchanges once over the RCCL
-stand-in (tests/fake_rccl) and once PEER TO PEER (STAN_OPT_COMM_P2P): tests/test_gpu_round3.py compares
+stand-in (tests/fake_rccl) and once PEER TO PEER (STAN_OPT_COMM_P2P): tests/test_gpu_transports.py compares
 the bits.  Needs GPU_MAX_HW_QUEUES >= 2 * nranks + 2 in the environment (ranks share the device).
 usage: p2p_worker.py <n | perf:n:frac> <nranks> <out.npz>"""
 import os

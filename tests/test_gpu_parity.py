@@ -648,7 +648,7 @@ def test_unstructured_mesh_parity(gpu_ctx, oracle, k, rings):
 
 
 # (test_valence_limits_are_errors lived here until round 4: the limits it pinned -- 64 incidences, 96 blocks per row --
-#  are gone; tests/test_gpu_round4.py assembles the same jobs and larger ones against the oracle)
+#  are gone; tests/test_gpu_assembly_edge.py assembles the same jobs and larger ones against the oracle)
 
 
 def test_edge_cases_empty_and_fully_fixed(gpu_ctx, oracle):
