@@ -2,7 +2,9 @@
 fold = 1: the products of every job read the FOLDED streams (STAN_OPT_ROW_FOLDING forced on, the small-system kernel
 off: the jobs are tiny), so the sweep exercises fold.hip's plans on a few hundred ragged meshes.
 kind: box (default) | collapsed (box jobs with 5 % of their elements collapsed into wedges) | revolved (solids of revolution
-with collapsed hexes on the axis, 3 ... 160 sectors: the high-valence slow paths).  mode: STAN_OPT_ASSEMBLY_MODE (0 / 1)."""
+with collapsed hexes on the axis, 3 ... 160 sectors: the high-valence slow paths) | round5 (box jobs through the paths round 5
+added, the large-system kernel forced: the first product scaling the matrix against the scaling pass, bit for bit; the fp32
+copy refined against the fp64 answer, its reported residual against an independent one).  mode: STAN_OPT_ASSEMBLY_MODE (0 / 1)."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -21,6 +23,48 @@ if fold:
     ctx.set_profiling(True)
 kind = sys.argv[4] if len(sys.argv) > 4 else "box"
 ctx.set_option(hip.OPT_ASSEMBLY_MODE, int(sys.argv[5]) if len(sys.argv) > 5 else 0)
+if kind == "round5":
+    ctx.set_option(hip.OPT_SPMV_SMALL, 0)
+    ctx.set_option(hip.OPT_CG_MERIT_STOP, 0)
+    ctx.set_profiling(True)
+    n_ok = n_skip = n_refined = 0
+    worst_du = worst_res_gap = 0.0
+    for seed in range(first, first + count):
+        job = fuzz.random_job(seed)
+        if job is None or job.has_g1 or job.n_red == 0 or np.linalg.norm(job.F) == 0:
+            n_skip += 1
+            continue
+        args = (job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+        res = {}
+        for lazy in (0, 1):
+            ctx.set_option(hip.OPT_CG_LAZY_SCALING, lazy)
+            K = ctx.assemble_hex8(*args)
+            U, rep = K.cg_solve(job.F, 1e-9, 20000)
+            res[lazy] = (U, rep, K)
+        assert res[0][1] == res[1][1] and np.array_equal(res[0][0], res[1][0]), (seed, res[0][1], res[1][1])
+        K = res[1][2]
+        res[0][2].free()
+        if res[1][1]["terminationtype"] == 1:       # (a floating sub-structure: K singular, nothing to compare)
+            Um, repm = K.cg_solve(job.F, 1e-9, 60000, precision_mode=hip.PREC_MIXED)
+            pr = ctx.profile()
+            indep = K.scaled_residual(job.F, Um)
+            gap = abs(indep - repm["rel_residual"]) / max(repm["rel_residual"], 1e-300)
+            if repm["rel_residual"] > 1e-12:
+                worst_res_gap = max(worst_res_gap, gap)
+                assert gap <= 0.2, (seed, repm, indep)
+            if repm["terminationtype"] == 1:
+                assert repm["rel_residual"] <= 1e-9, (seed, repm)
+                du = float(np.abs(Um - res[1][0]).max() / np.abs(res[1][0]).max())
+                worst_du = max(worst_du, du)
+                assert du <= 1e-4, (seed, du, repm)        # kappa * 1e-9, two runs
+                n_refined += pr["refine_passes"] > 1
+        K.free()
+        n_ok += 1
+        if seed % 20 == 0:
+            print("seed %d: its %d, mixed %s" % (seed, res[1][1]["iterations"], repm if res[1][1]["terminationtype"] == 1 else "-"), flush=True)
+    print("round5 sweep: %d jobs (lazy scaling == scaling pass bit for bit), %d skipped; fp32 copy: %d needed refinement passes, "
+          "worst |U - U64| / |U64| %.2e, worst reported-vs-independent residual gap %.1e" % (n_ok, n_skip, n_refined, worst_du, worst_res_gap))
+    sys.exit(0)
 folded_jobs = 0
 ok = skipped = 0
 worst = {"k_err": 0.0, "u_err": 0.0, "res": 0.0, "res48": 0.0}
