@@ -72,3 +72,25 @@ def test_secondary_legs_never_cost_the_headline(monkeypatch):
     calls.clear()
     legs = bench.secondary_legs(types.SimpleNamespace(secondary_budget=-1.0), Dog())
     assert not calls and all("skipped" in l["error"] for l in legs)
+
+
+def test_probe_recommendation_goes_by_tolerance_not_by_bits():
+    """with N >= 3 RCCL's summation order is not rank order, the residual bits of the RCCL and the
+    peer-to-peer leg differ after 200 iterations -- that must not stop a faster transport from being recommended."""
+    import bench
+
+    def leg(ms, its=200, res=1.4766136689192024):
+        return {"ms_per_iteration": ms, "iterations": its, "rel_residual": res}
+    legs = {"classic_rccl": leg(0.190), "classic_p2p": leg(0.150, res=1.4766136689192024 * (1 + 3e-13)),
+            "single_reduce_rccl": leg(0.170, res=1.47661344), "single_reduce_p2p": leg(0.160, res=1.47661344)}
+    r = bench.probe_report(legs, 200)
+    assert not r["same_residual_bits_classic"] and all(r["agrees_with_classic_rccl"].values())
+    assert r["fastest"] == "classic_p2p" and r["recommended"].startswith("classic_p2p (STAN_OPT_COMM_P2P=1)")
+    # a leg that is fastest but does not agree (another iteration count) is not recommended
+    legs["classic_p2p"] = leg(0.150, its=199)
+    r = bench.probe_report(legs, 200)
+    assert not r["agrees_with_classic_rccl"]["classic_p2p"] and r["fastest"] == "classic_p2p"
+    assert r["recommended"].startswith("single_reduce_p2p")          # the fastest leg that agrees
+    # nothing is 3 % faster than the defaults: the defaults stay
+    legs = {k: leg(0.190 if k == "classic_rccl" else 0.188) for k in legs}
+    assert bench.probe_report(legs, 200)["recommended"].startswith("classic_rccl (library defaults)")
