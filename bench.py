@@ -648,10 +648,10 @@ def run_probe_children(args, R, dog):
 
 
 # ---- N = 1: the other single-GPU configurations behind the headline, each in a process of its own ----------------------------
-def _child_json(cmd, timeout, env=None, marker='"metric"'):
+def _child_json(cmd, timeout, env=None, marker='"metric"', cwd=None):
     import signal
     import subprocess
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env,
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=cwd or ROOT, env=env,
                             start_new_session=True)
     try:
         out, err = proc.communicate(timeout=timeout)
@@ -723,6 +723,48 @@ def _console_leg(n, timeout):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def _pmc_leg(timeout_each):
+    """HBM-side traffic of the dominant kernel MEASURED BY THIS RUN: two rocprofv3 passes (--pmc FETCH_SIZE, then --pmc
+    WRITE_SIZE: separate passes with --kernel-trace only, as MI355X_MICROARCH.md prescribes) over one step of the headline
+    workload in a child process; per launch over the launches that did work (a launch queued behind a converged solve
+    returns at once: counters below 5 % of the kernel's median), FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    tmp = tempfile.mkdtemp(prefix="stan_pmc_", dir="/tmp")
+    res = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out_dir, "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu", "--no-secondary"]
+            line, why = _child_json(cmd, timeout_each, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
+            if line is None:
+                return {"error": "%s pass: %s" % (counter, why)}
+            vals = []
+            for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == counter and re.search(r"k_spmv<double, 1, 9>", row["Kernel_Name"]):
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return {"error": "%s pass: no k_spmv<double, 1, 9> dispatch in the counter file" % counter}
+            vals.sort()
+            med = vals[len(vals) // 2]
+            work = [v for v in vals if v >= 0.05 * med] if med > 0 else vals
+            res[counter] = (sum(work) / len(work), len(work), len(vals))
+        fetch, write = res["FETCH_SIZE"][0], res["WRITE_SIZE"][0]
+        return {"kernel": "k_spmv<double, 1, 9>", "FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write,
+                "fetch_correction": 2.0, "launches": res["FETCH_SIZE"][1], "dispatches": res["FETCH_SIZE"][2],
+                "traffic_bytes_per_launch": int((2.0 * fetch + write) * 1024)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def secondary_legs(args, dog):
     """BASELINE.json's other single-GPU configurations, measured by the driver's own run: each leg is a
     fresh child process with a bound of its own; a leg that fails leaves {"error": ...} and the headline untouched."""
@@ -735,6 +777,7 @@ def secondary_legs(args, dog):
             ("config 3: 200^3 fp64 (HBM-roofline SpMV run)", lambda: _bench_leg(["--size", "200"], min(150.0, left()))),
             ("148^3, FIXED-48 value stream", lambda: _bench_leg(["--size", "148", "--fixed48"], min(90.0, left()))),
             ("console driver end to end, 148^3", lambda: _console_leg(148, min(120.0, left()))),
+            ("HBM traffic of k_spmv from PMC counters, 148^3 (two rocprofv3 passes)", lambda: _pmc_leg(min(90.0, left()))),
             ("k_recover (stress recovery) at 148^3",
              lambda: (lambda d, why: d if d is not None else {"error": why})(
                  *_child_json([sys.executable, os.path.join(ROOT, "tools", "recover_time.py"), "148", "10"], min(60.0, left()),
@@ -1004,6 +1047,13 @@ def main():
             # the context's pool gives its parked blocks back first: the legs are processes of their own on this GPU
             ctx.set_option(R.hip.OPT_POOL_MAX_BYTES, 0)
             out["secondary"] = secondary_legs(args, dog)
+            for leg in out["secondary"]:   # counter traffic measured by this run replaces the committed figure
+                if leg.get("traffic_bytes_per_launch") and "error" not in leg:
+                    t_, ms_ = leg["traffic_bytes_per_launch"], out["roofline"]["avg_launch_ms"]
+                    out["roofline"].update(traffic=t_, traffic_source="PMC passes of THIS run (secondary leg: rocprofv3 --pmc FETCH_SIZE / "
+                                           "--pmc WRITE_SIZE over one step of the same workload in a child process; FETCH doubled)",
+                                           traffic_rate_GBs=t_ / (ms_ * 1e-3) / 1e9 if ms_ > 0 else None,
+                                           traffic_over_algorithmic=t_ / out["roofline"]["bytes_per_launch"])
             line = json.dumps(out)
         except Exception as e:   # noqa: BLE001
             sys.stderr.write("bench.py: secondary legs given up: %s\n" % e)

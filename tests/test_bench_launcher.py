@@ -61,12 +61,13 @@ def test_secondary_legs_never_cost_the_headline(monkeypatch):
         return None, "rc -11, no line; stderr tail: Segmentation fault"
     monkeypatch.setattr(bench, "_child_json", fake_child)
     monkeypatch.setattr(bench, "_console_leg", lambda n, timeout: {"error": "no GPU here"})
+    monkeypatch.setattr(bench, "_pmc_leg", lambda timeout: {"error": "no profiler here"})
     args = types.SimpleNamespace(secondary_budget=240.0)
     legs = bench.secondary_legs(args, Dog())
-    assert [l["leg"].split(":")[0] for l in legs][:2] == ["config 2", "config 3"] and len(legs) == 5
+    assert [l["leg"].split(":")[0] for l in legs][:2] == ["config 2", "config 3"] and len(legs) == 6
     assert legs[0]["value"] == good["value"] and legs[0]["roofline"]["frac"] == good["roofline"]["frac"] and "error" not in legs[0]
     assert "timed out" in legs[1]["error"] and "boom" in legs[2]["error"] and legs[3]["error"] == "no GPU here"
-    assert "Segmentation fault" in legs[4]["error"]
+    assert legs[4]["error"] == "no profiler here" and "Segmentation fault" in legs[5]["error"]
     assert all(t <= 150.0 for _, t in calls)
     # a spent budget: nothing is started any more
     calls.clear()
