@@ -478,6 +478,41 @@ def test_recovery_results_kept_on_the_device_and_mapped_by_threads(gpu_ctx):
     res.free()
 
 
+def test_stress_recovery_at_100_cubed_on_sampled_elements(gpu_ctx, oracle):
+    """k_recover at a size of BASELINE.json (config 2: 10^6 elements; 125 000 wavefronts of 8 elements) against the oracle's
+    Element.Recovery_Stress (Element.cs:211-246) on 400 sampled elements -- corners, faces, the last ones of the ragged tail
+    and random interior ones -- with the displacements of a real solve; both entry points (host arrays / kept on the device)."""
+    n = 100
+    job = problem.cube_job(n)
+    gpu_ctx.set_option(1, 0)
+    try:
+        K = gpu_ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+        U, rep = K.cg_solve(job.F, 1e-8)
+        K.free()
+    finally:
+        gpu_ctx.set_option(1, 1)
+    assert rep["terminationtype"] == 1
+    disp_full = np.zeros(job.n_dof)
+    disp_full[job.red != -1] = U
+    disp = disp_full[job.node_dof]                     # [n_nodes, 3] in NodeLib order
+    strain, stress = gpu_ctx.recover_hex8(job.xyz, disp, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu)
+    res = gpu_ctx.recover_hex8_keep(job.xyz, disp, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu)
+    ne = job.conn.shape[0]
+    rng = np.random.default_rng(100)
+    sample = np.unique(np.concatenate([[0, 1, 7, 8, n - 1, n * n - 1, ne - 9, ne - 8, ne - 2, ne - 1], rng.integers(0, ne, 390)]))
+    E, nu = job.mat_E_nu[0]
+    smax, emax = np.abs(stress).max(), np.abs(strain).max()
+    for e in sample:
+        rc, eo, so = oracle.recover_hex8(job.xyz[job.conn[e]], E, nu, 2, disp[job.conn[e]].ravel())
+        assert rc == 0
+        assert np.abs(strain[e] - eo).max() <= 1e-12 * emax, e     # (differences of displacements of size 0.26: absolute bars)
+        assert np.abs(stress[e] - so).max() <= 1e-12 * smax, e
+    for a, b in ((0, 4096), (ne - 4097, ne), (123457, 131072)):
+        e2, s2 = res.map(a, b)
+        assert np.array_equal(e2, strain[a:b]) and np.array_equal(s2, stress[a:b])
+    res.free()
+
+
 def test_nodal_forces_parity(gpu_ctx, oracle):
     """Element.Compute_NodalForces + the R assembly of Solver.cs:184-196 against the oracle."""
     job = problem.cube_job(5, jitter=0.1)
