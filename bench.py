@@ -360,6 +360,9 @@ def build_parser():
                          "rank processes (HIP IPC mappings; no RCCL launch in the loop) instead of over RCCL")
     ap.add_argument("--spmv-variant", type=int, default=-1,
                     help="STAN_OPT_SPMV_VARIANT: -1 = the library's choice; 0 / 9 / 12")
+    ap.add_argument("--spmv-small-rows", type=int, default=-1,
+                    help="STAN_OPT_SPMV_SMALL: block-row limit below which a slice belongs to a workgroup (k_spmv_small) instead of a "
+                         "wavefront (-1 = the library's 150 000; 0 = never)")
     ap.add_argument("--fold", type=int, default=-1,
                     help="STAN_OPT_ROW_FOLDING: -1 = auto (library default), 0 = never, 1 = long rows always lend their tails to the "
                          "idle slots of their slice (fold.hip)")
@@ -456,6 +459,8 @@ class RankRun:
             ctx.set_option(hip.OPT_SPMV_VARIANT, args.spmv_variant)
         if args.refine >= 0:
             ctx.set_option(hip.OPT_CG_REFINE, args.refine)
+        if args.spmv_small_rows >= 0:
+            ctx.set_option(hip.OPT_SPMV_SMALL, args.spmv_small_rows)
         if args.p2p and world > 1:
             ctx.set_option(hip.OPT_COMM_P2P, 1)
         ctx.set_profiling(True)
