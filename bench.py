@@ -728,14 +728,31 @@ def _console_leg(n, timeout):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def pmc_per_launch(csv_files, counter, kernel_regex=r"k_spmv<double, 1, 9>"):
+    """(average counter value per working launch, working launches, dispatches) of one kernel from rocprofv3's
+    *counter_collection.csv files.  A launch queued behind a converged solve returns at once: dispatches whose counter is
+    below 5 % of the kernel's median are not launches that did work."""
+    import csv
+    import re
+    vals = []
+    for f in csv_files:
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") == counter and re.search(kernel_regex, row.get("Kernel_Name", "")):
+                vals.append(float(row["Counter_Value"]))
+    if not vals:
+        return None
+    vals.sort()
+    med = vals[len(vals) // 2]
+    work = [v for v in vals if v >= 0.05 * med] if med > 0 else vals
+    return sum(work) / len(work), len(work), len(vals)
+
+
 def _pmc_leg(timeout_each):
     """HBM-side traffic of the dominant kernel MEASURED BY THIS RUN: two rocprofv3 passes (--pmc FETCH_SIZE, then --pmc
     WRITE_SIZE: separate passes with --kernel-trace only, as MI355X_MICROARCH.md prescribes) over one step of the headline
     workload in a child process; per launch over the launches that did work (a launch queued behind a converged solve
     returns at once: counters below 5 % of the kernel's median), FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B)."""
-    import csv
     import glob
-    import re
     import shutil
     import tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
@@ -751,17 +768,9 @@ def _pmc_leg(timeout_each):
             line, why = _child_json(cmd, timeout_each, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
             if line is None:
                 return {"error": "%s pass: %s" % (counter, why)}
-            vals = []
-            for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    if row.get("Counter_Name") == counter and re.search(r"k_spmv<double, 1, 9>", row["Kernel_Name"]):
-                        vals.append(float(row["Counter_Value"]))
-            if not vals:
+            res[counter] = pmc_per_launch(glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True), counter)
+            if res[counter] is None:
                 return {"error": "%s pass: no k_spmv<double, 1, 9> dispatch in the counter file" % counter}
-            vals.sort()
-            med = vals[len(vals) // 2]
-            work = [v for v in vals if v >= 0.05 * med] if med > 0 else vals
-            res[counter] = (sum(work) / len(work), len(work), len(vals))
         fetch, write = res["FETCH_SIZE"][0], res["WRITE_SIZE"][0]
         return {"kernel": "k_spmv<double, 1, 9>", "FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write,
                 "fetch_correction": 2.0, "launches": res["FETCH_SIZE"][1], "dispatches": res["FETCH_SIZE"][2],

@@ -95,3 +95,20 @@ def test_probe_recommendation_goes_by_tolerance_not_by_bits():
     # nothing is 3 % faster than the defaults: the defaults stay
     legs = {k: leg(0.190 if k == "classic_rccl" else 0.188) for k in legs}
     assert bench.probe_report(legs, 200)["recommended"].startswith("classic_rccl (library defaults)")
+
+
+def test_pmc_per_launch_counts_only_launches_that_did_work(tmp_path):
+    """bench.py's PMC leg averages a counter over the launches of k_spmv that did work: the launches queued behind a converged
+    solve return at once (a few KiB) and must not pull the average down; other kernels and counters are ignored."""
+    import bench
+    f = tmp_path / "pmc_counter_collection.csv"
+    rows = ["Kernel_Name,Counter_Name,Counter_Value"]
+    rows += ['"void (anonymous namespace)::k_spmv<double, 1, 9>(int, long)",FETCH_SIZE,3338000.0'] * 10
+    rows += ['"void (anonymous namespace)::k_spmv<double, 1, 9>(int, long)",FETCH_SIZE,12.0'] * 4          # early exits
+    rows += ['"void (anonymous namespace)::k_spmv<double, 1, 9>(int, long)",WRITE_SIZE,81000.0'] * 3
+    rows += ['"void (anonymous namespace)::k_spmv2<double>(int, long)",FETCH_SIZE,3450000.0'] * 2
+    f.write_text("\n".join(rows) + "\n")
+    avg, work, total = bench.pmc_per_launch([str(f)], "FETCH_SIZE")
+    assert (avg, work, total) == (3338000.0, 10, 14)
+    assert bench.pmc_per_launch([str(f)], "WRITE_SIZE") == (81000.0, 3, 3)
+    assert bench.pmc_per_launch([str(f)], "TCC_HIT") is None
