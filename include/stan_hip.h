@@ -288,6 +288,11 @@ int stan_hip_comm_init(stan_ctx *ctx, int rank, int nranks, const char id[128]);
  * communicator library), the communicator's own rank count and rank (ncclCommCount / ncclCommUserRank),
  * p2p = 1 when STAN_OPT_COMM_P2P is in effect.  Any pointer may be NULL. */
 int stan_hip_comm_info(stan_ctx *ctx, int32_t *rccl_version, int32_t *comm_ranks, int32_t *comm_rank, int32_t *p2p);
+/* The FILE the RCCL entry points were resolved from (realpath of dladdr, NUL-terminated, truncated to capacity;
+ * empty before comm_init) and reused = 1 when that library was ALREADY MAPPED in the process and is shared with the
+ * host (a PyTorch host brings its own librccl.so): comm_init asks with RTLD_NOLOAD first, so one process never runs
+ * two RCCL builds side by side.  path may be NULL with capacity 0; reused may be NULL. */
+int stan_hip_comm_library(stan_ctx *ctx, char *path, int64_t capacity, int32_t *reused);
 
 /* ---- assembly: replaces ParallelAssembly_K (SolverFunctions.cs:117-180) ----------------- */
 /* xyz            [n_nodes*3]  Node.X/Y/Z in NodeLib (wire) order           Node.cs:12-14

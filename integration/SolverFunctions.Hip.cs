@@ -14,6 +14,11 @@ namespace STAN_Solver
 {
     public class SolverFunctionsHip
     {
+        /// What the last LinearSolver_CG call took (alglib.lincgreport.iterationscount / r2): kept, never printed --
+        /// the console lines are the reference's, literal by literal (tests/test_integration_shim.py).
+        public int LastIterations;
+        public double LastRelResidual;
+
         /// STAN_GPUS = n > 1 in the environment: one handle for n devices (stan_hip_init_multi); default: device 0.
         static int GpuCount()
         {
@@ -83,9 +88,10 @@ namespace STAN_Solver
                   AnalysisLib.GetLinSolverTolerance(), AnalysisLib.GetLinSolverMaxIter(), StanHipNative.STAN_PREC_FP64,
                   U, out type, out its, out rel));
             Console.Write(type == 1 || type == 7 ? "  NORMAL " : "  ERROR ");          // :308-325
-            Console.Write(" (type " + type + ", " + its + " iterations)");
+            Console.Write(" (type " + type + ")");                                     // :325, verbatim
             sw.Stop();
             Console.WriteLine(" in " + sw.Elapsed.TotalSeconds.ToString("F2", CultureInfo.InvariantCulture) + "s");
+            LastIterations = its; LastRelResidual = rel;   // (alglib's report carries them too; the reference prints neither)
             return U;
         }
 

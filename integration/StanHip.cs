@@ -103,6 +103,7 @@ namespace STAN_Solver
         [DllImport(Lib)] internal static extern int stan_hip_comm_unique_id([Out] byte[] id);
         [DllImport(Lib)] internal static extern int stan_hip_comm_init(IntPtr ctx, int rank, int nranks, byte[] id);
         [DllImport(Lib)] internal static extern int stan_hip_comm_info(IntPtr ctx, out int rccl_version, out int comm_ranks, out int comm_rank, out int p2p);
+        [DllImport(Lib)] internal static extern int stan_hip_comm_library(IntPtr ctx, [Out] byte[] path, long capacity, out int reused);
 
         // ---- assembly: ParallelAssembly_K (SolverFunctions.cs:117-180)
         [DllImport(Lib)] internal static extern int stan_hip_assemble_hex8(

@@ -182,6 +182,22 @@ int stan_hip_comm_info(stan_ctx *ctx, int32_t *rccl_version, int32_t *comm_ranks
     return STAN_OK;
 }
 
+// which FILE the RCCL entry points of this context were resolved from (empty before comm_init)
+int stan_hip_comm_library(stan_ctx *ctx, char *path, int64_t capacity, int32_t *reused) {
+    if (!ctx || (capacity > 0 && !path) || capacity < 0) return STAN_E_ARG;
+    stan_ctx *c = ctx->group ? stan_group_rank0(ctx) : ctx;
+    std::string p;
+    int r = 0;
+    stan_comm_library(c, &p, &r);
+    if (capacity > 0) {
+        const size_t n = p.size() < (size_t)capacity - 1 ? p.size() : (size_t)capacity - 1;
+        memcpy(path, p.data(), n);
+        path[n] = 0;
+    }
+    if (reused) *reused = r;
+    return STAN_OK;
+}
+
 int stan_hip_set_profiling(stan_ctx *ctx, int32_t enabled) {
     if (!ctx) return STAN_E_ARG;
     if (ctx->group)

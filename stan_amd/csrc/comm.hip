@@ -27,13 +27,19 @@ typedef int (*fn_commInitRank)(void **, int, nccl_uid, int);
 int load_rccl(stan_ctx *ctx) {
     rccl_api &n = ctx->nccl;
     if (n.handle) return STAN_OK;
-    // STAN_RCCL_LIB: test hook only (tests/fake_rccl: several ranks on ONE GPU, which RCCL refuses)
-    const char *names[] = {getenv("STAN_RCCL_LIB"), "librccl.so.1", "librccl.so",
-                           "/opt/rocm/lib/librccl.so.1"};
-    for (const char *nm : names) {
-        if (!nm || !*nm) continue;
-        n.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-        if (n.handle) break;
+    // ONE RCCL per process: a host that already has RCCL mapped -- bench.py under torch, whose
+    // libtorch_hip.so brings its bundled librccl.so (SONAME librccl.so.1) -- keeps using THAT file: RTLD_NOLOAD
+    // only returns what is loaded.  A fresh load happens when there is none.  STAN_RCCL_LIB: test hook only
+    // (tests/fake_rccl: several ranks on ONE GPU, which RCCL refuses).
+    const char *hook = getenv("STAN_RCCL_LIB");
+    if (hook && *hook) n.handle = dlopen(hook, RTLD_NOW | RTLD_GLOBAL);
+    else {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (int i = 0; i < 2 && !n.handle; i++) {
+            n.handle = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD);
+            n.reused = n.handle != nullptr;
+        }
+        for (int i = 0; i < 3 && !n.handle; i++) n.handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
     }
     if (!n.handle) {
         ctx->err = std::string("dlopen(librccl): ") + dlerror();
@@ -60,6 +66,11 @@ int load_rccl(stan_ctx *ctx) {
     *(void **)(&n.CommCount) = dlsym(n.handle, "ncclCommCount");
     *(void **)(&n.CommUserRank) = dlsym(n.handle, "ncclCommUserRank");
 #undef SYM
+    Dl_info di;   // the FILE the entry points came from: bench.py prints it next to a multi-GPU line
+    if (dladdr((void *)n.AllReduce, &di) && di.dli_fname) {
+        char real[4096];
+        n.path = realpath(di.dli_fname, real) ? real : di.dli_fname;
+    }
     return STAN_OK;
 }
 
@@ -151,6 +162,13 @@ int stan_comm_info(stan_ctx *ctx, int *version, int *count, int *rank) {
     if (ctx->nccl.GetVersion) ctx->nccl.GetVersion(version);
     if (comm && ctx->nccl.CommCount) ctx->nccl.CommCount(comm, count);
     if (comm && ctx->nccl.CommUserRank) ctx->nccl.CommUserRank(comm, rank);
+    return STAN_OK;
+}
+
+// the file the RCCL entry points were resolved from, and whether it was already mapped when this library asked
+int stan_comm_library(stan_ctx *ctx, std::string *path, int *reused) {
+    *path = ctx->nccl.path;
+    *reused = ctx->nccl.reused ? 1 : 0;
     return STAN_OK;
 }
 

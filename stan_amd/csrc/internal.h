@@ -54,6 +54,8 @@ struct rccl_api {
     int (*GetVersion)(int *) = nullptr;          // optional
     int (*CommCount)(void *, int *) = nullptr;   // optional
     int (*CommUserRank)(void *, int *) = nullptr;
+    std::string path;      // the file the entry points live in (dladdr)
+    bool reused = false;   // it was already mapped in this process (RTLD_NOLOAD): no second RCCL next to the host's
 };
 
 // Device blocks of 8 MB and more are kept by the context when they are freed and handed out again
@@ -391,6 +393,7 @@ int stan_recover_device(stan_ctx *ctx, int64_t n_nodes, const double *d_xyz, con
 // ---- comm.cpp -------------------------------------------------------------------------------
 int stan_comm_allreduce_sum_f64(stan_ctx *ctx, double *d_buf, size_t count);
 int stan_comm_info(stan_ctx *ctx, int *version, int *count, int *rank);
+int stan_comm_library(stan_ctx *ctx, std::string *path, int *reused);
 int stan_comm_allgather_bytes(stan_ctx *ctx, const void *mine, size_t bytes, void *all);   // host buffers, [nranks*bytes] out
 // exchange: pack rows listed in K->d_send_rows from d_vec (3 doubles per block row) and
 // receive into d_vec + 3*nloc (halo region).

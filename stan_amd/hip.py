@@ -45,7 +45,7 @@ EXPORTS = [
     "stan_hip_ke_hex8_batch", "stan_hip_matrix_to_csr", "stan_hip_spmv", "stan_hip_spmv_bench",
     "stan_hip_set_profiling", "stan_hip_get_profile", "stan_hip_set_option", "stan_hip_recover_hex8", "stan_hip_recover_hex8_dev",
     "stan_hip_nodal_forces_hex8", "stan_hip_pool_info",
-    "stan_hip_matrix_plan", "stan_hip_spmv_local", "stan_hip_comm_info",
+    "stan_hip_matrix_plan", "stan_hip_spmv_local", "stan_hip_comm_info", "stan_hip_comm_library",
     "stan_hip_matrix_part_info", "stan_hip_get_profile_rank", "stan_hip_device_info", "stan_hip_matrix_diagonal",
     "stan_hip_recover_hex8_keep", "stan_hip_results_map", "stan_hip_results_free",
 ]
@@ -212,7 +212,10 @@ class Context:
         """What the sharded CG exchanges over: RCCL version code, the communicator's rank count / rank, p2p flag."""
         v, n, r, p = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
         self._chk(self.lib.stan_hip_comm_info(self.h, C.byref(v), C.byref(n), C.byref(r), C.byref(p)))
-        return dict(rccl_version=v.value, comm_ranks=n.value, comm_rank=r.value, p2p=bool(p.value))
+        buf, reused = C.create_string_buffer(4096), C.c_int32(0)
+        self._chk(self.lib.stan_hip_comm_library(self.h, buf, C.c_int64(4096), C.byref(reused)))
+        return dict(rccl_version=v.value, comm_ranks=n.value, comm_rank=r.value, p2p=bool(p.value),
+                    library=buf.value.decode(), library_reused=bool(reused.value))
 
     # -- K_e (debug / parity) ---------------------------------------------------------
     def ke_hex8(self, xyz8, E, nu, etype):

@@ -36,3 +36,20 @@ def gpu_ctx(built_libs):
     ctx = hip.Context(0)
     yield ctx
     ctx.close()
+
+
+def fake_rccl_env(mode, nranks_in_one_process=0):
+    """Environment of a child that runs over tests/fake_rccl in `mode`:
+      "sync"   every call drains its stream and moves the data on the host (the stand-in of rounds 1-5);
+      "async"  FAKE_RCCL_ASYNC=1: send / recv / all-reduce are enqueued on the caller's stream like RCCL's.
+    Ranks that share one PROCESS (stan_hip_init_multi) and one device need a hardware queue per stream in
+    asynchronous mode, exactly as the product's peer-to-peer path does (a polling kernel blocks its queue)."""
+    env = {"FAKE_RCCL_ASYNC": "1" if mode == "async" else "0"}
+    if mode == "async" and nranks_in_one_process:
+        env["GPU_MAX_HW_QUEUES"] = str(2 * nranks_in_one_process + 4)
+    return env
+
+
+@pytest.fixture(params=["sync", "async"])
+def fake_mode(request):
+    return request.param

@@ -4,7 +4,18 @@
 // Real RCCL refuses that ("Duplicate GPU detected"), which would leave the sharded CG
 // (halo exchange, all-reduces, result gather, two-stream overlap) untested end to end.
 // Selected only through the environment variable STAN_RCCL_LIB; the product default is the
-// real librccl.so.1.  Every call is synchronous (it drains the stream it is given).
+// real librccl.so.1.
+//
+// TWO MODES (round 6):
+//   * synchronous (default): every call drains the stream it is given and moves the data on the host.  A
+//     product-side ordering bug between the exchange and the kernels around it can hide behind those drains.
+//   * FAKE_RCCL_ASYNC=1: ncclSend / ncclRecv / ncclAllReduce are ENQUEUED on the caller's stream like RCCL's --
+//     polling kernels + copy kernels on mailboxes in host-registered shared memory, arrival counters written by
+//     the stream itself; the host never waits.  What the product forgets to order (a missing
+//     hipStreamWaitEvent between the side stream's interior product and the boundary product, say) really
+//     runs concurrently.  ncclBroadcast (set-up, the final gather of U) stays host-staged in both modes.
+//     Ranks that share one process need a hardware queue per stream (GPU_MAX_HW_QUEUES >= 2 * nranks + 2), as
+//     the product's own peer-to-peer path does: a polling kernel must never sit in front of its producer.
 //
 // Semantics kept from NCCL: collectives (all-reduce, broadcast) are matched by call order and
 // need EVERY rank; ncclSend/ncclRecv involve only the two peers (a one-message mailbox per
@@ -40,6 +51,21 @@ struct Header {
     std::atomic<long> produced[MAXR][MAXR], consumed[MAXR][MAXR];  // [src][dst]
     size_t pair_bytes[MAXR][MAXR];
 };
+// ---- asynchronous mode: what the stream-ordered kernels read and write (host-registered shared memory) ----
+constexpr int ASLOTS = 2;        // messages in flight per ordered pair / all-reduces in flight
+constexpr int AR_MAX = 256;      // doubles per all-reduce (the product sends 1..3)
+struct alignas(64) Ctr { unsigned long long v; char pad[56]; };   // a counter per cache line
+struct AHeader {
+    Ctr prod[MAXR][MAXR], cons[MAXR][MAXR];   // [src][dst]: messages written / taken (monotonic)
+    Ctr ar_prod[MAXR], ar_cons[MAXR];         // all-reduces a rank has published / finished
+    Ctr error;                                // first device-side failure: 1 a wait ran out, 2 message size mismatch
+    Ctr abort;                                // ncclCommAbort: every polling kernel returns
+    unsigned long long msg_bytes[MAXR][MAXR][ASLOTS];
+    unsigned long long ar_box[ASLOTS][MAXR][AR_MAX];   // doubles or int64 as bits
+};
+constexpr size_t PAGE = 4096;
+constexpr size_t page_up(size_t b) { return (b + PAGE - 1) / PAGE * PAGE; }
+
 struct Comm {
     Header *h;
     char *box;   // nranks mailboxes
@@ -49,6 +75,13 @@ struct Comm {
     long ncalls;
     char name[64];
     size_t bytes;
+    // asynchronous mode
+    bool async = false;
+    AHeader *ah = nullptr, *d_ah = nullptr;            // host view / device view of the registered header
+    char *abox = nullptr;                              // nranks x nranks x ASLOTS pair mailboxes
+    char *d_abox[MAXR][MAXR] = {};                     // device views, registered on first use
+    unsigned long long a_sent[MAXR] = {}, a_recvd[MAXR] = {}, ar_calls = 0;
+    long delay_us = 0;                                 // FAKE_RCCL_ASYNC_DELAY_US: a message's data lands late
 };
 struct Op { int kind; const void *src; void *dst; size_t bytes; int peer; hipStream_t st; };  // 0 send 1 recv 2 bcast
 thread_local int g_depth = 0;
@@ -93,9 +126,153 @@ size_t tsize(int dt) { return dt == 1 ? 1 : 8; }  // ncclUint8 = 1; ncclInt64 = 
 
 char *pair_box(Comm *c, int src, int dst) { return c->pbox + ((size_t)src * c->nranks + dst) * PAIRBOX; }
 
+// ---------------------------------------------------------------------------------------------------------------
+// asynchronous mode: kernels.  A polling wave gives up after STALL_S (wall_clock64 ticks at 100 MHz) and leaves
+// error = 1, so that a protocol mismatch ends as a failed test and never as a wedged device.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long a_load(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void a_store(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ bool a_poll_ge(const Ctr *c, unsigned long long want, AHeader *h) {
+    const long long t0 = wall_clock64(), bound = (long long)(STALL_S * 1e8);
+    while (a_load(&c->v) < want) {
+        if (a_load(&h->abort.v)) return false;
+        if (wall_clock64() - t0 > bound) { a_store(&h->error.v, 1); return false; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    return true;
+}
+// the stream waits until *c >= want; a receive also checks the size the sender recorded for that slot
+__global__ void k_a_wait(AHeader *h, const Ctr *c, unsigned long long want, const unsigned long long *size_word,
+                         unsigned long long size_want) {
+    if (threadIdx.x != 0) return;
+    if (a_poll_ge(c, want, h) && size_word && a_load(size_word) != size_want) a_store(&h->error.v, 2);
+}
+__global__ void k_a_copy(char *dst, const char *src, size_t bytes) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((((uintptr_t)dst | (uintptr_t)src | bytes) & 15) == 0) {
+        const size_t n = bytes / 16;
+        for (size_t i = t; i < n; i += stride) ((uint4 *)dst)[i] = ((const uint4 *)src)[i];
+    } else {
+        for (size_t i = t; i < bytes; i += stride) dst[i] = src[i];
+    }
+}
+// what came before on the stream is finished and visible to every agent; then the counter moves
+__global__ void k_a_set(Ctr *c, unsigned long long v, unsigned long long *size_word, unsigned long long size) {
+    __threadfence_system();
+    if (size_word) a_store(size_word, size);
+    a_store(&c->v, v);
+}
+__global__ void k_a_spin(long us) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < us * 100) __builtin_amdgcn_s_sleep(8);
+}
+// all-reduce number k of this communicator, whole: wait until slot k % ASLOTS is free on every rank, publish this
+// rank's values, wait for every rank's, add them IN RANK ORDER (what the synchronous mode and the product's
+// peer-to-peer path do: the bits agree), say so.  One workgroup; count <= AR_MAX.
+__global__ void k_a_allreduce(AHeader *h, int rank, int n, unsigned long long k, const unsigned long long *send,
+                              unsigned long long *recv, int count, int is_int) {
+    const int t = threadIdx.x, slot = (int)(k % ASLOTS);
+    if (k >= ASLOTS && t < n) a_poll_ge(&h->ar_cons[t], k - ASLOTS + 1, h);
+    __syncthreads();
+    for (int i = t; i < count; i += blockDim.x) a_store(&h->ar_box[slot][rank][i], send[i]);
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) a_store(&h->ar_prod[rank].v, k + 1);
+    if (t < n) a_poll_ge(&h->ar_prod[t], k + 1, h);
+    __syncthreads();
+    __threadfence_system();
+    for (int i = t; i < count; i += blockDim.x) {
+        if (is_int) {
+            long long s = 0;
+            for (int r = 0; r < n; r++) s += (long long)a_load(&h->ar_box[slot][r][i]);
+            recv[i] = (unsigned long long)s;
+        } else {
+            double s = 0;
+            for (int r = 0; r < n; r++) s += __longlong_as_double((long long)a_load(&h->ar_box[slot][r][i]));
+            recv[i] = (unsigned long long)__double_as_longlong(s);
+        }
+    }
+    __syncthreads();
+    if (t == 0) a_store(&h->ar_cons[rank].v, k + 1);
+}
+
+char *a_pair_box(Comm *c, int src, int dst) {   // device view of the pair's ASLOTS mailboxes, registered on first use
+    if (!c->d_abox[src][dst]) {
+        char *hp = c->abox + ((size_t)src * c->nranks + dst) * ASLOTS * PAIRBOX;
+        void *dp = nullptr;
+        if (hipHostRegister(hp, ASLOTS * PAIRBOX, hipHostRegisterMapped) != hipSuccess ||
+            hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+            fprintf(stderr, "fake_rccl: hipHostRegister of a pair mailbox failed: %s\n", hipGetErrorString(hipGetLastError()));
+            return nullptr;
+        }
+        c->d_abox[src][dst] = (char *)dp;
+    }
+    return c->d_abox[src][dst];
+}
+unsigned a_grid(size_t bytes) { size_t b = (bytes / 16 + 255) / 256; return (unsigned)(b < 1 ? 1 : b > 256 ? 256 : b); }
+
+int a_error(Comm *c, const char *where) {   // a device-side failure recorded so far?
+    const unsigned long long e = c->ah ? ((volatile Ctr *)&c->ah->error)->v : 0;
+    if (!e) return 0;
+    fprintf(stderr, "fake_rccl (async): rank %d, %s: %s\n", c->rank, where,
+            e == 1 ? "a stream-ordered wait ran out (protocol mismatch or a rank that left)" : "message size mismatch");
+    return 5;
+}
+
+// send / receive of one group, enqueued: nothing here waits on the host
+int a_enqueue_p2p(Comm *c) {
+    AHeader *d = c->d_ah;
+    for (const Op &o : g_ops) {
+        if (o.kind != 0) continue;
+        if (o.bytes > PAIRBOX) { fprintf(stderr, "fake_rccl: message larger than the pair mailbox\n"); return 5; }
+        char *box = a_pair_box(c, c->rank, o.peer);
+        if (!box) return 2;
+        const unsigned long long k = c->a_sent[o.peer]++;
+        const int slot = (int)(k % ASLOTS);
+        if (k >= ASLOTS)
+            hipLaunchKernelGGL(k_a_wait, dim3(1), dim3(64), 0, o.st, d, &d->cons[c->rank][o.peer], k - ASLOTS + 1,
+                               (const unsigned long long *)nullptr, 0ULL);
+        hipLaunchKernelGGL(k_a_copy, dim3(a_grid(o.bytes)), dim3(256), 0, o.st, box + (size_t)slot * PAIRBOX,
+                           (const char *)o.src, o.bytes);
+        hipLaunchKernelGGL(k_a_set, dim3(1), dim3(1), 0, o.st, &d->prod[c->rank][o.peer], k + 1,
+                           &d->msg_bytes[c->rank][o.peer][slot], (unsigned long long)o.bytes);
+    }
+    for (const Op &o : g_ops) {
+        if (o.kind != 1) continue;
+        char *box = a_pair_box(c, o.peer, c->rank);
+        if (!box) return 2;
+        const unsigned long long k = c->a_recvd[o.peer]++;
+        const int slot = (int)(k % ASLOTS);
+        hipLaunchKernelGGL(k_a_wait, dim3(1), dim3(64), 0, o.st, d, &d->prod[o.peer][c->rank], k + 1,
+                           (const unsigned long long *)&d->msg_bytes[o.peer][c->rank][slot], (unsigned long long)o.bytes);
+        if (c->delay_us > 0) hipLaunchKernelGGL(k_a_spin, dim3(1), dim3(1), 0, o.st, c->delay_us);
+        hipLaunchKernelGGL(k_a_copy, dim3(a_grid(o.bytes)), dim3(256), 0, o.st, (char *)o.dst,
+                           (const char *)box + (size_t)slot * PAIRBOX, o.bytes);
+        hipLaunchKernelGGL(k_a_set, dim3(1), dim3(1), 0, o.st, &d->cons[o.peer][c->rank], k + 1,
+                           (unsigned long long *)nullptr, 0ULL);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 int flush_group(Comm *c) {
     if (!c) return 5;
     c->ncalls++;
+    if (c->async) {
+        int rc = a_enqueue_p2p(c);
+        if (rc) return rc;
+        std::vector<Op> bc;
+        for (const Op &o : g_ops) if (o.kind == 2) bc.push_back(o);
+        g_ops.swap(bc);
+        if (g_ops.empty()) return 0;
+        // broadcasts stay host-staged (set-up and the final gather): the code below, on the broadcasts alone;
+        // the drain in front of it is also where a device-side failure of the enqueued exchanges surfaces
+        for (const Op &o : g_ops) hipStreamSynchronize(o.st);
+        if ((rc = a_error(c, "before a broadcast group"))) return rc;
+    }
     for (const Op &o : g_ops) hipStreamSynchronize(o.st);
     // point-to-point: all sends of the group first (one message in flight per ordered pair),
     // then the receives -- only the two peers of a message ever wait for each other
@@ -186,7 +363,10 @@ int ncclCommInitRank(void **comm, int nranks, nccl_uid id, int rank) {
     Comm *c = new Comm();
     c->rank = rank; c->nranks = nranks; c->local_sense = 0;
     strncpy(c->name, id.internal, 63);
-    c->bytes = sizeof(Header) + (size_t)nranks * MAILBOX + (size_t)nranks * nranks * PAIRBOX;
+    const char *am = getenv("FAKE_RCCL_ASYNC");
+    c->async = am && atoi(am) != 0;
+    const size_t sync_bytes = page_up(sizeof(Header) + (size_t)nranks * MAILBOX + (size_t)nranks * nranks * PAIRBOX);
+    c->bytes = sync_bytes + (c->async ? page_up(sizeof(AHeader)) + (size_t)nranks * nranks * ASLOTS * PAIRBOX : 0);
     int fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
     if (fd < 0 || ftruncate(fd, (off_t)c->bytes) != 0) return 2;
     void *p = mmap(nullptr, c->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
@@ -196,6 +376,19 @@ int ncclCommInitRank(void **comm, int nranks, nccl_uid id, int rank) {
     c->box = (char *)p + sizeof(Header);
     c->pbox = c->box + (size_t)nranks * MAILBOX;
     c->h->nranks = nranks;
+    if (c->async) {   // the counters and the all-reduce slots, visible to this rank's kernels
+        c->ah = (AHeader *)((char *)p + sync_bytes);
+        c->abox = (char *)c->ah + page_up(sizeof(AHeader));
+        void *dp = nullptr;
+        if (hipHostRegister(c->ah, page_up(sizeof(AHeader)), hipHostRegisterMapped) != hipSuccess ||
+            hipHostGetDevicePointer(&dp, c->ah, 0) != hipSuccess) {
+            fprintf(stderr, "fake_rccl: hipHostRegister of the shared header failed: %s\n", hipGetErrorString(hipGetLastError()));
+            return 2;
+        }
+        c->d_ah = (AHeader *)dp;
+        if (const char *e = getenv("FAKE_RCCL_ASYNC_DELAY_US")) c->delay_us = atol(e);
+        if (rank == 0) fprintf(stderr, "fake_rccl: asynchronous mode (stream-ordered send / recv / all-reduce), %d ranks\n", nranks);
+    }
     c->h->init.fetch_add(1);
     c->ncalls = 0;
     if (!wait_until(c, [&] { return c->h->init.load() >= nranks; }, "init", -1)) return 2;
@@ -207,7 +400,17 @@ int ncclCommInitRank(void **comm, int nranks, nccl_uid id, int rank) {
 
 int ncclCommDestroy(void *comm) {
     Comm *c = (Comm *)comm;
+    if (c->async) {
+        hipDeviceSynchronize();
+        a_error(c, "at ncclCommDestroy");
+    }
     if (!c->h->aborted.load()) barrier(c, "destroy");
+    if (c->async) {
+        for (int a = 0; a < c->nranks; a++)
+            for (int b = 0; b < c->nranks; b++)
+                if (c->d_abox[a][b]) hipHostUnregister(c->abox + ((size_t)a * c->nranks + b) * ASLOTS * PAIRBOX);
+        hipHostUnregister(c->ah);
+    }
     if (c->rank == 0) shm_unlink(c->name);
     munmap((void *)c->h, c->bytes);
     delete c;
@@ -217,6 +420,7 @@ int ncclCommDestroy(void *comm) {
 int ncclCommAbort(void *comm) {   // like NCCL's: queued and blocked operations of this communicator return
     Comm *c = (Comm *)comm;
     c->h->aborted.store(1);
+    if (c->ah) ((volatile Ctr *)&c->ah->abort)->v = 1;   // the polling kernels of every rank return
     return 0;
 }
 
@@ -225,6 +429,13 @@ int ncclAllReduce(const void *send, void *recv, size_t count, int dt, int op, vo
     if (op != 0 || (dt != 8 && dt != 4)) return 4;
     const size_t bytes = count * 8;
     if (bytes > MAILBOX) return 5;
+    if (c->async) {
+        if (count > (size_t)AR_MAX) return 4;
+        c->ncalls++;
+        hipLaunchKernelGGL(k_a_allreduce, dim3(1), dim3(256), 0, st, c->d_ah, c->rank, c->nranks, c->ar_calls++,
+                           (const unsigned long long *)send, (unsigned long long *)recv, (int)count, dt == 4 ? 1 : 0);
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
     hipStreamSynchronize(st);
     c->ncalls++;
     hipMemcpy(c->box + (size_t)c->rank * MAILBOX, send, bytes, hipMemcpyDeviceToHost);

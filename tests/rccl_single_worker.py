@@ -1,7 +1,9 @@
 """One process, one GPU, a REAL 1-rank RCCL communicator (tests/test_gpu_parity.py runs this as a
 child: a process that has held an RCCL communicator slows every later multi-process GPU test of the
 same pytest session to a crawl on a shared device, so the pytest process itself never creates one).
-Prints 'same_bits <0|1> its <a> <b>'."""
+Prints 'same_bits <0|1> its <a> <b>' and 'rccl <file> reused <0|1> mappings <n>': which librccl the
+library resolved, whether it was the one the host (torch) had already mapped, and how many distinct
+librccl files /proc/self/maps shows afterwards (never two RCCL builds in one process)."""
 import os
 import sys
 
@@ -17,7 +19,13 @@ res = []
 for use_comm in (False, True):
     ctx = hip.Context(0)
     if use_comm:
+        import torch.distributed  # noqa: F401  (libtorch_hip.so brings torch's bundled librccl.so into the process)
         ctx.comm_init(0, 1, ctx.unique_id())
+        info = ctx.comm_info()
+        mapped = sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l})
+        print("rccl %s reused %d mappings %d version %d" % (info["library"], int(info["library_reused"]), len(mapped),
+                                                             info["rccl_version"]))
+        print("mapped " + " ".join(mapped))
     K = ctx.assemble_hex8(*args)
     res.append(K.cg_solve(job.F, 1e-10))
     K.free()

@@ -37,7 +37,8 @@ K = ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_ty
 info = K.info()
 if spec.startswith("bench:"):     # bench mode: merit stop off, 1e-8, fp64 only; the whole U comes back on every rank
     ctx.set_option(hip.OPT_CG_MERIT_STOP, 0)
-    U, rep = K.cg_solve(job.F, 1e-8)
+    # SHARDED_WORKER_MAXITS: a bound for the run of a deliberately broken library (whose loop may never converge)
+    U, rep = K.cg_solve(job.F, 1e-8, int(os.environ.get("SHARDED_WORKER_MAXITS", "0")))
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), U=U, its=rep["iterations"], term=rep["terminationtype"],
              rows=np.array([info["row_begin"], info["row_end"], info["n_halo"]]))
     K.free()

@@ -84,3 +84,35 @@ def test_plain_c_consumer_builds_and_fails_loudly_without_a_gpu(built_libs):
     assert out.returncode == 3, out.stdout + out.stderr
     assert "nodes 27 elements 8 nDOF 81 fixed 27 N 54" in out.stdout     # SURVEY.md Appendix E, n = 2
     assert "stan_hip_init failed" in out.stderr
+
+
+@pytest.mark.parametrize("host_has_rccl", [True, False])
+def test_one_rccl_per_process(built_libs, host_has_rccl):
+    """a host that has already mapped RCCL (bench.py and every torch host:
+    libtorch_hip.so NEEDs its bundled librccl.so) must not get a second build next to it -- comm.hip asks with
+    RTLD_NOLOAD first.  A host without RCCL gets exactly one fresh load.  (ncclGetUniqueId needs no GPU.)"""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, os, sys
+sys.path.insert(0, %r)
+if %d:
+    import torch
+    from stan_amd import hip
+    lib = hip.load()
+else:      # a host without torch (the C# shim, stan_solver): the bare library
+    lib = C.CDLL(os.path.join(%r, "stan_amd", "lib", "libstan_hip.so"))
+before = sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l})
+buf = C.create_string_buffer(128)
+rc = lib.stan_hip_comm_unique_id(buf)   # (ROCm 7.2's own RCCL wants a device even for this; the bundled one does not)
+assert rc == 0 or not %d
+after = sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l})
+print("BEFORE", len(before), "AFTER", len(after), " ".join(after))
+''' % (ROOT, int(host_has_rccl), ROOT, int(host_has_rccl))
+    env = dict(os.environ)
+    env.pop("STAN_RCCL_LIB", None)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout + p.stderr[-2000:]
+    w = [l for l in p.stdout.splitlines() if l.startswith("BEFORE")][0].split()
+    assert int(w[1]) == (1 if host_has_rccl else 0) and int(w[3]) == 1, p.stdout
+    assert ("torch" in w[4]) == host_has_rccl

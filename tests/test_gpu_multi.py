@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 from stan_amd import problem
+from tests.conftest import fake_rccl_env
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,10 +21,10 @@ FAKE = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
 
 
 @pytest.mark.parametrize("nranks", [2, 3])
-def test_one_process_several_ranks_matches_oracle(built_libs, oracle, tmp_path, nranks):
+def test_one_process_several_ranks_matches_oracle(built_libs, oracle, tmp_path, nranks, fake_mode):
     n = 12
     out = str(tmp_path / "multi.npz")
-    env = dict(os.environ, STAN_RCCL_LIB=FAKE)
+    env = dict(os.environ, STAN_RCCL_LIB=FAKE, **fake_rccl_env(fake_mode, nranks))
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multi_worker.py"), str(n), str(nranks), out],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
@@ -101,10 +102,11 @@ def test_init_multi_fails_loudly_on_a_missing_device(built_libs):
     assert ei.value.code in (hip.E_HIP, hip.E_COMM)
 
 
-def test_a_failing_rank_does_not_hang_the_host(built_libs, tmp_path):
+def test_a_failing_rank_does_not_hang_the_host(built_libs, tmp_path, fake_mode):
     """a rank that fails inside the solve leaves its peers blocked in a collective.  The
     group handle notices the failure, aborts the communicators after a grace period, reports the
-    failing rank and refuses further sharded calls."""
+    failing rank and refuses further sharded calls.  Over the stream-ordered stand-in the peers are blocked the way
+    they are in RCCL: in kernels of the collective sitting on their streams, which ncclCommAbort must end."""
     code = r'''
 import os, sys, time
 sys.path.insert(0, %r)
@@ -131,7 +133,7 @@ except hip.StanHipError as e:
 K.free(); ctx.close()
 print("CLOSED")
 ''' % ROOT
-    env = dict(os.environ, STAN_RCCL_LIB=FAKE)
+    env = dict(os.environ, STAN_RCCL_LIB=FAKE, **fake_rccl_env(fake_mode, 2))
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180, env=env, cwd=ROOT)
     out = p.stdout
     assert p.returncode == 0, out[-2000:] + p.stderr[-3000:]
@@ -142,11 +144,11 @@ print("CLOSED")
     assert "CLOSED" in out
 
 
-def test_more_ranks_than_slices_through_the_group_handle(built_libs, oracle, tmp_path):
+def test_more_ranks_than_slices_through_the_group_handle(built_libs, oracle, tmp_path, fake_mode):
     """3^3 cube = 64 nodes = ONE slice: ranks 1..3 of four own no rows (empty shards, zero-size
     launches, no boundary product to fold the reduction into), classic and single-reduction loop."""
     out = str(tmp_path / "multi.npz")
-    env = dict(os.environ, STAN_RCCL_LIB=FAKE)
+    env = dict(os.environ, STAN_RCCL_LIB=FAKE, **fake_rccl_env(fake_mode, 4))
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multi_worker.py"), "3", "4", out, "small"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
@@ -159,14 +161,16 @@ def test_more_ranks_than_slices_through_the_group_handle(built_libs, oracle, tmp
         assert np.abs(d[key] - Uo).max() <= 1e-4 * np.abs(Uo).max(), key
 
 
-@pytest.mark.parametrize("transport", ["rccl", "p2p"])
+@pytest.mark.parametrize("transport", ["rccl", "rccl-async", "p2p"])
 def test_config4_200_cubed_on_8_ranks_against_the_oracle_fixture(built_libs, tmp_path, transport):
     """BASELINE.json config 4 -- "200^3 cube row-partitioned across 8 x MI355X, RCCL dot-allreduce + SpMV halo" -- at its
     own size and rank count (Solver.cs:156-162 are the two calls it replaces): one process, eight
     ranks through stan_hip_init_multi, bench mode, against the oracle's committed answer (tests/golden/bench_mode_200.npz:
     iterations within 2, max |dU| / max |U| <= 1e-9).  Every rank reports the same iteration count and code, the
     device-derived halo of every rank equals the host plan's (tests/test_partition_plan.py: 30 k - 111 k block rows per
-    neighbour), the RCCL-shaped loop makes two collectives per iteration and the peer-to-peer loop none."""
+    neighbour), the RCCL-shaped loop makes two collectives per iteration and the peer-to-peer loop none.
+    "rccl-async" (round 6): the same over the stream-ordered form of the stand-in -- eight ranks' exchanges and
+    two-stream overlaps in flight on the device at once, nothing drained on the host."""
     import torch
     from stan_amd import host
     golden = os.path.join(ROOT, "tests", "golden", "bench_mode_200.npz")
@@ -177,7 +181,10 @@ def test_config4_200_cubed_on_8_ranks_against_the_oracle_fixture(built_libs, tmp
                     % (torch.cuda.mem_get_info(0)[0] / 1e9))
     n, nranks = 200, 8
     out = str(tmp_path / "config4.npz")
-    env = dict(os.environ, STAN_RCCL_LIB=FAKE, GPU_MAX_HW_QUEUES=str(2 * nranks + 4))
+    env = dict(os.environ, STAN_RCCL_LIB=FAKE, GPU_MAX_HW_QUEUES=str(2 * nranks + 4),
+               **fake_rccl_env("async" if transport == "rccl-async" else "sync"))
+    env["GPU_MAX_HW_QUEUES"] = str(2 * nranks + 4)
+    transport = transport.split("-")[0]
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "config4_worker.py"), str(n), str(nranks), transport, golden, out],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]

@@ -654,6 +654,12 @@ def test_single_rank_rccl_communicator(built_libs):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("same_bits")][0].split()
     assert line[1] == "1" and line[3] == line[4] and int(line[3]) > 0
+    # round 6: ONE RCCL per process.  torch has mapped its bundled librccl.so before comm_init asks; the library
+    # takes that file (RTLD_NOLOAD) instead of loading /opt/rocm's next to it, and says which file it is.
+    rl = [l for l in out.stdout.splitlines() if l.startswith("rccl ")][0].split()
+    assert "librccl" in rl[1] and os.path.isabs(rl[1]) and rl[3] == "1" and rl[5] == "1" and int(rl[7]) > 20000, out.stdout
+    mapped = [l for l in out.stdout.splitlines() if l.startswith("mapped ")][0].split()[1:]
+    assert [os.path.realpath(m) for m in mapped] == [rl[1]]
 
 
 def _star_job(k, layers=3, rings=2):

@@ -14,10 +14,12 @@ import numpy as np
 import pytest
 
 from stan_amd import problem
+from tests.conftest import fake_rccl_env
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAKE = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+ASYNC_BANNER = "fake_rccl: asynchronous mode"
 
 
 def _port():
@@ -25,40 +27,44 @@ def _port():
     return p
 
 
-def _torchrun(nproc, script_args, env_extra):
+def _torchrun(nproc, script_args, env_extra, timeout=300, attempts=2):
     """Several ranks sharing ONE GPU through the shared-memory RCCL stand-in (which gives up after
     60 s of waiting with a dump of its counters).  Many processes time-slicing one device can
     be slow for reasons that have nothing to do with the code under test (see the docstring of
     test_sharded_solve_matches_oracle), so a timed-out attempt is killed as a process group,
     its output shown, and repeated once."""
-    for attempt in (1, 2):
+    for attempt in range(1, attempts + 1):
         env = dict(os.environ, STAN_RCCL_LIB=FAKE, **env_extra)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                "--master-addr", "127.0.0.1", "--master-port", str(_port())] + script_args
         proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
                                 cwd=ROOT, start_new_session=True)   # own process group: launcher + ranks
         try:
-            out, err = proc.communicate(timeout=300)
+            out, err = proc.communicate(timeout=timeout)
             return subprocess.CompletedProcess(cmd, proc.returncode, out, err)
         except subprocess.TimeoutExpired:
             os.killpg(proc.pid, signal.SIGKILL)                      # exactly the group started above
             out, err = proc.communicate()
             print("sharded run timed out (attempt %d):\n%s" % (attempt, (err or "")[-3000:]))
-            if attempt == 2:
+            if attempt == attempts:
                 raise
 
 
 @pytest.mark.parametrize("world,overlap,spec", [(2, 1, "12"), (3, 1, "12"), (3, 0, "12"),
                                                 (4, 1, "fuzz:124"), (4, 1, "fuzz:101"), (3, 1, "rev:3")])
-def test_sharded_solve_matches_oracle(built_libs, oracle, tmp_path, world, overlap, spec):
-    """fuzz:124 = 383 shuffled nodes on 4 ranks (1, 3, 2, 2 neighbours); fuzz:101 = 191 nodes on
+def test_sharded_solve_matches_oracle(built_libs, oracle, tmp_path, world, overlap, spec, fake_mode):
+    """Both modes of the stand-in (round 6): "sync" drains every stream on the host, "async" enqueues the exchanges on
+    the caller's stream the way RCCL does, so the two-stream overlap really overlaps.
+    fuzz:124 = 383 shuffled nodes on 4 ranks (1, 3, 2, 2 neighbours); fuzz:101 = 191 nodes on
     4 ranks, the first of which owns no rows.  More processes than that on the one GPU next to the
     pytest process's own context make every kernel launch crawl (device time-slicing), so the
     6-rank (4 neighbours) and 7-rank (four empty ranks) runs of the same jobs live in
     tools/shard_loop.sh, where they take 4 s each."""
     assert os.path.exists(FAKE), "run __graft_entry__.build()"
-    out = _torchrun(world, [os.path.join(ROOT, "tests", "sharded_worker.py"), spec, str(tmp_path), str(overlap)], {})
+    out = _torchrun(world, [os.path.join(ROOT, "tests", "sharded_worker.py"), spec, str(tmp_path), str(overlap)],
+                    fake_rccl_env(fake_mode))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert (ASYNC_BANNER in out.stderr) == (fake_mode == "async")
     if spec.startswith("fuzz:"):
         from tests import fuzz
         job = fuzz.random_job(int(spec[5:]))
@@ -86,16 +92,19 @@ def test_sharded_solve_matches_oracle(built_libs, oracle, tmp_path, world, overl
     assert all(r[2] > 0 for r in rows if r[1] > r[0])     # every rank that owns rows has a halo
 
 
-@pytest.mark.parametrize("n,world,p2p", [(100, 2, False), (100, 4, False), (100, 2, True), (148, 2, False), (148, 3, True)])
-def test_sharded_bench_mode_against_the_oracle_fixture(built_libs, tmp_path, n, world, p2p):
+@pytest.mark.parametrize("n,world,p2p,mode", [(100, 2, False, "sync"), (100, 2, False, "async"), (100, 4, False, "async"),
+                                              (100, 2, True, "sync"), (148, 2, False, "sync"), (148, 2, False, "async"),
+                                              (148, 3, True, "async")])
+def test_sharded_bench_mode_against_the_oracle_fixture(built_libs, tmp_path, n, world, p2p, mode):
     """BASELINE config 4 in miniature: the rows of the 100^3 cube (config 2's size, 3 M DOF) and of the 148^3 cube (the
     headline's 10 M DOF) partitioned over 2 / 3 / 4 ranks -- here all on the one GPU, over the test transport, RCCL-shaped
     exchanges and peer-to-peer mailboxes -- in bench mode (merit stop off, 1e-8) against the ORACLE's committed answer
     (tests/golden/bench_mode_<n>.npz): iterations within 2,
-    max |dU| / max |U| <= 1e-9 at the 4096 sampled DOFs, the norms; every rank returns the same bits."""
+    max |dU| / max |U| <= 1e-9 at the 4096 sampled DOFs, the norms; every rank returns the same bits.  mode: the
+    stand-in's synchronous or stream-ordered form (the peer-to-peer legs use it for set-up and the gather only)."""
     g = np.load(os.path.join(ROOT, "tests", "golden", "bench_mode_%d.npz" % n))
     args = [os.path.join(ROOT, "tests", "sharded_worker.py"), "bench:%d" % n, str(tmp_path), "1"] + (["p2p"] if p2p else [])
-    out = _torchrun(world, args, {"GPU_MAX_HW_QUEUES": str(2 * world + 4)} if p2p else {})
+    out = _torchrun(world, args, dict(fake_rccl_env(mode), **({"GPU_MAX_HW_QUEUES": str(2 * world + 4)} if p2p else {})))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     r0 = np.load(os.path.join(str(tmp_path), "rank0.npz"))
     um = float(g["u_max"])
@@ -108,6 +117,60 @@ def test_sharded_bench_mode_against_the_oracle_fixture(built_libs, tmp_path, n, 
         assert abs(np.sqrt(d["U"] @ d["U"]) - float(g["u_l2"])) <= 1e-9 * float(g["u_l2"])
         assert np.array_equal(d["U"], r0["U"])
         assert d["rows"][2] > 0                                  # a halo on every rank
+
+
+@pytest.mark.parametrize("world,spec", [(3, "12"), (4, "fuzz:124")])
+def test_the_two_modes_of_the_stand_in_give_the_same_bits(built_libs, tmp_path, world, spec):
+    """the sharded solve over the synchronous stand-in and over the stream-ordered one -- fp64,
+    fp32 copy, FIXED-48, the refinement passes of sharded_worker.py -- returns IDENTICAL bits on every rank: both add
+    the ranks' partials in rank order, and the product orders its streams itself instead of leaning on the host
+    drains of the synchronous mode."""
+    res = {}
+    for mode in ("sync", "async"):
+        d = tmp_path / mode
+        d.mkdir()
+        out = _torchrun(world, [os.path.join(ROOT, "tests", "sharded_worker.py"), spec, str(d), "1"], fake_rccl_env(mode))
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+        assert (ASYNC_BANNER in out.stderr) == (mode == "async")
+        res[mode] = [np.load(str(d / ("rank%d.npz" % r))) for r in range(world)]
+    for a, b in zip(res["sync"], res["async"]):
+        assert int(a["its"]) == int(b["its"]) and int(a["its_x"]) == int(b["its_x"]) and int(a["term"]) == int(b["term"])
+        for k in ("U", "Um", "Ux"):
+            assert np.array_equal(a[k], b[k]), k
+
+
+def test_the_asynchronous_stand_in_catches_a_missing_stream_wait(built_libs, tmp_path):
+    """The point of the asynchronous mode, shown on a DELIBERATELY BROKEN library (stan_amd/csrc/lab/
+    drop_overlap_wait.patch -> build_broken/libstan_hip_no_overlap_wait.so: cg.hip's boundary product no longer waits
+    for the interior product on the side stream, `hipStreamWaitEvent(st_, ev_b)` dropped).  Over the synchronous
+    stand-in the host-staged halo exchange takes longer than the interior product, so the broken library passes the
+    oracle fixture like the good one; over the stream-ordered stand-in the boundary product (and the fold of the
+    interior launch's partials) overtakes the interior product and the solve no longer reproduces the fixture.  The
+    GOOD library passes under both (test_sharded_bench_mode_against_the_oracle_fixture)."""
+    broken = os.path.join(ROOT, "stan_amd", "csrc", "build_broken", "libstan_hip_no_overlap_wait.so")
+    assert os.path.exists(broken), "make -C stan_amd/csrc broken"
+    g = np.load(os.path.join(ROOT, "tests", "golden", "bench_mode_100.npz"))
+    um = float(g["u_max"])
+    verdict = {}
+    for mode in ("sync", "async"):
+        d = tmp_path / mode
+        d.mkdir()
+        try:     # (its fixture run takes 900 iterations; a loop that lost its way ends at 3000 with type 5)
+            out = _torchrun(2, [os.path.join(ROOT, "tests", "sharded_worker.py"), "bench:100", str(d), "1"],
+                            dict(fake_rccl_env(mode), STAN_HIP_LIB=broken, SHARDED_WORKER_MAXITS="3000"),
+                            timeout=200, attempts=1)
+            ok = out.returncode == 0
+        except subprocess.TimeoutExpired:
+            ok = False
+        if ok:
+            for r in range(2):
+                x = np.load(str(d / ("rank%d.npz" % r)))
+                ok = ok and int(x["term"]) == 1 and abs(int(x["its"]) - int(g["iterations"])) <= 2 \
+                    and bool(np.abs(x["U"][g["idx"]] - g["U"]).max() <= 1e-9 * um)
+        verdict[mode] = ok
+        print("broken library over the %s stand-in: %s" % (mode, "passes the fixture" if ok else "CAUGHT"))
+    assert verdict["sync"], "the synchronous stand-in was expected to hide the missing wait"
+    assert not verdict["async"], "the asynchronous stand-in did not expose the missing wait"
 
 
 @pytest.mark.parametrize("world,spec", [(2, "12"), (3, "12"), (4, "fuzz:124")])

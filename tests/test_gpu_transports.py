@@ -12,6 +12,7 @@ import pytest
 
 from stan_amd import problem
 from stan_amd.cube import cube_mesh, revolved_mesh
+from tests.conftest import fake_rccl_env
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,9 +25,10 @@ OPT_FOLD = 19
 OPT_SELL_SIGMA, OPT_MERIT = 17, 1
 
 
-def _p2p_run(tmp_path, spec, nranks, wait_mode=None):
+def _p2p_run(tmp_path, spec, nranks, wait_mode=None, fake_mode="sync"):
     out = str(tmp_path / "p2p.npz")
-    env = dict(os.environ, STAN_RCCL_LIB=FAKE, GPU_MAX_HW_QUEUES=str(2 * nranks + 4))
+    env = dict(os.environ, STAN_RCCL_LIB=FAKE, **fake_rccl_env(fake_mode))
+    env["GPU_MAX_HW_QUEUES"] = str(2 * nranks + 4)
     if wait_mode is not None:
         env["STAN_P2P_WAIT_MODE"] = str(wait_mode)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "p2p_worker.py"), spec, str(nranks), out],
@@ -35,17 +37,20 @@ def _p2p_run(tmp_path, spec, nranks, wait_mode=None):
     return np.load(out)
 
 
-@pytest.mark.parametrize("spec,nranks,wait_mode", [("12", 2, None), ("12", 3, None), ("perf:10:0.3", 4, None), ("3", 4, None),
-                                                   ("12", 3, 0), ("12", 3, 2), ("perf:10:0.3", 4, 2)])
-def test_peer_to_peer_exchanges_give_the_bits_of_the_rccl_path(built_libs, tmp_path, spec, nranks, wait_mode):
+@pytest.mark.parametrize("spec,nranks,wait_mode,fake_mode",
+                         [("12", 2, None, "sync"), ("12", 3, None, "sync"), ("perf:10:0.3", 4, None, "sync"), ("3", 4, None, "sync"),
+                          ("12", 3, 0, "sync"), ("12", 3, 2, "sync"), ("perf:10:0.3", 4, 2, "sync"),
+                          ("12", 3, None, "async"), ("perf:10:0.3", 4, None, "async"), ("3", 4, None, "async")])
+def test_peer_to_peer_exchanges_give_the_bits_of_the_rccl_path(built_libs, tmp_path, spec, nranks, wait_mode, fake_mode):
     """STAN_OPT_COMM_P2P: the sharded CG's reductions and halo exchanges without one collective launch
     (mailboxes + arrival counters + stream waits, p2p.hip).  The partials are added in rank order, like
     the stand-in transport's all-reduce: U, the iteration count and the termination code are IDENTICAL,
     classic and single-reduction loop, fp64 and FIXED-48 stream, a MaxIts stop inside a refresh cycle,
     folded and unfolded reductions; "3" on 4 ranks = three ranks own no rows.  wait_mode: how a stream waits for
     an arrival count (STAN_P2P_WAIT_MODE): default a one-wave polling kernel, 0 hipStreamWaitValue64, 2 the
-    reductions are polled by the consuming kernel itself (no wait launch for them at all)."""
-    d = _p2p_run(tmp_path, spec, nranks, wait_mode)
+    reductions are polled by the consuming kernel itself (no wait launch for them at all).  fake_mode "async": the
+    RCCL-shaped legs run over the stream-ordered stand-in -- the same bits again."""
+    d = _p2p_run(tmp_path, spec, nranks, wait_mode, fake_mode)
     for loop in ("classic", "sr"):
         for prec in ("f64", "fx48", "cap"):
             a, b = "rccl_%s_%s" % (loop, prec), "p2p_%s_%s" % (loop, prec)

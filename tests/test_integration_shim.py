@@ -232,3 +232,51 @@ def test_shim_uses_only_members_the_reference_declares():
         assert m in {"NodeLib", "ElemLib", "MatLib", "nDOF"}, m
     for m in set(re.findall(r"\bAnalysisLib\.(\w+)", shim)):
         assert m in {"GetLinSolverTolerance", "GetLinSolverMaxIter"}, m
+
+
+def _method_body(text, name):
+    m = re.search(r"public\s+[\w\.\[\]<>]+\s+%s\s*\(" % name, text)
+    i = text.index("{", m.end())
+    depth, j = 1, i + 1
+    while depth:
+        depth += {"{": 1, "}": -1}.get(text[j], 0)
+        j += 1
+    return text[i:j]
+
+
+def _console_literals(body):
+    """The string literals of every Console.Write / Console.WriteLine call of a method body, in order."""
+    out = []
+    for m in re.finditer(r"Console\.Write(?:Line)?\s*\(", body):
+        depth, i = 1, m.end()
+        while depth:
+            depth += {"(": 1, ")": -1}.get(body[i], 0)
+            i += 1
+        out += re.findall(r'"((?:[^"\\]|\\.)*)"', body[m.end():i - 1])
+    return out
+
+
+# what the two hot methods of the reference print, literal by literal (SolverFunctions.cs:127, 177; :273, 323-327)
+CONSOLE_REF = {
+    "ParallelAssembly_K": ["   K Matrix assembly: ", "          Done in ", "F2", "s"],
+    "LinearSolver_CG": ["   Solving linear system...   ", "  NORMAL ", "  ERROR ", " (type ", ")", " in ", "F2", "s"],
+}
+
+
+def test_the_shim_prints_the_reference_console_lines_literal_by_literal():
+    """`integration/SolverFunctions.Hip.cs` printed " (type N, M iterations)" where the reference
+    prints " (type N)" (SolverFunctions.cs:325).  Every Console.Write* literal of the two replaced methods is compared
+    with the reference's -- against the list above everywhere, and against the reference's own source where the
+    checkout is present (this container; the GPU box has none)."""
+    shim = _strip_c_comments(open(SHIM2).read())
+    for name, want in CONSOLE_REF.items():
+        assert _console_literals(_method_body(shim, name)) == want, name
+    if os.path.isdir(REF):
+        ref = _strip_c_comments(open(os.path.join(REF, "STAN_Solver", "SolverFunctions.cs"), encoding="utf-8-sig").read())
+        for name, want in CONSOLE_REF.items():
+            assert _console_literals(_method_body(ref, name)) == want, name
+    # the native console driver (stan_amd/host/solver_functions.cpp) prints the same text through printf
+    cpp = open(os.path.join(ROOT, "stan_amd", "host", "solver_functions.cpp")).read()
+    for lit in ('"   K Matrix assembly: "', '"          Done in %.2fs\\n"', '"   Solving linear system...   "',
+                '"  NORMAL "', '"  ERROR "', '" (type %d) in %.2fs\\n"'):
+        assert lit in cpp, lit
