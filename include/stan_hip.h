@@ -419,7 +419,9 @@ int stan_hip_ke_hex8_batch(stan_ctx *ctx, int64_t n, const double *xyz8, double 
  * ascending -- what alglib.sparseconverttocrs holds (SolverFunctions.cs:275).
  * upper_only=1: only col >= row (the reference's storage).  Two-call protocol: pass
  * rowptr=col=val=NULL to get *nnz, then call again with buffers [N+1],[nnz],[nnz].
- * Single-rank contexts only. */
+ * The export never changes the matrix.  Before the first solve the values are the assembled bits; a solve
+ * keeps K in its scaled form S K S, after which the export divides by s_row s_col on the way out: every
+ * value within 1 ulp of the assembled one, the pattern identical.  Single-rank contexts only. */
 int stan_hip_matrix_to_csr(stan_ctx *ctx, stan_matrix *K, int32_t upper_only, int64_t *nnz,
                            int64_t *rowptr, int32_t *col, double *val);
 
@@ -444,6 +446,13 @@ int stan_hip_spmv(stan_ctx *ctx, stan_matrix *K, const double *x, double *y);
  * Returns average milliseconds per launch. */
 int stan_hip_spmv_bench(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode, int32_t reps,
                         double *avg_ms);
+
+/* The yardstick of that roofline: `reps` read-only sweeps over K's resident fp64 values in the product's own access
+ * pattern (one wavefront per slice, XCD-chunked mapping, non-temporal loads) with nothing else -- no columns, no gather,
+ * no product vector.  avg_ms per sweep, *bytes = what one sweep reads (n_slots * 64 * 72).  bytes / avg_ms is what
+ * THIS device's memory system gives a sweep of THIS block: the product's rate can be read against it
+ * (bench.py: roofline.stream_GBs, frac_of_stream).  Single-rank contexts only. */
+int stan_hip_stream_bench(stan_ctx *ctx, stan_matrix *K, int32_t reps, double *avg_ms, int64_t *bytes);
 
 /* (The scalar-CSR comparison kernel of round 1, stan_hip_csr_spmv_bench, is a lab aid and lives in
  * the lab build only: stan_amd/csrc/lab/stan_hip_lab.h, `make -C stan_amd/csrc lab`.) */

@@ -154,6 +154,7 @@ namespace STAN_Solver
         [DllImport(Lib)] internal static extern int stan_hip_spmv_local(IntPtr ctx, IntPtr K, double[] x_local, [Out] double[] y_owned);
         [DllImport(Lib)] internal static extern int stan_hip_spmv(IntPtr ctx, IntPtr K, double[] x, [Out] double[] y);
         [DllImport(Lib)] internal static extern int stan_hip_spmv_bench(IntPtr ctx, IntPtr K, int precision_mode, int reps, out double avg_ms);
+        [DllImport(Lib)] internal static extern int stan_hip_stream_bench(IntPtr ctx, IntPtr K, int reps, out double avg_ms, out long bytes);
         [DllImport(Lib)] internal static extern int stan_hip_set_profiling(IntPtr ctx, int enabled);
         [DllImport(Lib)] internal static extern int stan_hip_get_profile(IntPtr ctx, out StanProfile profile);
         [DllImport(Lib)] internal static extern int stan_hip_get_profile_rank(IntPtr ctx, int rank, out StanProfile profile);

@@ -476,11 +476,25 @@ int recover_keep_one(stan_ctx *ctx, int64_t n_nodes, const double *xyz, const do
     // plain device memory, owned by the results object (it may outlive the context's pool)
     double *de = nullptr, *ds = nullptr;
     const size_t bytes = (size_t)(n_elem > 0 ? n_elem : 1) * 48 * 8;
-    if (hipMalloc((void **)&de, bytes) != hipSuccess || hipMalloc((void **)&ds, bytes) != hipSuccess) {
+    auto both = [&]() {
+        if (hipMalloc((void **)&de, bytes) == hipSuccess && hipMalloc((void **)&ds, bytes) == hipSuccess) return true;
         (void)hipGetLastError();
         if (de) hipFree(de);
-        ctx->err = "recover_hex8_keep: device allocation failed";
-        return STAN_E_ALLOC;
+        de = ds = nullptr;
+        return false;
+    };
+    if (!both()) {
+        // the context's pool may hold most of the device parked (stan_solver lets it: STAN_OPT_POOL_MAX_BYTES = -1) while K
+        // and the CG's vectors are still live: give the parked blocks back -- what stan_dmalloc_bytes does for a pooled
+        // request -- and try once more (400^3 keeps 49 GB of results)
+        if (!ctx->pool.avail.empty() && hipStreamSynchronize(ctx->stream) == hipSuccess) {
+            ctx->pool.flush();
+            (void)both();
+        }
+        if (!de) {
+            ctx->err = "recover_hex8_keep: device allocation of 2 x " + std::to_string(bytes) + " B failed";
+            return STAN_E_ALLOC;
+        }
     }
     int rc = stan_recover_device(ctx, n_nodes, dx.p, du.p, n_elem, dc.p, dm.p, dt.p, n_mat, mat_E_nu, de, ds, nullptr, nullptr, nullptr);
     if (rc == STAN_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = STAN_E_HIP;
@@ -666,10 +680,11 @@ int stan_hip_matrix_to_csr(stan_ctx *ctx, stan_matrix *K, int32_t upper_only, in
     STAN_NO_GROUP(ctx, "matrix_to_csr");
     if (ctx->nranks != 1) { ctx->err = "matrix_to_csr: single-rank contexts only"; return STAN_E_UNSUPPORTED; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    // export K itself, not S K S: the values are divided by s_row s_col on the way out.  The matrix is brought into its
-    // scaled form first if no solve has done so, so that every export of a matrix takes the same path and yields the
-    // same bits (within 1 ulp of the assembled entry: (a t) / t).
-    STANCHK(stan_matrix_ensure_scaled(ctx, K));
+    // export K itself, not S K S.  A matrix no solve has scaled yet is exported AS ASSEMBLED -- the exact bits, and the
+    // export changes nothing (round 5 scaled it here as a side effect, which also cost the next solve its lazy-scaling
+    // first product: ADVICE r05).  Once a solve has brought it into its scaled form, the values are divided by
+    // s_row s_col on the way out: within 1 ulp of the assembled entry ((a t) / t), the matrix again untouched.
+    const bool scaled = K->scaled;
     const int64_t nloc = K->nloc;
     std::vector<double> scale((size_t)3 * (size_t)K->nslices * 64);
     std::vector<int32_t> slot_ptr((size_t)K->nslices + 1), rowlen((size_t)K->nslices * 64),
@@ -682,7 +697,7 @@ int stan_hip_matrix_to_csr(stan_ctx *ctx, stan_matrix *K, int32_t upper_only, in
     if (!cols.empty()) HIPCHK(ctx, hipMemcpyAsync(cols.data(), K->d_cols, cols.size() * 4, hipMemcpyDeviceToHost, st));
     if (!vals.empty()) HIPCHK(ctx, hipMemcpyAsync(vals.data(), K->d_vals, vals.size() * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(red.data(), K->d_red, red.size() * 4, hipMemcpyDeviceToHost, st));
-    if (!scale.empty()) HIPCHK(ctx, hipMemcpyAsync(scale.data(), K->d_scale, scale.size() * 8, hipMemcpyDeviceToHost, st));
+    if (scaled && !scale.empty()) HIPCHK(ctx, hipMemcpyAsync(scale.data(), K->d_scale, scale.size() * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     int64_t count = 0;
     for (int pass = 0; pass < 2; pass++) {
@@ -704,7 +719,8 @@ int stan_hip_matrix_to_csr(stan_ctx *ctx, stan_matrix *K, int32_t upper_only, in
                         if (upper_only && dc < d) continue;
                         if (pass == 1) {
                             col[q] = (int32_t)(dc - red[dc]);
-                            val[q] = vals[(slot * 9 + 3 * m + n) * 64 + lane] / (scale[(size_t)d] * scale[(size_t)dc]);
+                            const double a = vals[(slot * 9 + 3 * m + n) * 64 + lane];
+                            val[q] = scaled ? a / (scale[(size_t)d] * scale[(size_t)dc]) : a;
                         }
                         q++;
                     }
@@ -787,6 +803,13 @@ int stan_hip_spmv_bench(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode, i
     STAN_NO_GROUP(ctx, "spmv_bench");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return stan_spmv_bench_device(ctx, K, precision_mode, reps, avg_ms);
+}
+
+int stan_hip_stream_bench(stan_ctx *ctx, stan_matrix *K, int32_t reps, double *avg_ms, int64_t *bytes) {
+    if (!ctx || !K || !avg_ms || !bytes || reps <= 0 || K->ctx != ctx) return STAN_E_ARG;
+    STAN_NO_GROUP(ctx, "stream_bench");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return stan_stream_bench_device(ctx, K, reps, avg_ms, bytes);
 }
 
 }  // extern "C"

@@ -1391,6 +1391,32 @@ int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode
     return STAN_OK;
 }
 
+// `reps` sweeps of k_value_stream over K's resident fp64 values (see the kernel): average ms per sweep and the bytes one
+// sweep reads (the slots' values: padded slots are streamed like real ones, as the product streams them).
+int stan_stream_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t reps, double *avg_ms, int64_t *bytes) {
+    hipStream_t st_ = ctx->stream;
+    *avg_ms = 0;
+    *bytes = (int64_t)K->nslots * 64 * 72;
+    if (K->nslices <= 0 || !K->d_vals) return STAN_OK;
+    const unsigned grid = nblk(K->nslices, 4);
+    dev_bufs bufs;
+    double *sink;
+    STANCHK(alloc(ctx, bufs, &sink, (size_t)grid));
+    event_bag events;
+    hipEvent_t a = events.make(), b = events.make();
+    auto one = [&]() { hipLaunchKernelGGL(k_value_stream, dim3(grid), dim3(256), 0, st_, K->nslices, K->d_slot_ptr, K->d_vals, sink); };
+    for (int i = 0; i < 3; i++) one();
+    hipEventRecord(a, st_);
+    for (int i = 0; i < reps; i++) one();
+    hipEventRecord(b, st_);
+    HIPCHK(ctx, hipEventSynchronize(b));
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    *avg_ms = ms / reps;
+    HIPCHK(ctx, hipGetLastError());
+    return STAN_OK;
+}
+
 // Time of the fp64 SpMV of K streaming its values from `vals` (any contents: only the addresses
 // matter), median of 3 launches after a warm-up.  Used by the allocation-by-trial of placement.hip.
 // self_pair: the gather vector and the product are carved out of the FRONT of the candidate block

@@ -364,6 +364,7 @@ int stan_spmv_reduced(stan_ctx *ctx, stan_matrix *K, const double *d_x, double *
 int stan_matrix_diagonal(stan_ctx *ctx, stan_matrix *K, double *d_diag);
 int stan_spmv_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t precision_mode, int32_t reps,
                            double *avg_ms);
+int stan_stream_bench_device(stan_ctx *ctx, stan_matrix *K, int32_t reps, double *avg_ms, int64_t *bytes);
 int stan_spmv_local(stan_ctx *ctx, stan_matrix *K, const double *d_x, double *d_y);
 int stan_matrix_make_fp32(stan_ctx *ctx, stan_matrix *K);
 // ---- fold.hip -------------------------------------------------------------------------------

@@ -42,7 +42,7 @@ EXPORTS = [
     "stan_hip_set_stream", "stan_hip_comm_unique_id", "stan_hip_comm_init",
     "stan_hip_assemble_hex8", "stan_hip_assemble_hex8_dev", "stan_hip_matrix_free",
     "stan_hip_cg_solve", "stan_hip_cg_solve_dev", "stan_hip_matrix_info", "stan_hip_ke_hex8",
-    "stan_hip_ke_hex8_batch", "stan_hip_matrix_to_csr", "stan_hip_spmv", "stan_hip_spmv_bench",
+    "stan_hip_ke_hex8_batch", "stan_hip_matrix_to_csr", "stan_hip_spmv", "stan_hip_spmv_bench", "stan_hip_stream_bench",
     "stan_hip_set_profiling", "stan_hip_get_profile", "stan_hip_set_option", "stan_hip_recover_hex8", "stan_hip_recover_hex8_dev",
     "stan_hip_nodal_forces_hex8", "stan_hip_pool_info",
     "stan_hip_matrix_plan", "stan_hip_spmv_local", "stan_hip_comm_info", "stan_hip_comm_library",
@@ -472,6 +472,12 @@ class Matrix:
         self.ctx._chk(self.ctx.lib.stan_hip_csr_spmv_bench(self.ctx.h, self.k, C.c_int32(reps),
                                                            C.byref(ms), C.byref(nb), C.byref(diff)))
         return ms.value, nb.value, diff.value
+
+    def stream_bench(self, reps=20):
+        """(ms per read-only sweep of K's resident fp64 values in the product's access pattern, bytes per sweep)"""
+        ms, nb = C.c_double(0), C.c_int64(0)
+        self.ctx._chk(self.ctx.lib.stan_hip_stream_bench(self.ctx.h, self.k, C.c_int32(reps), C.byref(ms), C.byref(nb)))
+        return ms.value, nb.value
 
     def spmv_bench(self, reps=20, precision_mode=PREC_FP64):
         ms = C.c_double(0)

@@ -1,6 +1,8 @@
 // dof.cpp -- host-side integer steps around the GPU hot path (include/stan_host.h).
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -108,19 +110,33 @@ int AssignDofCore(int64_t n_nodes, int64_t n_elem, const int32_t *conn, int32_t 
     int64_t head = 0, tail = 0;
     queue[(size_t)tail++] = (int32_t)first;   // Database.cs:209-211; NextNode = Neighbors[FirstNode]
     state[(size_t)first].store(0, std::memory_order_relaxed);
-    // persistent workers for the wide levels (a thread per level would cost more than the level)
+    // persistent workers for the wide levels (a thread per level would cost more than the level).  Between the phases of
+    // one wide level a worker spins (yield) for the next phase; through a run of serial, narrow levels -- the first and last
+    // levels of a cube, every level of a slender mesh -- it PARKS on a condition variable after a bounded spin instead of
+    // burning a core per worker for the whole walk.
     struct Pool {
         int n;
         std::vector<std::thread> th;
-        std::atomic<int> phase{0}, arrived{0};
+        std::atomic<int> phase{0}, arrived{0}, sleepers{0};
         std::atomic<bool> quit{false};
+        std::mutex mu;
+        std::condition_variable cv;
         std::function<void(int)> job;
+        void wake() {   // (phase / quit were stored before this load: a worker either sees them or is counted here)
+            if (sleepers.load() > 0) { std::lock_guard<std::mutex> lk(mu); cv.notify_all(); }
+        }
         void run(const std::function<void(int)> &f) {   // f(t) on every worker, the caller is worker 0
             job = f;
             arrived.store(0, std::memory_order_relaxed);
-            phase.fetch_add(1, std::memory_order_release);
+            phase.fetch_add(1);
+            wake();
             f(0);
             while (arrived.load(std::memory_order_acquire) < n - 1) std::this_thread::yield();
+        }
+        void stop() {
+            quit.store(true);
+            wake();
+            for (std::thread &x : th) x.join();
         }
     } pool;
     pool.n = threads;
@@ -129,9 +145,14 @@ int AssignDofCore(int64_t n_nodes, int64_t n_elem, const int32_t *conn, int32_t 
             pool.th.emplace_back([&pool, t] {
                 int seen = 0;
                 for (;;) {
-                    while (pool.phase.load(std::memory_order_acquire) == seen) {
-                        if (pool.quit.load(std::memory_order_relaxed)) return;
-                        std::this_thread::yield();
+                    int spins = 0;
+                    while (pool.phase.load() == seen) {
+                        if (pool.quit.load()) return;
+                        if (++spins < 2000) { std::this_thread::yield(); continue; }
+                        std::unique_lock<std::mutex> lk(pool.mu);
+                        pool.sleepers.fetch_add(1);
+                        pool.cv.wait(lk, [&] { return pool.phase.load() != seen || pool.quit.load(); });
+                        pool.sleepers.fetch_sub(1);
                     }
                     seen++;
                     pool.job(t);
@@ -141,7 +162,7 @@ int AssignDofCore(int64_t n_nodes, int64_t n_elem, const int32_t *conn, int32_t 
     };
     std::vector<int64_t> cnt_t((size_t)threads + 1, 0);
     while (tail < n_nodes) {
-        if (head >= tail) { pool.quit.store(true); for (std::thread &x : pool.th) x.join(); return STAN_HOST_E_DISCONNECTED; }
+        if (head >= tail) { pool.stop(); return STAN_HOST_E_DISCONNECTED; }
         const int64_t l0 = head, l1 = tail;   // the level to scan
         if (threads <= 1 || l1 - l0 < par_min) {
             for (int64_t h = l0; h < l1; h++) {
@@ -199,8 +220,7 @@ int AssignDofCore(int64_t n_nodes, int64_t n_elem, const int32_t *conn, int32_t 
         });
         head = l1;
     }
-    pool.quit.store(true);
-    for (std::thread &x : pool.th) x.join();
+    pool.stop();
     par_ranges(n_nodes, threads, [&](int64_t a, int64_t b) { for (int64_t i = a; i < b; i++) node_index_out[queue[(size_t)i]] = (int32_t)i; });
     lap("breadth-first walk");
     if (node_dof_out)

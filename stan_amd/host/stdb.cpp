@@ -451,7 +451,16 @@ struct Sink {
     int fd = -1;
     char *map = nullptr;
     size_t map_len = 0;
+    bool sequential = false;   // the target cannot seek (a FIFO, /dev/stdout into a pipe, a socket): plain write calls, ONE writer, in order
     bool put(const char *p, size_t n, int64_t off) const {
+        if (sequential) {
+            while (n > 0) {
+                const ssize_t k = write(fd, p, n);
+                if (k < 0) { if (errno == EINTR) continue; return false; }
+                p += k; n -= (size_t)k;
+            }
+            return true;
+        }
         if (map) {
             if (off < 0 || (size_t)off + n > map_len) return false;   // (the bound is an upper bound: never)
             memcpy(map + off, p, n);
@@ -553,9 +562,14 @@ bool WriteStdb(const Database &db, const std::string &path, bool packed, std::st
     // Solver.cs:454-462 ExportOutput: FileMode.Create, overwrite.  Entries are streamed in chunks, so
     // the writer is not bound by protobuf-net's 2 GB MemoryStream; the chunks of a library are encoded
     // and written in parallel, each at its own offset (write_lib): the bytes are SerializeStdb's.
-    const int fd = open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+    int fd = open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);   // (a write-only special file)
     if (fd < 0) { if (err) *err = "cannot open " + path + " for writing"; return false; }
-    const int threads = HostThreads();
+    // Writing chunks at their offsets needs a file that can seek.  Anything else -- a FIFO, /dev/stdout into a pipe --
+    // gets the bytes the way round 4 wrote them: one writer, in order (pwrite fails there with ESPIPE).
+    struct stat sb;
+    const bool seekable = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
+    const int threads = seekable ? HostThreads() : 1;
     const Database::ResultView *rv = (db.results.disp || db.results.strain || db.results.fetch) ? &db.results : nullptr;
     // the small tail of the file first (its size is part of the bound)
     std::string tail;
@@ -569,9 +583,10 @@ bool WriteStdb(const Database &db, const std::string &path, bool packed, std::st
     }
     Sink sink;
     sink.fd = fd;
+    sink.sequential = !seekable;
     // STAN_STDB_WRITE=map: through a shared mapping (see Sink) when the file system has room for the bound
     const char *mode = getenv("STAN_STDB_WRITE");
-    if (mode && !strcmp(mode, "map")) {
+    if (seekable && mode && !strcmp(mode, "map")) {
         const size_t bound = max_lib_size(db.NodeLib.Items(), rv, threads) + max_lib_size(db.ElemLib.Items(), rv, threads) + tail.size() + 4096;
         struct statvfs vfs;
         const bool room = fstatvfs(fd, &vfs) == 0 && (double)vfs.f_bavail * (double)vfs.f_frsize > 1.05 * (double)bound;
@@ -586,7 +601,7 @@ bool WriteStdb(const Database &db, const std::string &path, bool packed, std::st
     ok = ok && sink.put(tail.data(), tail.size(), off);
     off += (int64_t)tail.size();
     if (sink.map) munmap(sink.map, sink.map_len);
-    if (ftruncate(fd, ok ? (off_t)off : 0) != 0) ok = false;   // the true length (a failed export leaves an empty file, not a padded one)
+    if (seekable && ftruncate(fd, ok ? (off_t)off : 0) != 0) ok = false;   // the true length (a failed export leaves an empty file, not a padded one)
     ok = (close(fd) == 0) && ok;
     if (!ok && err) *err = "short write to " + path;
     return ok;

@@ -7,8 +7,10 @@
 // real librccl.so.1.
 //
 // TWO MODES (round 6):
-//   * synchronous (default): every call drains the stream it is given and moves the data on the host.  A
-//     product-side ordering bug between the exchange and the kernels around it can hide behind those drains.
+//   * synchronous (default): every call drains the stream it is given and moves the data on the host.  What runs on
+//     ANOTHER stream (the interior product of the two-stream overlap) keeps running: the overlap is real, but its
+//     timing is the host's.  FAKE_RCCL_SYNC_DEVICE=1 drains the whole device instead -- a fully serialising
+//     transport, behind which a product-side ordering bug hides (tests/test_gpu_sharded.py shows it on a broken build).
 //   * FAKE_RCCL_ASYNC=1: ncclSend / ncclRecv / ncclAllReduce are ENQUEUED on the caller's stream like RCCL's --
 //     polling kernels + copy kernels on mailboxes in host-registered shared memory, arrival counters written by
 //     the stream itself; the host never waits.  What the product forgets to order (a missing
@@ -82,6 +84,9 @@ struct Comm {
     char *d_abox[MAXR][MAXR] = {};                     // device views, registered on first use
     unsigned long long a_sent[MAXR] = {}, a_recvd[MAXR] = {}, ar_calls = 0;
     long delay_us = 0;                                 // FAKE_RCCL_ASYNC_DELAY_US: a message's data lands late
+    bool sync_device = false;                          // FAKE_RCCL_SYNC_DEVICE: the synchronous mode drains the whole DEVICE
+    unsigned *d_tickets = nullptr;                     // device memory: 4096 workgroup tickets (a_ticket)
+    unsigned long long n_tickets = 0;
 };
 struct Op { int kind; const void *src; void *dst; size_t bytes; int peer; hipStream_t st; };  // 0 send 1 recv 2 bcast
 thread_local int g_depth = 0;
@@ -145,30 +150,59 @@ __device__ bool a_poll_ge(const Ctr *c, unsigned long long want, AHeader *h) {
     }
     return true;
 }
-// the stream waits until *c >= want; a receive also checks the size the sender recorded for that slot
-__global__ void k_a_wait(AHeader *h, const Ctr *c, unsigned long long want, const unsigned long long *size_word,
-                         unsigned long long size_want) {
-    if (threadIdx.x != 0) return;
-    if (a_poll_ge(c, want, h) && size_word && a_load(size_word) != size_want) a_store(&h->error.v, 2);
-}
-__global__ void k_a_copy(char *dst, const char *src, size_t bytes) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if ((((uintptr_t)dst | (uintptr_t)src | bytes) & 15) == 0) {
-        const size_t n = bytes / 16;
-        for (size_t i = t; i < n; i += stride) ((uint4 *)dst)[i] = ((const uint4 *)src)[i];
-    } else {
-        for (size_t i = t; i < bytes; i += stride) dst[i] = src[i];
+// One message, one kernel each side (as few launches between the product's kernels as RCCL has).
+// send: every workgroup waits until the pair's slot is free (the receiver has taken message k - ASLOTS), copies its share
+// into the mailbox; the LAST workgroup to finish (device-scope ticket) publishes size and count at system scope.
+__global__ void k_a_send(AHeader *h, const Ctr *cons, unsigned long long need_cons, char *box, const char *src, size_t bytes,
+                         Ctr *prod, unsigned long long new_prod, unsigned long long *size_word, unsigned *ticket) {
+    __shared__ int ok;
+    if (threadIdx.x == 0) ok = need_cons ? (int)a_poll_ge(cons, need_cons, h) : 1;
+    __syncthreads();
+    if (ok) {
+        const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if ((((uintptr_t)box | (uintptr_t)src | bytes) & 15) == 0)
+            for (size_t i = t; i < bytes / 16; i += stride) ((uint4 *)box)[i] = ((const uint4 *)src)[i];
+        else
+            for (size_t i = t; i < bytes; i += stride) box[i] = src[i];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {
+        __threadfence_system();
+        atomicExch(ticket, 0u);
+        a_store(size_word, (unsigned long long)bytes);
+        a_store(&prod->v, new_prod);
     }
 }
-// what came before on the stream is finished and visible to every agent; then the counter moves
-__global__ void k_a_set(Ctr *c, unsigned long long v, unsigned long long *size_word, unsigned long long size) {
+// recv: every workgroup waits for message k, checks its size, copies its share out; the last one marks the slot taken.
+// delay_us (FAKE_RCCL_ASYNC_DELAY_US): the data lands that much later -- a consumer that does not wait for the exchange
+// reads the old halo.
+__global__ void k_a_recv(AHeader *h, const Ctr *prod, unsigned long long need_prod, const unsigned long long *size_word,
+                         char *dst, const char *box, size_t bytes, Ctr *cons, unsigned *ticket, long delay_us) {
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        ok = (int)a_poll_ge(prod, need_prod, h);
+        if (ok && a_load(size_word) != (unsigned long long)bytes) { a_store(&h->error.v, 2); ok = 0; }
+        if (ok && delay_us > 0) {
+            const long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < delay_us * 100) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    if (ok) {
+        const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if ((((uintptr_t)box | (uintptr_t)dst | bytes) & 15) == 0)
+            for (size_t i = t; i < bytes / 16; i += stride) ((uint4 *)dst)[i] = ((const uint4 *)box)[i];
+        else
+            for (size_t i = t; i < bytes; i += stride) dst[i] = box[i];
+    }
     __threadfence_system();
-    if (size_word) a_store(size_word, size);
-    a_store(&c->v, v);
-}
-__global__ void k_a_spin(long us) {
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < us * 100) __builtin_amdgcn_s_sleep(8);
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {
+        __threadfence_system();
+        atomicExch(ticket, 0u);
+        a_store(&cons->v, need_prod);
+    }
 }
 // all-reduce number k of this communicator, whole: wait until slot k % ASLOTS is free on every rank, publish this
 // rank's values, wait for every rank's, add them IN RANK ORDER (what the synchronous mode and the product's
@@ -213,6 +247,9 @@ char *a_pair_box(Comm *c, int src, int dst) {   // device view of the pair's ASL
     }
     return c->d_abox[src][dst];
 }
+// a device-side ticket per enqueued message (the last workgroup of a copy publishes): a ring of zeroed counters, each
+// put back to zero by the workgroup that drew the last ticket; 4096 messages would have to be in flight for a clash
+unsigned *a_ticket(Comm *c) { return c->d_tickets + (c->n_tickets++ & 4095); }
 unsigned a_grid(size_t bytes) { size_t b = (bytes / 16 + 255) / 256; return (unsigned)(b < 1 ? 1 : b > 256 ? 256 : b); }
 
 int a_error(Comm *c, const char *where) {   // a device-side failure recorded so far?
@@ -233,13 +270,9 @@ int a_enqueue_p2p(Comm *c) {
         if (!box) return 2;
         const unsigned long long k = c->a_sent[o.peer]++;
         const int slot = (int)(k % ASLOTS);
-        if (k >= ASLOTS)
-            hipLaunchKernelGGL(k_a_wait, dim3(1), dim3(64), 0, o.st, d, &d->cons[c->rank][o.peer], k - ASLOTS + 1,
-                               (const unsigned long long *)nullptr, 0ULL);
-        hipLaunchKernelGGL(k_a_copy, dim3(a_grid(o.bytes)), dim3(256), 0, o.st, box + (size_t)slot * PAIRBOX,
-                           (const char *)o.src, o.bytes);
-        hipLaunchKernelGGL(k_a_set, dim3(1), dim3(1), 0, o.st, &d->prod[c->rank][o.peer], k + 1,
-                           &d->msg_bytes[c->rank][o.peer][slot], (unsigned long long)o.bytes);
+        hipLaunchKernelGGL(k_a_send, dim3(a_grid(o.bytes)), dim3(256), 0, o.st, d, &d->cons[c->rank][o.peer],
+                           k >= ASLOTS ? k - ASLOTS + 1 : 0ULL, box + (size_t)slot * PAIRBOX, (const char *)o.src, o.bytes,
+                           &d->prod[c->rank][o.peer], k + 1, &d->msg_bytes[c->rank][o.peer][slot], a_ticket(c));
     }
     for (const Op &o : g_ops) {
         if (o.kind != 1) continue;
@@ -247,13 +280,10 @@ int a_enqueue_p2p(Comm *c) {
         if (!box) return 2;
         const unsigned long long k = c->a_recvd[o.peer]++;
         const int slot = (int)(k % ASLOTS);
-        hipLaunchKernelGGL(k_a_wait, dim3(1), dim3(64), 0, o.st, d, &d->prod[o.peer][c->rank], k + 1,
-                           (const unsigned long long *)&d->msg_bytes[o.peer][c->rank][slot], (unsigned long long)o.bytes);
-        if (c->delay_us > 0) hipLaunchKernelGGL(k_a_spin, dim3(1), dim3(1), 0, o.st, c->delay_us);
-        hipLaunchKernelGGL(k_a_copy, dim3(a_grid(o.bytes)), dim3(256), 0, o.st, (char *)o.dst,
-                           (const char *)box + (size_t)slot * PAIRBOX, o.bytes);
-        hipLaunchKernelGGL(k_a_set, dim3(1), dim3(1), 0, o.st, &d->cons[o.peer][c->rank], k + 1,
-                           (unsigned long long *)nullptr, 0ULL);
+        hipLaunchKernelGGL(k_a_recv, dim3(a_grid(o.bytes)), dim3(256), 0, o.st, d, &d->prod[o.peer][c->rank], k + 1,
+                           (const unsigned long long *)&d->msg_bytes[o.peer][c->rank][slot], (char *)o.dst,
+                           (const char *)box + (size_t)slot * PAIRBOX, o.bytes, &d->cons[o.peer][c->rank], a_ticket(c),
+                           c->delay_us);
     }
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
@@ -273,6 +303,7 @@ int flush_group(Comm *c) {
         for (const Op &o : g_ops) hipStreamSynchronize(o.st);
         if ((rc = a_error(c, "before a broadcast group"))) return rc;
     }
+    if (c->sync_device) hipDeviceSynchronize();
     for (const Op &o : g_ops) hipStreamSynchronize(o.st);
     // point-to-point: all sends of the group first (one message in flight per ordered pair),
     // then the receives -- only the two peers of a message ever wait for each other
@@ -365,6 +396,8 @@ int ncclCommInitRank(void **comm, int nranks, nccl_uid id, int rank) {
     strncpy(c->name, id.internal, 63);
     const char *am = getenv("FAKE_RCCL_ASYNC");
     c->async = am && atoi(am) != 0;
+    const char *sd = getenv("FAKE_RCCL_SYNC_DEVICE");
+    c->sync_device = sd && atoi(sd) != 0;
     const size_t sync_bytes = page_up(sizeof(Header) + (size_t)nranks * MAILBOX + (size_t)nranks * nranks * PAIRBOX);
     c->bytes = sync_bytes + (c->async ? page_up(sizeof(AHeader)) + (size_t)nranks * nranks * ASLOTS * PAIRBOX : 0);
     int fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
@@ -386,6 +419,8 @@ int ncclCommInitRank(void **comm, int nranks, nccl_uid id, int rank) {
             return 2;
         }
         c->d_ah = (AHeader *)dp;
+        if (hipMalloc((void **)&c->d_tickets, 4096 * sizeof(unsigned)) != hipSuccess ||
+            hipMemset(c->d_tickets, 0, 4096 * sizeof(unsigned)) != hipSuccess) return 2;
         if (const char *e = getenv("FAKE_RCCL_ASYNC_DELAY_US")) c->delay_us = atol(e);
         if (rank == 0) fprintf(stderr, "fake_rccl: asynchronous mode (stream-ordered send / recv / all-reduce), %d ranks\n", nranks);
     }
@@ -410,6 +445,7 @@ int ncclCommDestroy(void *comm) {
             for (int b = 0; b < c->nranks; b++)
                 if (c->d_abox[a][b]) hipHostUnregister(c->abox + ((size_t)a * c->nranks + b) * ASLOTS * PAIRBOX);
         hipHostUnregister(c->ah);
+        hipFree(c->d_tickets);
     }
     if (c->rank == 0) shm_unlink(c->name);
     munmap((void *)c->h, c->bytes);
@@ -436,6 +472,7 @@ int ncclAllReduce(const void *send, void *recv, size_t count, int dt, int op, vo
                            (const unsigned long long *)send, (unsigned long long *)recv, (int)count, dt == 4 ? 1 : 0);
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
+    if (c->sync_device) hipDeviceSynchronize();
     hipStreamSynchronize(st);
     c->ncalls++;
     hipMemcpy(c->box + (size_t)c->rank * MAILBOX, send, bytes, hipMemcpyDeviceToHost);

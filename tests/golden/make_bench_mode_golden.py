@@ -67,7 +67,7 @@ def main():
                     help="threads of the oracle's matrix-vector product (1 = serial, what alglib does)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
-    import bench
+    import bench_legs as bench
     from oracle import pyoracle as O
     cores = min(8, bench.effective_cores())
     for name in args.jobs:

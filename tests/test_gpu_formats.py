@@ -80,6 +80,27 @@ def test_mixed_solve_after_spmv_bench_on_a_fresh_matrix(gpu_ctx, oracle):
     K.free(); K2.free()
 
 
+def test_value_stream_yardstick(gpu_ctx):
+    """stan_hip_stream_bench (round 6): a read-only sweep of K's resident fp64 values in the product's
+    own access pattern -- the yardstick bench.py prints next to the product's rate (`roofline.stream_GBs`).  It reads
+    n_slots * 64 * 72 bytes, leaves K untouched (the next product has the same bits), and at a size the caches cannot
+    hold (100^3: 1.9 GB) it is FASTER than the product that reads the same values plus columns and vectors -- the old
+    yardstick (torch.sum over 1 GiB, 5.4 TB/s) was slower than the product it was meant to bound."""
+    job = problem.cube_job(100)
+    K = gpu_ctx.assemble_hex8(job.xyz, job.node_dof, job.conn, job.elem_mat, job.elem_type, job.mat_E_nu, job.red)
+    x = np.random.default_rng(5).standard_normal(job.n_red)
+    y0 = K.spmv(x)
+    ms, nbytes = K.stream_bench(10)
+    assert nbytes == K.info()["n_slots"] * 64 * 72 and ms > 0
+    assert np.array_equal(K.spmv(x), y0)
+    ms_spmv = K.spmv_bench(10)
+    stream, product = nbytes / ms, nbytes / ms_spmv       # the product also moves columns and vectors: its own rate is higher than this
+    print("100^3: value stream %.3f ms = %.2f TB/s; product %.3f ms = %.2f TB/s on the same bytes" %
+          (ms, stream / 1e9, ms_spmv, product / 1e9))
+    assert ms < ms_spmv and 3.0e9 < stream < 8.0e9        # bytes per ms: 3 ... 8 TB/s
+    K.free()
+
+
 @pytest.mark.parametrize("n,prec,jit", [(20, "fp64", 0.05), (33, "fp64", 0.0), (24, "fixed48", 0.1), (24, "mixed", 0.05)])
 def test_packed_column_stream_gives_the_same_bits(gpu_ctx, n, prec, jit):
     """STAN_OPT_PACKED_COLUMNS: 16-bit column offsets from a per-slot base, two slots per dword --

@@ -264,7 +264,8 @@ def test_cg_fixed48_stream(gpu_ctx, oracle):
     gpu_ctx.set_option(hip.OPT_CG_MERIT_STOP, 0)   # converge both runs to the residual test
     try:
         K, A = _assemble_both(gpu_ctx, oracle, job)
-        vals_fresh = K.to_csr()[2]          # export BEFORE any solve
+        vals_fresh = K.to_csr()[2]          # export BEFORE any solve: the assembled bits, and K stays as assembled
+        assert K.info()["scaled"] == 0 and np.array_equal(K.to_csr()[2], vals_fresh)
         # at a tolerance the quantised entries can carry (7e-15 * kappa ~ 1e-10 in the residual) the iteration history is
         # the fp64 stream's and the fp64 check passes at once
         U64c, rep64c = K.cg_solve(job.F, 1e-9, 20000)
@@ -290,10 +291,12 @@ def test_cg_fixed48_stream(gpu_ctx, oracle):
     Uo, _ = oracle.cg(A, job.F, 1e-12)
     assert np.abs(U48 - Uo).max() <= 1e-6 * np.abs(Uo).max()
     assert K.spmv_bench(3, hip.PREC_FIXED48) > 0
-    # the fp64 values are untouched: the export after four solves is the export before them, bit for bit (round 5: an
-    # export divides the scaled values on its way out instead of un-scaling the matrix in place), and the oracle's matrix
+    # the fp64 values are untouched by four solves and by the exports: an export after them divides the scaled values on
+    # its way out ((a t) / t: within 1 ulp of the export before any solve, which is the assembled bits -- round 6), twice
+    # the same bits, and the oracle's matrix
     rowptr, cols, vals = K.to_csr()
-    assert np.array_equal(vals, vals_fresh)
+    assert np.abs(vals - vals_fresh).max() <= 2.3e-16 * np.abs(vals_fresh).max() and np.all(np.abs(vals - vals_fresh) <= 2.3e-16 * np.abs(vals_fresh))
+    assert np.array_equal(K.to_csr()[2], vals)
     assert np.abs(vals - A.vals).max() <= K_TOL * np.abs(A.vals).max()
     K.free()
 

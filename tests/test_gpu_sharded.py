@@ -139,38 +139,47 @@ def test_the_two_modes_of_the_stand_in_give_the_same_bits(built_libs, tmp_path, 
             assert np.array_equal(a[k], b[k]), k
 
 
-def test_the_asynchronous_stand_in_catches_a_missing_stream_wait(built_libs, tmp_path):
-    """The point of the asynchronous mode, shown on a DELIBERATELY BROKEN library (stan_amd/csrc/lab/
-    drop_overlap_wait.patch -> build_broken/libstan_hip_no_overlap_wait.so: cg.hip's boundary product no longer waits
-    for the interior product on the side stream, `hipStreamWaitEvent(st_, ev_b)` dropped).  Over the synchronous
-    stand-in the host-staged halo exchange takes longer than the interior product, so the broken library passes the
-    oracle fixture like the good one; over the stream-ordered stand-in the boundary product (and the fold of the
-    interior launch's partials) overtakes the interior product and the solve no longer reproduces the fixture.  The
-    GOOD library passes under both (test_sharded_bench_mode_against_the_oracle_fixture)."""
+def _broken_library_run(tmp_path, tag, n, env_extra):
+    """bench:<n> on 2 ranks with the library that lacks the stream wait; True = it still reproduces the oracle fixture."""
     broken = os.path.join(ROOT, "stan_amd", "csrc", "build_broken", "libstan_hip_no_overlap_wait.so")
     assert os.path.exists(broken), "make -C stan_amd/csrc broken"
-    g = np.load(os.path.join(ROOT, "tests", "golden", "bench_mode_100.npz"))
+    g = np.load(os.path.join(ROOT, "tests", "golden", "bench_mode_%d.npz" % n))
     um = float(g["u_max"])
-    verdict = {}
-    for mode in ("sync", "async"):
-        d = tmp_path / mode
-        d.mkdir()
-        try:     # (its fixture run takes 900 iterations; a loop that lost its way ends at 3000 with type 5)
-            out = _torchrun(2, [os.path.join(ROOT, "tests", "sharded_worker.py"), "bench:100", str(d), "1"],
-                            dict(fake_rccl_env(mode), STAN_HIP_LIB=broken, SHARDED_WORKER_MAXITS="3000"),
-                            timeout=200, attempts=1)
-            ok = out.returncode == 0
-        except subprocess.TimeoutExpired:
-            ok = False
-        if ok:
-            for r in range(2):
-                x = np.load(str(d / ("rank%d.npz" % r)))
-                ok = ok and int(x["term"]) == 1 and abs(int(x["its"]) - int(g["iterations"])) <= 2 \
-                    and bool(np.abs(x["U"][g["idx"]] - g["U"]).max() <= 1e-9 * um)
-        verdict[mode] = ok
-        print("broken library over the %s stand-in: %s" % (mode, "passes the fixture" if ok else "CAUGHT"))
-    assert verdict["sync"], "the synchronous stand-in was expected to hide the missing wait"
-    assert not verdict["async"], "the asynchronous stand-in did not expose the missing wait"
+    d = tmp_path / tag
+    d.mkdir()
+    try:     # (a loop that lost its way ends at 3000 iterations with type 5; the fixture runs take 900 / 1334)
+        out = _torchrun(2, [os.path.join(ROOT, "tests", "sharded_worker.py"), "bench:%d" % n, str(d), "1"],
+                        dict(env_extra, STAN_HIP_LIB=broken, SHARDED_WORKER_MAXITS="3000"), timeout=240, attempts=1)
+        ok = out.returncode == 0
+    except subprocess.TimeoutExpired:
+        ok = False
+    if ok:
+        for r in range(2):
+            x = np.load(str(d / ("rank%d.npz" % r)))
+            ok = ok and int(x["term"]) == 1 and abs(int(x["its"]) - int(g["iterations"])) <= 2 \
+                and bool(np.abs(x["U"][g["idx"]] - g["U"]).max() <= 1e-9 * um)
+    print("library without the stream wait, %d^3 on 2 ranks, %s: %s" % (n, tag, "passes the fixture" if ok else "CAUGHT"))
+    return ok
+
+
+def test_a_serialising_stand_in_hides_a_missing_stream_wait_and_the_stream_ordered_one_does_not(built_libs, tmp_path):
+    """VERDICT r05 item 1, shown on a DELIBERATELY BROKEN library (stan_amd/csrc/lab/drop_overlap_wait.patch ->
+    build_broken/libstan_hip_no_overlap_wait.so: cg.hip's boundary product and the vector kernels behind it no longer
+    wait for the interior product on the side stream -- `hipStreamWaitEvent(st_, ev_b)` dropped).
+      * Over a transport that drains the DEVICE at every call (FAKE_RCCL_SYNC_DEVICE=1: the fully serialising stand-in)
+        the interior product has always finished when the exchange returns: the broken library reproduces the oracle
+        fixture like the good one.  A suite that only ever ran over such a transport would never see the bug.
+      * Over the stream-ordered stand-in nothing orders the two streams but the product itself: at 148^3 on 2 ranks the
+        interior product (~0.5 ms) outlasts the enqueued exchange several times over, the boundary product and r' = r - a v
+        overtake it, and the solve no longer reproduces the fixture.
+    (The default synchronous stand-in drains only the stream it is given, so the side stream's product overlaps there
+    too -- with the host's timing: it caught this library at 100^3 in round 6's first run; what it catches depends on how
+    long the host-staged copies take.)  The GOOD library passes under every mode
+    (test_sharded_bench_mode_against_the_oracle_fixture, test_the_two_modes_of_the_stand_in_give_the_same_bits)."""
+    hidden = _broken_library_run(tmp_path, "device-draining", 148, dict(fake_rccl_env("sync"), FAKE_RCCL_SYNC_DEVICE="1"))
+    caught = not _broken_library_run(tmp_path, "stream-ordered", 148, fake_rccl_env("async"))
+    assert hidden, "a transport that drains the device was expected to hide the missing wait"
+    assert caught, "the stream-ordered stand-in did not expose the missing wait"
 
 
 @pytest.mark.parametrize("world,spec", [(2, "12"), (3, "12"), (4, "fuzz:124")])
@@ -205,6 +214,7 @@ def test_bench_multi_rank_code_path(built_libs):
     assert d["config"]["parallelism"] == "rows sharded x2" and d["roofline"]["launches"] > 0
     # round 3: a multi-GPU line explains itself -- transport, per-rank SpMV rates, exchange times per call
     assert "stand-in" in d["config"]["transport"] and "communicator of 2 ranks" in d["config"]["transport"]
+    assert "libfake_rccl.so" in d["config"]["transport"]      # round 6: the line names the FILE the RCCL entry points came from
     pr = d["roofline"]["per_rank"]
     assert len(pr["frac"]) == 2 and 0 < pr["frac_min"] <= pr["frac_max"]
     ex = d["config"]["exchange"]

@@ -319,3 +319,36 @@ def test_repeated_key_keeps_its_first_entry_also_on_the_parallel_index_build(bui
     late.assign_dof()
     ref.assign_dof()
     assert np.array_equal(late.flat()["node_dof"], ref.flat()["node_dof"])
+
+
+def test_export_into_a_pipe_writes_the_same_bytes(built_libs, tmp_path):
+    """the export writes its chunks at their offsets (pwrite) and cuts the file to length at the end, which a
+    target that cannot seek -- a FIFO, /dev/stdout into a pipe -- refuses (ESPIPE: "short write").  Such a target gets the
+    bytes from one writer, in order: a model with results (many chunks, four host threads) written into a FIFO arrives
+    byte for byte as the regular file does."""
+    import threading
+    import numpy as np
+    from stan_amd import host
+    from stan_amd.cube import cube_bcs, cube_mesh
+    n = 18          # 5832 elements: more than one chunk of 4096 entries per library
+    xyz, conn = cube_mesh(n)
+    d = host.Db()
+    ne = conn.shape[0]
+    d.set_mesh(np.arange(1, xyz.shape[0] + 1), xyz, np.arange(1, ne + 1), np.ones(ne), conn + 1, "HEX8_G2")
+    d.add_material(1, "Steel", 210000.0, 0.3); d.assign_part(1, 1, "HEX8_G2")
+    spc, ld, f = cube_bcs(n)
+    d.add_bc(1, "fix", "SPC", spc + 1, np.ones((len(spc), 3)))
+    d.add_bc(2, "load", "PointLoad", ld + 1, np.tile(f, (len(ld), 1)))
+    d.set_analysis(tol=1e-6)
+    rng = np.random.default_rng(5)
+    disp, strain, stress = rng.standard_normal((xyz.shape[0], 3)), rng.standard_normal((ne, 8, 6)), rng.standard_normal((ne, 8, 6))
+    plain = str(tmp_path / "file.STdb")
+    d.write_stdb_with_results(plain, disp, strain, stress)
+    fifo = str(tmp_path / "pipe.STdb")
+    os.mkfifo(fifo)
+    got = []
+    t = threading.Thread(target=lambda: got.append(open(fifo, "rb").read()))
+    t.start()
+    d.write_stdb_with_results(fifo, disp, strain, stress)
+    t.join(60)
+    assert not t.is_alive() and len(got[0]) > 4_000_000 and got[0] == open(plain, "rb").read()

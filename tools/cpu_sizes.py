@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch  # noqa
-import bench
+import bench_legs as bench
 from stan_amd import hip, problem
 sizes = [int(a) for a in sys.argv[1:]] or [24, 100]
 ctx = hip.Context(0)

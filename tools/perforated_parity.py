@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch  # noqa
-import bench
+import bench_legs as bench
 from stan_amd import hip, problem
 from oracle import pyoracle as O
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 120

@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/$OUT
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/$OUT/$C -o pmc -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu "$@" > $R/$OUT/bench_$C.json 2> $R/$OUT/bench_$C.err
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/$OUT/$C -o pmc -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu --no-secondary "$@" > $R/$OUT/bench_$C.json 2> $R/$OUT/bench_$C.err
 done
 cd $R
 python3 tools/pmc_summary.py $OUT
