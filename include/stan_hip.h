@@ -269,8 +269,12 @@ int stan_hip_set_stream(stan_ctx *ctx, void *hip_stream);
                            step, 4.7 s of hipMalloc per step; with the budget the assembly is 0.24 s, its kernels' time). */
 #define STAN_OPT_SPMV_VARIANT 3 /* SpMV kernel variant (cg.hip): -1 = auto (default: 9 for fp64/fp32 streams,
                            12 for FIXED-48), 0 = plain loads + identity mapping, 9 = non-temporal matrix
-                           stream + XCD-chunked workgroup mapping, 12 = 9 unrolled by 4.  Every accepted
-                           value computes the same product; anything else is STAN_E_ARG. */
+                           stream + XCD-chunked workgroup mapping, 12 = 9 unrolled by 4: these three add a row's
+                           products in the same order (same bits).  20 (round 6) = TWO wavefronts per slice
+                           (k_spmv_pair: the slots split at an even slot, the halves added in a fixed order): the
+                           same products summed in another order; +9 % at 60^3, +5 % at 80^3, nothing at 72^3 and
+                           100^3 (profiles/r06/spmv_pair_kernel_n60_n72_n80_n100.txt), so never chosen by -1.
+                           Anything else is STAN_E_ARG. */
 int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value);
 /* What STAN_OPT_POOL currently keeps: bytes and number of parked device blocks (either may be NULL). */
 int stan_hip_pool_info(stan_ctx *ctx, int64_t *bytes_parked, int64_t *blocks_parked);

@@ -155,7 +155,7 @@ int stan_hip_set_option(stan_ctx *ctx, int32_t option, int64_t value) {
     else if (option == STAN_OPT_PLACEMENT_TRIES && value >= 1 && value <= 64) ctx->placement_tries = (int)value;
     else if (option == STAN_OPT_PLACEMENT_MAX_BYTES && value >= 0) ctx->placement_max_bytes = value;
     else if (option == STAN_OPT_ROW_FOLDING && value >= -1 && value <= 1) ctx->row_folding = (int)value;
-    else if (option == STAN_OPT_SPMV_VARIANT && (value == -1 || value == 0 || value == 9 || value == 12))
+    else if (option == STAN_OPT_SPMV_VARIANT && (value == -1 || value == 0 || value == 9 || value == 12 || value == 20))
         ctx->spmv_variant = (int)value;
     else { ctx->err = "set_option: unknown option or bad value"; return STAN_E_ARG; }
     return STAN_OK;

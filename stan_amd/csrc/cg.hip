@@ -222,6 +222,8 @@ inline bool stan_small_system(const stan_ctx *ctx, const stan_matrix *K) {
     return ctx->spmv_variant < 0 && K->nb_glob <= ctx->spmv_small_rows;
 }
 
+inline bool stan_pair_kernel(const stan_ctx *ctx) { return ctx->spmv_variant == 20; }
+
 // the folded form of the value stream `vals` of K, if the products are to read it (fold.hip)
 template <typename VT> const VT *fold_vals(const stan_ctx *ctx, const stan_matrix *K, const VT *vals);
 template <> const double *fold_vals<double>(const stan_ctx *ctx, const stan_matrix *K, const double *vals) {
@@ -263,6 +265,16 @@ unsigned launch_spmv(stan_ctx *ctx, stan_matrix *K, const VT *vals, const double
         hipLaunchKernelGGL((k_spmv_small<VT, DOT>), dim3(grid_s), dim3(256), 0, stream, K->nslices, K->nloc,
                            K->d_slot_ptr, K->d_rowof, K->d_cols, vals, x, y, partial, st, k, slist, nlist, poff_s, fold, cs);
         return grid_s;
+    }
+    if (stan_pair_kernel(ctx)) {   // two wavefronts per slice, two slices per workgroup (k_spmv_pair; STAN_OPT_SPMV_VARIANT 20)
+        const int32_t poff_p = which == 2 ? (int32_t)nblk(K->n_sl_int, 2) : 0;
+        const unsigned grid_p = nblk(nlist, 2);
+        if (grid_p == 0) return 0;
+        fold.nblocks = grid_p;
+        fold.np = (int)grid_p + poff_p;
+        hipLaunchKernelGGL((k_spmv_pair<VT, DOT, true>), dim3(grid_p), dim3(256), 0, stream, K->nslices, K->nloc,
+                           K->d_slot_ptr, K->d_rowof, K->d_cols, vals, x, y, partial, st, k, slist, nlist, poff_p, fold, cs);
+        return grid_p;
     }
     const int32_t poff = which == 2 ? (int32_t)nblk(K->n_sl_int, 4) : 0;
     const unsigned grid = nblk(nlist, 4);
@@ -832,7 +844,9 @@ int cg_run::setup() {
         ctx->err = "cg: the peer-to-peer exchange of this context is broken (a peer rank failed earlier); start a fresh process";
         return STAN_E_COMM;
     }
-    if (p2p) ctx->defer_frees = true;   // no hipFree while the peers' streams wait for this rank's future exchanges (stan_ctx::defer_frees)
+    // no hipFree while the peers' streams wait for this rank's future exchanges (stan_ctx::defer_frees): peer to peer, and
+    // any transport when ranks of this process share the device
+    if (p2p || (dist && ctx->peers_share_device)) ctx->defer_frees = true;
     STANCHK(stan_cg_workspace(ctx, K));   // the context's vectors (the placement search probed with them)
     if (p2p) {
         // my neighbours write their boundary rows straight into these vectors: tell them where they are
@@ -879,7 +893,7 @@ int cg_run::setup() {
     xb[0] = ctx->ws.xb[0]; xb[1] = ctx->ws.xb[1]; p = ctx->ws.p; r = ctx->ws.r;
     v = ctx->ws.v; w = ctx->ws.w; bh = ctx->ws.bh;
     if (sr) sv = ctx->ws.sv;
-    const unsigned spmv_blocks = stan_small_system(ctx, K) ? (unsigned)K->nslices : nblk(K->nslices, 4);
+    const unsigned spmv_blocks = stan_small_system(ctx, K) ? (unsigned)K->nslices : nblk(K->nslices, stan_pair_kernel(ctx) ? 2 : 4);
     const size_t npart = 2 * (size_t)(spmv_blocks > VEC_BLOCKS ? spmv_blocks : VEC_BLOCKS) + 16;
     STANCHK(alloc(ctx, bufs, &partial, npart));
     STANCHK(alloc(ctx, bufs, &sc, (size_t)S_NSCAL));

@@ -227,6 +227,7 @@ struct stan_ctx {
     // every expectation of the stuck ranks met -- they sat in the hipFree of a temporary).  Blocks released
     // during such a solve are kept and freed when it has ended (stan_cg_device).
     bool defer_frees = false;
+    bool peers_share_device = false;   // group rank whose device also carries another rank of the process (multi.hip): frees deferred on every transport
     std::vector<void *> deferred;
     // solver options (include/stan_hip.h STAN_OPT_*)
     bool cg_merit_stop = true;

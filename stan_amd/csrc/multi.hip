@@ -237,6 +237,15 @@ extern "C" int stan_hip_init_multi(int n_devices, const int *devices, stan_ctx *
         return rc;
     }
     if (n_devices > 1) {
+        // Ranks of this process that SHARE a device (the test topology; a node gives every rank its own): hipFree waits for
+        // every stream of the device, i.e. also for the other ranks' queued collectives -- which, over a stream-ordered
+        // transport (RCCL; tests/fake_rccl in its asynchronous mode), wait for exchanges THIS rank has not enqueued yet.
+        // Such ranks keep their frees for the end of the solve on every transport (stan_ctx::defer_frees; round 6: config 4
+        // on 8 ranks of one GPU hung exactly there, rounds 3-5 knew the hazard from the peer-to-peer path only).
+        bool shared = false;
+        for (int a = 0; a < n_devices; a++)
+            for (int b = a + 1; b < n_devices; b++) shared |= g->devices[(size_t)a] == g->devices[(size_t)b];
+        for (stan_ctx *c : g->ctx) c->peers_share_device = shared;
         for (stan_ctx *c : g->ctx) c->result_segment = true;
         setup_p2p(g);
     }

@@ -18,7 +18,7 @@
 
 namespace {
 
-// Round 5 (profiles/r05/k_recover.md): the first form let each of the 8 lanes of an element load all 8 nodes' coordinates
+// Round 5 (profiles/r05/k_recover_n148_kernel_trace_summary_r05_final.txt): the first form let each of the 8 lanes of an element load all 8 nodes' coordinates
 // and displacements itself (56 gathers per lane) and store its 6 + 6 values 48 B apart: 1.73 ms at 148^3 for 3.2 GB =
 // 0.23 of the HBM peak, bound by the address pipeline.  Now lane i of an element loads node i only (7 gathers) and the
 // element's 48 values go round through LDS (one record per element, 49 doubles apart: no bank conflicts between the 8

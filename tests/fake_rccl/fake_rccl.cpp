@@ -84,6 +84,7 @@ struct Comm {
     char *d_abox[MAXR][MAXR] = {};                     // device views, registered on first use
     unsigned long long a_sent[MAXR] = {}, a_recvd[MAXR] = {}, ar_calls = 0;
     long delay_us = 0;                                 // FAKE_RCCL_ASYNC_DELAY_US: a message's data lands late
+    bool error_reported = false;
     bool sync_device = false;                          // FAKE_RCCL_SYNC_DEVICE: the synchronous mode drains the whole DEVICE
     unsigned *d_tickets = nullptr;                     // device memory: 4096 workgroup tickets (a_ticket)
     unsigned long long n_tickets = 0;
@@ -144,64 +145,41 @@ __device__ __forceinline__ void a_store(unsigned long long *p, unsigned long lon
 __device__ bool a_poll_ge(const Ctr *c, unsigned long long want, AHeader *h) {
     const long long t0 = wall_clock64(), bound = (long long)(STALL_S * 1e8);
     while (a_load(&c->v) < want) {
-        if (a_load(&h->abort.v)) return false;
+        if (a_load(&h->abort.v) || a_load(&h->error.v)) return false;   // aborted, or some wait of some rank ran out already
         if (wall_clock64() - t0 > bound) { a_store(&h->error.v, 1); return false; }
         __builtin_amdgcn_s_sleep(16);
     }
     return true;
 }
-// One message, one kernel each side (as few launches between the product's kernels as RCCL has).
-// send: every workgroup waits until the pair's slot is free (the receiver has taken message k - ASLOTS), copies its share
-// into the mailbox; the LAST workgroup to finish (device-scope ticket) publishes size and count at system scope.
-__global__ void k_a_send(AHeader *h, const Ctr *cons, unsigned long long need_cons, char *box, const char *src, size_t bytes,
-                         Ctr *prod, unsigned long long new_prod, unsigned long long *size_word, unsigned *ticket) {
-    __shared__ int ok;
-    if (threadIdx.x == 0) ok = need_cons ? (int)a_poll_ge(cons, need_cons, h) : 1;
-    __syncthreads();
-    if (ok) {
-        const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if ((((uintptr_t)box | (uintptr_t)src | bytes) & 15) == 0)
-            for (size_t i = t; i < bytes / 16; i += stride) ((uint4 *)box)[i] = ((const uint4 *)src)[i];
-        else
-            for (size_t i = t; i < bytes; i += stride) box[i] = src[i];
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {
-        __threadfence_system();
-        atomicExch(ticket, 0u);
-        a_store(size_word, (unsigned long long)bytes);
-        a_store(&prod->v, new_prod);
+// A message = a WAIT by ONE wavefront (stream-ordered: what follows on the stream starts when it ends) + a copy by many
+// workgroups, the last of which (device-scope ticket) publishes at system scope.  Never many workgroups that poll: eight
+// ranks sharing one device, each with two neighbours, would fill every CU with pollers and starve the very kernels they
+// wait for (round 6: the first fused form hung config 4 on 8 ranks that way).
+__global__ void k_a_wait(AHeader *h, const Ctr *c, unsigned long long want, const unsigned long long *size_word,
+                         unsigned long long size_want, long delay_us) {
+    if (threadIdx.x != 0) return;
+    if (!a_poll_ge(c, want, h)) return;
+    if (size_word && a_load(size_word) != size_want) { a_store(&h->error.v, 2); return; }
+    if (delay_us > 0) {   // FAKE_RCCL_ASYNC_DELAY_US: the data lands that much later -- a consumer that does not wait for
+        const long long t0 = wall_clock64();   // the exchange reads the old halo
+        while (wall_clock64() - t0 < delay_us * 100) __builtin_amdgcn_s_sleep(8);
     }
 }
-// recv: every workgroup waits for message k, checks its size, copies its share out; the last one marks the slot taken.
-// delay_us (FAKE_RCCL_ASYNC_DELAY_US): the data lands that much later -- a consumer that does not wait for the exchange
-// reads the old halo.
-__global__ void k_a_recv(AHeader *h, const Ctr *prod, unsigned long long need_prod, const unsigned long long *size_word,
-                         char *dst, const char *box, size_t bytes, Ctr *cons, unsigned *ticket, long delay_us) {
-    __shared__ int ok;
-    if (threadIdx.x == 0) {
-        ok = (int)a_poll_ge(prod, need_prod, h);
-        if (ok && a_load(size_word) != (unsigned long long)bytes) { a_store(&h->error.v, 2); ok = 0; }
-        if (ok && delay_us > 0) {
-            const long long t0 = wall_clock64();
-            while (wall_clock64() - t0 < delay_us * 100) __builtin_amdgcn_s_sleep(8);
-        }
-    }
-    __syncthreads();
-    if (ok) {
-        const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if ((((uintptr_t)box | (uintptr_t)dst | bytes) & 15) == 0)
-            for (size_t i = t; i < bytes / 16; i += stride) ((uint4 *)dst)[i] = ((const uint4 *)box)[i];
-        else
-            for (size_t i = t; i < bytes; i += stride) dst[i] = box[i];
-    }
+__global__ void k_a_copy_publish(AHeader *h, char *dst, const char *src, size_t bytes, Ctr *ctr, unsigned long long value,
+                                 unsigned long long *size_word, unsigned *ticket) {
+    if (a_load(&h->error.v) || a_load(&h->abort.v)) return;   // a failed wait in front of this copy: nothing is published
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((((uintptr_t)dst | (uintptr_t)src | bytes) & 15) == 0)
+        for (size_t i = t; i < bytes / 16; i += stride) ((uint4 *)dst)[i] = ((const uint4 *)src)[i];
+    else
+        for (size_t i = t; i < bytes; i += stride) dst[i] = src[i];
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {
         __threadfence_system();
         atomicExch(ticket, 0u);
-        a_store(&cons->v, need_prod);
+        if (size_word) a_store(size_word, (unsigned long long)bytes);
+        a_store(&ctr->v, value);
     }
 }
 // all-reduce number k of this communicator, whole: wait until slot k % ASLOTS is free on every rank, publish this
@@ -255,6 +233,8 @@ unsigned a_grid(size_t bytes) { size_t b = (bytes / 16 + 255) / 256; return (uns
 int a_error(Comm *c, const char *where) {   // a device-side failure recorded so far?
     const unsigned long long e = c->ah ? ((volatile Ctr *)&c->ah->error)->v : 0;
     if (!e) return 0;
+    if (c->error_reported) return 5;
+    c->error_reported = true;
     fprintf(stderr, "fake_rccl (async): rank %d, %s: %s\n", c->rank, where,
             e == 1 ? "a stream-ordered wait ran out (protocol mismatch or a rank that left)" : "message size mismatch");
     return 5;
@@ -263,6 +243,8 @@ int a_error(Comm *c, const char *where) {   // a device-side failure recorded so
 // send / receive of one group, enqueued: nothing here waits on the host
 int a_enqueue_p2p(Comm *c) {
     AHeader *d = c->d_ah;
+    int rc = a_error(c, "at an exchange");   // a device-side failure recorded so far ends the solve at its next call
+    if (rc) return rc;
     for (const Op &o : g_ops) {
         if (o.kind != 0) continue;
         if (o.bytes > PAIRBOX) { fprintf(stderr, "fake_rccl: message larger than the pair mailbox\n"); return 5; }
@@ -270,9 +252,12 @@ int a_enqueue_p2p(Comm *c) {
         if (!box) return 2;
         const unsigned long long k = c->a_sent[o.peer]++;
         const int slot = (int)(k % ASLOTS);
-        hipLaunchKernelGGL(k_a_send, dim3(a_grid(o.bytes)), dim3(256), 0, o.st, d, &d->cons[c->rank][o.peer],
-                           k >= ASLOTS ? k - ASLOTS + 1 : 0ULL, box + (size_t)slot * PAIRBOX, (const char *)o.src, o.bytes,
-                           &d->prod[c->rank][o.peer], k + 1, &d->msg_bytes[c->rank][o.peer][slot], a_ticket(c));
+        if (k >= ASLOTS)   // the slot is free once the receiver has taken message k - ASLOTS
+            hipLaunchKernelGGL(k_a_wait, dim3(1), dim3(64), 0, o.st, d, (const Ctr *)&d->cons[c->rank][o.peer], k - ASLOTS + 1,
+                               (const unsigned long long *)nullptr, 0ULL, 0L);
+        hipLaunchKernelGGL(k_a_copy_publish, dim3(a_grid(o.bytes)), dim3(256), 0, o.st, d, box + (size_t)slot * PAIRBOX,
+                           (const char *)o.src, o.bytes, &d->prod[c->rank][o.peer], k + 1,
+                           &d->msg_bytes[c->rank][o.peer][slot], a_ticket(c));
     }
     for (const Op &o : g_ops) {
         if (o.kind != 1) continue;
@@ -280,10 +265,12 @@ int a_enqueue_p2p(Comm *c) {
         if (!box) return 2;
         const unsigned long long k = c->a_recvd[o.peer]++;
         const int slot = (int)(k % ASLOTS);
-        hipLaunchKernelGGL(k_a_recv, dim3(a_grid(o.bytes)), dim3(256), 0, o.st, d, &d->prod[o.peer][c->rank], k + 1,
-                           (const unsigned long long *)&d->msg_bytes[o.peer][c->rank][slot], (char *)o.dst,
-                           (const char *)box + (size_t)slot * PAIRBOX, o.bytes, &d->cons[o.peer][c->rank], a_ticket(c),
+        hipLaunchKernelGGL(k_a_wait, dim3(1), dim3(64), 0, o.st, d, (const Ctr *)&d->prod[o.peer][c->rank], k + 1,
+                           (const unsigned long long *)&d->msg_bytes[o.peer][c->rank][slot], (unsigned long long)o.bytes,
                            c->delay_us);
+        hipLaunchKernelGGL(k_a_copy_publish, dim3(a_grid(o.bytes)), dim3(256), 0, o.st, d, (char *)o.dst,
+                           (const char *)box + (size_t)slot * PAIRBOX, o.bytes, &d->cons[o.peer][c->rank], k + 1,
+                           (unsigned long long *)nullptr, a_ticket(c));
     }
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
@@ -467,6 +454,7 @@ int ncclAllReduce(const void *send, void *recv, size_t count, int dt, int op, vo
     if (bytes > MAILBOX) return 5;
     if (c->async) {
         if (count > (size_t)AR_MAX) return 4;
+        if (a_error(c, "at an all-reduce")) return 5;
         c->ncalls++;
         hipLaunchKernelGGL(k_a_allreduce, dim3(1), dim3(256), 0, st, c->d_ah, c->rank, c->nranks, c->ar_calls++,
                            (const unsigned long long *)send, (unsigned long long *)recv, (int)count, dt == 4 ? 1 : 0);

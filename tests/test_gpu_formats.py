@@ -46,7 +46,7 @@ def test_spmv_variant_option_only_takes_kernels_that_compute_the_product(gpu_ctx
         for v in (0, 9, 12, -1):
             gpu_ctx.set_option(hip.OPT_SPMV_VARIANT, v)
             ys.append(K.spmv(x))
-        for v in (1, 8, 13, 14, -2):
+        for v in (1, 8, 13, 14, 19, 21, -2):
             with pytest.raises(hip.StanHipError) as ei:
                 gpu_ctx.set_option(hip.OPT_SPMV_VARIANT, v)
             assert ei.value.code == hip.E_ARG
@@ -78,6 +78,46 @@ def test_mixed_solve_after_spmv_bench_on_a_fresh_matrix(gpu_ctx, oracle):
     U2, rep2 = K2.cg_solve(job.F, 1e-12, precision_mode=hip.PREC_FIXED48)
     assert np.abs(U2 - Uo).max() <= U_TOL * np.abs(Uo).max()
     K.free(); K2.free()
+
+
+@pytest.mark.parametrize("n,prec", [(14, "fp64"), (33, "fp64"), (24, "fixed48"), (20, "mixed")])
+def test_two_wavefronts_per_slice_kernel(gpu_ctx, oracle, n, prec):
+    """Round 6: k_spmv_pair -- the slots of a slice split between two wavefronts at an even slot, the
+    halves added in a fixed order -- behind STAN_OPT_SPMV_VARIANT 20.  The same products as the one-wave kernel summed in
+    another order (1e-13), the same bits from run to run and with the packed and the int32 column stream, and a CG on
+    it (merit stop off: both runs end on the residual test) meets the oracle like the default kernel
+    (33^3: wide BFS levels, two-base slices and the ragged last slice; 14^3: slices with an odd slot count)."""
+    from stan_amd import hip
+    job = problem.cube_job(n, jitter=0.05)
+    K, A = _assemble_both(gpu_ctx, oracle, job)
+    mode = {"fp64": hip.PREC_FP64, "fixed48": hip.PREC_FIXED48, "mixed": hip.PREC_MIXED}[prec]
+    eps = 1e-6 if prec == "mixed" else 1e-9
+    x = np.random.default_rng(2).standard_normal(job.n_red)
+    gpu_ctx.set_option(hip.OPT_SPMV_SMALL, 0)
+    gpu_ctx.set_option(hip.OPT_CG_MERIT_STOP, 0)
+    try:
+        gpu_ctx.set_option(hip.OPT_SPMV_VARIANT, 9)
+        y9 = K.spmv(x)
+        U9, rep9 = K.cg_solve(job.F, eps, precision_mode=mode)
+        gpu_ctx.set_option(hip.OPT_SPMV_VARIANT, 20)
+        y20 = K.spmv(x)
+        assert np.array_equal(K.spmv(x), y20)
+        gpu_ctx.set_option(hip.OPT_PACKED_COLUMNS, 0)
+        assert np.array_equal(K.spmv(x), y20)
+        gpu_ctx.set_option(hip.OPT_PACKED_COLUMNS, 1)
+        U20, rep20 = K.cg_solve(job.F, eps, precision_mode=mode)
+        U20b, rep20b = K.cg_solve(job.F, eps, precision_mode=mode)
+    finally:
+        gpu_ctx.set_option(hip.OPT_SPMV_VARIANT, -1)
+        gpu_ctx.set_option(hip.OPT_SPMV_SMALL, 1)
+        gpu_ctx.set_option(hip.OPT_PACKED_COLUMNS, 1)
+        gpu_ctx.set_option(hip.OPT_CG_MERIT_STOP, 1)
+    assert np.abs(y20 - y9).max() <= 1e-13 * np.abs(y9).max()
+    assert rep20 == rep20b and np.array_equal(U20, U20b)
+    assert rep20["terminationtype"] == rep9["terminationtype"] == 1 and abs(rep20["iterations"] - rep9["iterations"]) <= 2
+    Uo, _ = oracle.cg(A, job.F, 1e-12)
+    assert np.abs(U20 - Uo).max() <= (1e-3 if prec == "mixed" else 1e-6) * np.abs(Uo).max()
+    K.free()
 
 
 def test_value_stream_yardstick(gpu_ctx):

@@ -173,9 +173,10 @@ def test_a_serialising_stand_in_hides_a_missing_stream_wait_and_the_stream_order
         interior product (~0.5 ms) outlasts the enqueued exchange several times over, the boundary product and r' = r - a v
         overtake it, and the solve no longer reproduces the fixture.
     (The default synchronous stand-in drains only the stream it is given, so the side stream's product overlaps there
-    too -- with the host's timing: it caught this library at 100^3 in round 6's first run; what it catches depends on how
-    long the host-staged copies take.)  The GOOD library passes under every mode
-    (test_sharded_bench_mode_against_the_oracle_fixture, test_the_two_modes_of_the_stand_in_give_the_same_bits)."""
+    too, with the host's timing: tools/lab/explore_broken_library.py ran this library at 100^3 and 148^3 under the three
+    transports, twice each -- device-draining: passes 4 of 4; synchronous and stream-ordered: caught 4 of 4 each,
+    gpurun_out of round 6 -> profiles/r06/broken_library_under_the_three_transports.txt.)  The GOOD library passes under
+    every mode (test_sharded_bench_mode_against_the_oracle_fixture, test_the_two_modes_of_the_stand_in_give_the_same_bits)."""
     hidden = _broken_library_run(tmp_path, "device-draining", 148, dict(fake_rccl_env("sync"), FAKE_RCCL_SYNC_DEVICE="1"))
     caught = not _broken_library_run(tmp_path, "stream-ordered", 148, fake_rccl_env("async"))
     assert hidden, "a transport that drains the device was expected to hide the missing wait"
