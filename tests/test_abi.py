@@ -116,3 +116,21 @@ print("BEFORE", len(before), "AFTER", len(after), " ".join(after))
     w = [l for l in p.stdout.splitlines() if l.startswith("BEFORE")][0].split()
     assert int(w[1]) == (1 if host_has_rccl else 0) and int(w[3]) == 1, p.stdout
     assert ("torch" in w[4]) == host_has_rccl
+
+
+def test_lab_patches_still_apply(tmp_path):
+    """stan_amd/csrc/lab/lab_hooks.patch (the lab build) and drop_overlap_wait.patch (the broken build of
+    tests/test_gpu_sharded.py) are diffs against the PRODUCT sources and must track every product edit: `patch --dry-run` on
+    copies, so that a product change that breaks `make lab` / `make broken` fails here, in the CPU suite, not on the GPU box."""
+    import shutil
+    import subprocess
+    csrc = os.path.join(ROOT, "stan_amd", "csrc")
+    work = tmp_path / "src"
+    work.mkdir()
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".inc", ".h")):
+            shutil.copy(os.path.join(csrc, f), str(work / f))
+    for patch in ("lab_hooks.patch", "drop_overlap_wait.patch"):
+        p = subprocess.run(["patch", "-p1", "--dry-run", "-i", os.path.join(csrc, "lab", patch)], cwd=str(work),
+                           capture_output=True, text=True)
+        assert p.returncode == 0 and "FAILED" not in p.stdout, patch + ":\n" + p.stdout[-1500:]
