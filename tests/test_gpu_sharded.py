@@ -126,17 +126,21 @@ def test_the_two_modes_of_the_stand_in_give_the_same_bits(built_libs, tmp_path, 
     the ranks' partials in rank order, and the product orders its streams itself instead of leaning on the host
     drains of the synchronous mode."""
     res = {}
-    for mode in ("sync", "async"):
+    # "async-late": every message's data lands 300 us after it was announced (FAKE_RCCL_ASYNC_DELAY_US) -- a kernel that
+    # read its halo without waiting for the exchange on its stream would read the previous iteration's
+    for mode in ("sync", "async", "async-late"):
         d = tmp_path / mode
         d.mkdir()
-        out = _torchrun(world, [os.path.join(ROOT, "tests", "sharded_worker.py"), spec, str(d), "1"], fake_rccl_env(mode))
+        env = dict(fake_rccl_env(mode.split("-")[0]), **({"FAKE_RCCL_ASYNC_DELAY_US": "300"} if mode == "async-late" else {}))
+        out = _torchrun(world, [os.path.join(ROOT, "tests", "sharded_worker.py"), spec, str(d), "1"], env)
         assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
-        assert (ASYNC_BANNER in out.stderr) == (mode == "async")
+        assert (ASYNC_BANNER in out.stderr) == (mode != "sync")
         res[mode] = [np.load(str(d / ("rank%d.npz" % r))) for r in range(world)]
-    for a, b in zip(res["sync"], res["async"]):
-        assert int(a["its"]) == int(b["its"]) and int(a["its_x"]) == int(b["its_x"]) and int(a["term"]) == int(b["term"])
-        for k in ("U", "Um", "Ux"):
-            assert np.array_equal(a[k], b[k]), k
+    for other in ("async", "async-late"):
+        for a, b in zip(res["sync"], res[other]):
+            assert int(a["its"]) == int(b["its"]) and int(a["its_x"]) == int(b["its_x"]) and int(a["term"]) == int(b["term"])
+            for k in ("U", "Um", "Ux"):
+                assert np.array_equal(a[k], b[k]), (other, k)
 
 
 def _broken_library_run(tmp_path, tag, n, env_extra):
@@ -174,8 +178,9 @@ def test_a_serialising_stand_in_hides_a_missing_stream_wait_and_the_stream_order
         overtake it, and the solve no longer reproduces the fixture.
     (The default synchronous stand-in drains only the stream it is given, so the side stream's product overlaps there
     too, with the host's timing: tools/lab/explore_broken_library.py ran this library at 100^3 and 148^3 under the three
-    transports, twice each -- device-draining: passes 4 of 4; synchronous and stream-ordered: caught 4 of 4 each,
-    gpurun_out of round 6 -> profiles/r06/broken_library_under_the_three_transports.txt.)  The GOOD library passes under
+    transports, twice each -- device-draining: passes 4 of 4; synchronous: caught 4 of 4; stream-ordered: caught 2 of 2 at
+    148^3 and 0 of 2 at 100^3, where its exchange takes as long as the interior product:
+    profiles/r06/broken_library_under_the_three_transports.txt.)  The GOOD library passes under
     every mode (test_sharded_bench_mode_against_the_oracle_fixture, test_the_two_modes_of_the_stand_in_give_the_same_bits)."""
     hidden = _broken_library_run(tmp_path, "device-draining", 148, dict(fake_rccl_env("sync"), FAKE_RCCL_SYNC_DEVICE="1"))
     caught = not _broken_library_run(tmp_path, "stream-ordered", 148, fake_rccl_env("async"))
