@@ -20,8 +20,11 @@ over RCCL inside the CG).
 
 Prints ONE JSON line (rank 0): metric DOF/s = nDOF * K / t, plus
   roofline     achieved HBM GB/s of the dominant kernel (the BSELL-64 SpMV), from HIP events
-               around every SpMV launch of the timed solves, against 8 TB/s;
-  cpu_baseline the CPU oracle (a port of the reference algorithm) on a bounded sample.
+               around every SpMV launch of the timed solves, against 8 TB/s -- and against what a read-only
+               sweep of K's resident values reaches on THIS box (stream_GBs, frac_of_stream);
+  cpu_baseline the CPU oracle (a port of the reference algorithm) on a bounded sample;
+  secondary    (N = 1, default workload) BASELINE.json's other single-GPU configs, 100^3 ... 400^3, as child processes
+               BEHIND the measured line: a signal or a stall there prints the line as measured (bench_legs.py).
 The merit-function stop of ALGLIB's lincg (termination type 7) is switched OFF here and in
 the CPU baseline: with it the reference algorithm gives up near 1e-7 on cubes of this size
 and would never reach the 1e-8 the metric names.

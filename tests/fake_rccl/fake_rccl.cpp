@@ -12,8 +12,10 @@
 //     timing is the host's.  FAKE_RCCL_SYNC_DEVICE=1 drains the whole device instead -- a fully serialising
 //     transport, behind which a product-side ordering bug hides (tests/test_gpu_sharded.py shows it on a broken build).
 //   * FAKE_RCCL_ASYNC=1: ncclSend / ncclRecv / ncclAllReduce are ENQUEUED on the caller's stream like RCCL's --
-//     polling kernels + copy kernels on mailboxes in host-registered shared memory, arrival counters written by
-//     the stream itself; the host never waits.  What the product forgets to order (a missing
+//     a one-wavefront polling kernel (the wait) + a wide copy kernel per message, the message landing in the
+//     RECEIVER'S DEVICE MEMORY (its inbox: the raw pointer between ranks of one process, a HIP IPC mapping between
+//     processes; host-registered shared memory only if no IPC mapping can be had), arrival counters in host-registered
+//     shared memory written by the stream itself; the host never waits.  What the product forgets to order (a missing
 //     hipStreamWaitEvent between the side stream's interior product and the boundary product, say) really
 //     runs concurrently.  ncclBroadcast (set-up, the final gather of U) stays host-staged in both modes.
 //     Ranks that share one process need a hardware queue per stream (GPU_MAX_HW_QUEUES >= 2 * nranks + 2), as
@@ -64,6 +66,11 @@ struct AHeader {
     Ctr abort;                                // ncclCommAbort: every polling kernel returns
     unsigned long long msg_bytes[MAXR][MAXR][ASLOTS];
     unsigned long long ar_box[ASLOTS][MAXR][AR_MAX];   // doubles or int64 as bits
+    // every rank's INBOX in device memory (messages land where RCCL's land: in the receiver's HBM, at HBM speed): how the
+    // other ranks reach it -- the raw pointer inside one process, a HIP IPC handle between processes
+    hipIpcMemHandle_t ipc[MAXR];
+    unsigned long long raw[MAXR];
+    int pid[MAXR], inbox_ok[MAXR];
 };
 constexpr size_t PAGE = 4096;
 constexpr size_t page_up(size_t b) { return (b + PAGE - 1) / PAGE * PAGE; }
@@ -81,7 +88,10 @@ struct Comm {
     bool async = false;
     AHeader *ah = nullptr, *d_ah = nullptr;            // host view / device view of the registered header
     char *abox = nullptr;                              // nranks x nranks x ASLOTS pair mailboxes
-    char *d_abox[MAXR][MAXR] = {};                     // device views, registered on first use
+    char *d_abox[MAXR][MAXR] = {};                     // device views, registered on first use (the fallback: host mailboxes)
+    char *inbox = nullptr;                             // this rank's inbox: [src rank][ASLOTS][PAIRBOX] of device memory
+    char *dev_inbox[MAXR] = {};                        // every rank's inbox as this rank reaches it; all null = host mailboxes
+    bool inbox_mapped[MAXR] = {};                      // opened through hipIpcOpenMemHandle (to be closed)
     unsigned long long a_sent[MAXR] = {}, a_recvd[MAXR] = {}, ar_calls = 0;
     long delay_us = 0;                                 // FAKE_RCCL_ASYNC_DELAY_US: a message's data lands late
     bool error_reported = false;
@@ -212,8 +222,9 @@ __global__ void k_a_allreduce(AHeader *h, int rank, int n, unsigned long long k,
     if (t == 0) a_store(&h->ar_cons[rank].v, k + 1);
 }
 
-char *a_pair_box(Comm *c, int src, int dst) {   // device view of the pair's ASLOTS mailboxes, registered on first use
-    if (!c->d_abox[src][dst]) {
+char *a_pair_box(Comm *c, int src, int dst) {   // device-visible address of the pair's ASLOTS mailboxes
+    if (c->dev_inbox[dst]) return c->dev_inbox[dst] + (size_t)src * ASLOTS * PAIRBOX;   // in the receiver's device memory
+    if (!c->d_abox[src][dst]) {                 // fallback: host memory, registered on first use
         char *hp = c->abox + ((size_t)src * c->nranks + dst) * ASLOTS * PAIRBOX;
         void *dp = nullptr;
         if (hipHostRegister(hp, ASLOTS * PAIRBOX, hipHostRegisterMapped) != hipSuccess ||
@@ -409,12 +420,42 @@ int ncclCommInitRank(void **comm, int nranks, nccl_uid id, int rank) {
         if (hipMalloc((void **)&c->d_tickets, 4096 * sizeof(unsigned)) != hipSuccess ||
             hipMemset(c->d_tickets, 0, 4096 * sizeof(unsigned)) != hipSuccess) return 2;
         if (const char *e = getenv("FAKE_RCCL_ASYNC_DELAY_US")) c->delay_us = atol(e);
-        if (rank == 0) fprintf(stderr, "fake_rccl: asynchronous mode (stream-ordered send / recv / all-reduce), %d ranks\n", nranks);
+        // this rank's inbox, and how the others reach it
+        c->ah->pid[rank] = (int)getpid();
+        c->ah->raw[rank] = 0;
+        if (!getenv("FAKE_RCCL_ASYNC_HOST_BOXES") && hipMalloc((void **)&c->inbox, (size_t)nranks * ASLOTS * PAIRBOX) == hipSuccess) {
+            if (hipIpcGetMemHandle(&c->ah->ipc[rank], c->inbox) == hipSuccess) c->ah->raw[rank] = (unsigned long long)(uintptr_t)c->inbox;
+            else { (void)hipGetLastError(); hipFree(c->inbox); c->inbox = nullptr; }
+        } else (void)hipGetLastError();
     }
     c->h->init.fetch_add(1);
     c->ncalls = 0;
     if (!wait_until(c, [&] { return c->h->init.load() >= nranks; }, "init", -1)) return 2;
     if (!barrier(c, "init barrier")) return 2;
+    if (c->async) {   // map every rank's inbox; device mailboxes only if EVERY rank reaches every inbox (both ends of a pair must agree)
+        bool ok = c->inbox != nullptr;
+        char *map[MAXR] = {};
+        for (int r = 0; r < nranks && ok; r++) {
+            if (!c->ah->raw[r]) { ok = false; break; }
+            if (r == rank) map[r] = c->inbox;
+            else if (c->ah->pid[r] == (int)getpid()) map[r] = (char *)(uintptr_t)c->ah->raw[r];   // a thread of this process: the pointer itself
+            else {
+                void *q = nullptr;
+                if (hipIpcOpenMemHandle(&q, c->ah->ipc[r], hipIpcMemLazyEnablePeerAccess) == hipSuccess) { map[r] = (char *)q; c->inbox_mapped[r] = true; }
+                else { (void)hipGetLastError(); ok = false; }
+            }
+        }
+        c->ah->inbox_ok[rank] = ok ? 1 : 0;
+        if (!barrier(c, "inbox exchange")) return 2;
+        for (int r = 0; r < nranks; r++) ok = ok && c->ah->inbox_ok[r] == 1;
+        for (int r = 0; r < nranks; r++) {
+            if (ok) c->dev_inbox[r] = map[r];
+            else if (c->inbox_mapped[r]) { hipIpcCloseMemHandle(map[r]); c->inbox_mapped[r] = false; }
+        }
+        if (rank == 0)
+            fprintf(stderr, "fake_rccl: asynchronous mode (stream-ordered send / recv / all-reduce), %d ranks, mailboxes in %s\n", nranks,
+                    ok ? "the receivers' device memory" : "host memory (no IPC mapping of the inboxes)");
+    }
     *comm = c;
     g_comm = c;
     return 0;
@@ -433,9 +474,12 @@ int ncclCommDestroy(void *comm) {
                 if (c->d_abox[a][b]) hipHostUnregister(c->abox + ((size_t)a * c->nranks + b) * ASLOTS * PAIRBOX);
         hipHostUnregister(c->ah);
         hipFree(c->d_tickets);
+        for (int r = 0; r < c->nranks; r++)
+            if (c->inbox_mapped[r]) hipIpcCloseMemHandle(c->dev_inbox[r]);
     }
     if (c->rank == 0) shm_unlink(c->name);
     munmap((void *)c->h, c->bytes);
+    if (c->inbox) hipFree(c->inbox);   // (after the barrier above: no peer still copies into it)
     delete c;
     return 0;
 }
