@@ -65,6 +65,7 @@ def test_sharded_solve_matches_oracle(built_libs, oracle, tmp_path, world, overl
                     fake_rccl_env(fake_mode))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert (ASYNC_BANNER in out.stderr) == (fake_mode == "async")
+    assert fake_mode != "async" or "mailboxes in the receivers' device memory" in out.stderr   # (HIP IPC between the rank processes)
     if spec.startswith("fuzz:"):
         from tests import fuzz
         job = fuzz.random_job(int(spec[5:]))
@@ -128,15 +129,18 @@ def test_the_two_modes_of_the_stand_in_give_the_same_bits(built_libs, tmp_path, 
     res = {}
     # "async-late": every message's data lands 300 us after it was announced (FAKE_RCCL_ASYNC_DELAY_US) -- a kernel that
     # read its halo without waiting for the exchange on its stream would read the previous iteration's
-    for mode in ("sync", "async", "async-late"):
+    # "async-hostboxes": the fallback of a host without IPC mappings (FAKE_RCCL_ASYNC_HOST_BOXES: mailboxes in shared host memory)
+    modes = ("sync", "async", "async-late") + (("async-hostboxes",) if world == 3 else ())
+    for mode in modes:
         d = tmp_path / mode
         d.mkdir()
-        env = dict(fake_rccl_env(mode.split("-")[0]), **({"FAKE_RCCL_ASYNC_DELAY_US": "300"} if mode == "async-late" else {}))
+        env = dict(fake_rccl_env(mode.split("-")[0]), **({"FAKE_RCCL_ASYNC_DELAY_US": "300"} if mode == "async-late" else
+                                                         {"FAKE_RCCL_ASYNC_HOST_BOXES": "1"} if mode == "async-hostboxes" else {}))
         out = _torchrun(world, [os.path.join(ROOT, "tests", "sharded_worker.py"), spec, str(d), "1"], env)
         assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
         assert (ASYNC_BANNER in out.stderr) == (mode != "sync")
         res[mode] = [np.load(str(d / ("rank%d.npz" % r))) for r in range(world)]
-    for other in ("async", "async-late"):
+    for other in modes[1:]:
         for a, b in zip(res["sync"], res[other]):
             assert int(a["its"]) == int(b["its"]) and int(a["its_x"]) == int(b["its_x"]) and int(a["term"]) == int(b["term"])
             for k in ("U", "Um", "Ux"):
