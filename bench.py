@@ -471,6 +471,7 @@ def main():
         BL.hold_line(dog, line)
     if rank == 0:
         print(line, flush=True)
+        BL.release_line(dog)
     # the measurement is out: a teardown that stalls (a peer that is gone) ends quietly with code 0, never a second line
     dog.held_line, dog.optional = None, True
     dog.touch("teardown")

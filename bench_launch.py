@@ -104,6 +104,7 @@ def hold_line(dog, line):
         os.replace(path + ".tmp", path)
     except OSError:
         pass
+    dog._side_file = path
     if getattr(dog, "_signals", False):
         return
     dog._signals = True
@@ -125,6 +126,16 @@ def hold_line(dog, line):
         try:
             signal.signal(sg, on_signal)
         except (ValueError, OSError):   # not the main thread
+            pass
+
+
+def release_line(dog):
+    """The line is on stdout: the default side file (not one the caller named) has served its purpose."""
+    path = getattr(dog, "_side_file", None)
+    if path and not os.environ.get("STAN_BENCH_SIDE_FILE"):
+        try:
+            os.remove(path)
+        except OSError:
             pass
 
 
