@@ -18,6 +18,8 @@
 //     shared memory written by the stream itself; the host never waits.  What the product forgets to order (a missing
 //     hipStreamWaitEvent between the side stream's interior product and the boundary product, say) really
 //     runs concurrently.  ncclBroadcast (set-up, the final gather of U) stays host-staged in both modes.
+//     FAKE_RCCL_ASYNC_HOST_BOXES=1 forces the host-memory mailboxes (the fallback, compared bit for bit in the tests);
+//     FAKE_RCCL_ASYNC_DELAY_US=n makes every message's data land n microseconds after its arrival was announced.
 //     Ranks that share one process need a hardware queue per stream (GPU_MAX_HW_QUEUES >= 2 * nranks + 2), as
 //     the product's own peer-to-peer path does: a polling kernel must never sit in front of its producer.
 //
