@@ -130,6 +130,16 @@ def _bench_leg(extra, timeout, steps=2, warmup=1):
     return _leg_summary(d) if d is not None else {"error": why}
 
 
+def _host_mem_available_gb():
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable"):
+                return int(ln.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
 def _n400_leg(timeout):
     """BASELINE.json configs[4]'s size: the 400^3 cube (193 M DOF, 1.75 G blocks, 126 GB of fp64 values),
     HEX8_G2, `--steps 1 --warmup 0` -- ONE cold step: the placement search and the first allocations are inside it --
@@ -137,6 +147,9 @@ def _n400_leg(timeout):
     AssignDOF, for both).  Returns two entries: DOF/s, SpMV fraction, refinement passes and the FP64 residual of each.
     (The config as NAMED -- fp32 matrix + HEX8_G1 -- is ill-posed at this size, profiles/r02/CONFIG5.md; its halves are
     tests/test_gpu_configs.py.)"""
+    avail_gb = _host_mem_available_gb()
+    if avail_gb < 48:   # (the child's mesh, DOF tables and incidence lists take ~20 GB of host memory: never drive a box out of memory)
+        return [{"leg": "config 5's size: 400^3", "error": "skipped: %.0f GB of host memory available, the 400^3 set-up wants 48" % avail_gb}]
     d, why = _child_json([sys.executable, BENCH, "--gpus", "1", "--size", "400", "--steps", "1", "--warmup", "0", "--no-cpu",
                           "--no-secondary", "--then-fixed48", "--watchdog", str(int(timeout))], timeout)
     if d is None:

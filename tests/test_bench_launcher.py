@@ -66,6 +66,7 @@ def test_secondary_legs_never_cost_the_headline(monkeypatch):
     monkeypatch.setattr(bench, "_child_json", fake_child)
     monkeypatch.setattr(bench, "_console_leg", lambda n, timeout: {"error": "no GPU here"})
     monkeypatch.setattr(bench, "_pmc_leg", lambda timeout: {"error": "no profiler here"})
+    monkeypatch.setattr(bench, "_host_mem_available_gb", lambda: 200.0)
     args = types.SimpleNamespace(secondary_budget=600.0)
     seen = []
     legs = bench.secondary_legs(args, Dog(), seen.append)
@@ -85,6 +86,11 @@ def test_secondary_legs_never_cost_the_headline(monkeypatch):
     calls.clear()
     legs = bench.secondary_legs(types.SimpleNamespace(secondary_budget=200.0), Dog())
     assert not [c for c, _ in calls if "400" in c] and "skipped" in legs[-1]["error"] and len(legs) == 7
+    # a host without the memory for the 400^3 set-up: that leg is skipped, never attempted
+    calls.clear()
+    monkeypatch.setattr(bench, "_host_mem_available_gb", lambda: 31.0)
+    legs = bench.secondary_legs(types.SimpleNamespace(secondary_budget=600.0), Dog())
+    assert not [c for c, _ in calls if "400" in c] and "host memory" in legs[-1]["error"]
     # a spent budget: nothing is started any more
     calls.clear()
     legs = bench.secondary_legs(types.SimpleNamespace(secondary_budget=-1.0), Dog())
