@@ -141,6 +141,28 @@ def test_value_stream_yardstick(gpu_ctx):
     K.free()
 
 
+def test_round6_helpers_on_degenerate_inputs(gpu_ctx):
+    """stan_hip_stream_bench on a matrix without a single block (nodes, no elements) reads nothing and says so; a context
+    that never joined a communicator names no RCCL file; bad arguments are STAN_E_ARG, not a crash."""
+    import ctypes as C
+    from stan_amd import hip
+    job = problem.cube_job(2)
+    K = gpu_ctx.assemble_hex8(job.xyz, job.node_dof, np.zeros((0, 8), np.int32), np.zeros(0, np.int32), np.zeros(0, np.uint8),
+                              job.mat_E_nu, job.red)
+    ms, nbytes = K.stream_bench(3)
+    assert nbytes == K.info()["n_slots"] * 64 * 72 and ms >= 0
+    with pytest.raises(hip.StanHipError) as ei:
+        K.stream_bench(0)
+    assert ei.value.code == hip.E_ARG
+    K.free()
+    info = gpu_ctx.comm_info()
+    assert info["library"] == "" and info["library_reused"] is False and info["comm_ranks"] == 0
+    # a buffer too small for the path: truncated and NUL-terminated, never overrun
+    buf = C.create_string_buffer(b"x" * 8, 8)
+    assert gpu_ctx.lib.stan_hip_comm_library(gpu_ctx.h, buf, C.c_int64(4), None) == 0 and buf.raw[4:] == b"xxxx"
+    assert gpu_ctx.lib.stan_hip_comm_library(gpu_ctx.h, None, C.c_int64(4), None) == hip.E_ARG
+
+
 @pytest.mark.parametrize("n,prec,jit", [(20, "fp64", 0.05), (33, "fp64", 0.0), (24, "fixed48", 0.1), (24, "mixed", 0.05)])
 def test_packed_column_stream_gives_the_same_bits(gpu_ctx, n, prec, jit):
     """STAN_OPT_PACKED_COLUMNS: 16-bit column offsets from a per-slot base, two slots per dword --
