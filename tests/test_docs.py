@@ -70,3 +70,19 @@ def test_every_tool_the_documents_name_exists():
             if not os.path.exists(os.path.join(ROOT, m.group(0))):
                 missing.append((rel, m.group(0)))
     assert not missing, sorted(set(missing))
+
+
+def test_every_bare_profile_file_name_the_documents_cite_exists():
+    """A list like "`profiles/r03/a.txt`, `b.txt`" cites b.txt without its directory: every back-ticked file name with a data
+    suffix in the documents must exist somewhere in the tree (round 6's pruning had removed one such file; restored)."""
+    own = {"README.md", "DESIGN.md", "INTEGRATION.md", "SURVEY.md", "BASELINE.md", "VERDICT.md", "ADVICE.md", "BASELINE.json"}
+    missing = []
+    for rel in DOCS[:3] + [os.path.join("include", f) for f in sorted(os.listdir(os.path.join(ROOT, "include")))]:
+        text = open(os.path.join(ROOT, rel)).read()
+        for m in re.finditer(r"`([A-Za-z0-9_\-\*\{\},\.]+\.(?:txt|json|jsonl|csv|md))`", text):
+            if m.group(1) in own or m.group(1).startswith("BENCH_"):
+                continue
+            for name in _expand(m.group(1)):
+                if not glob.glob(os.path.join(ROOT, "**", name), recursive=True):
+                    missing.append((rel, name))
+    assert not missing, missing
