@@ -65,7 +65,9 @@ def test_sharded_solve_matches_oracle(built_libs, oracle, tmp_path, world, overl
                     fake_rccl_env(fake_mode))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert (ASYNC_BANNER in out.stderr) == (fake_mode == "async")
-    assert fake_mode != "async" or "mailboxes in the receivers' device memory" in out.stderr   # (HIP IPC between the rank processes)
+    # (the stand-in says where its mailboxes are: the receivers' device memory through HIP IPC -- what it does on this pool --
+    # or, where no IPC mapping can be had, host memory; both forms give the same bits: test_the_two_modes_...)
+    assert fake_mode != "async" or "mailboxes in " in out.stderr
     if spec.startswith("fuzz:"):
         from tests import fuzz
         job = fuzz.random_job(int(spec[5:]))
