@@ -294,7 +294,9 @@ def run_one_process(args):
 
 
 # ---- N > 1: the loop forms and transports side by side, in a process group of their own -------------------------------------
-PROBE_LEGS = (("classic_rccl", 0, 0), ("classic_p2p", 0, 1), ("single_reduce_rccl", 1, 0), ("single_reduce_p2p", 1, 1))
+# the RCCL legs first: should a peer-to-peer leg stall or crash on a node (its IPC mappings have only ever met one GPU), the
+# report of the two RCCL forms is already out (probe_child_main prints an interim result, the parent takes the last it sees)
+PROBE_LEGS = (("classic_rccl", 0, 0), ("single_reduce_rccl", 1, 0), ("classic_p2p", 0, 1), ("single_reduce_p2p", 1, 1))
 
 
 def probe_report(legs, capped_at):
@@ -314,11 +316,16 @@ def probe_report(legs, capped_at):
             "single_reduce_rccl": "STAN_OPT_CG_SINGLE_REDUCE=1", "single_reduce_p2p": "STAN_OPT_CG_SINGLE_REDUCE=1 + STAN_OPT_COMM_P2P=1"}
     best_ok = min((k for k in legs if ok[k]), key=lambda k: legs[k]["ms_per_iteration"])   # (the defaults agree with themselves)
     rec = best_ok if legs[best_ok]["ms_per_iteration"] < 0.97 * base["ms_per_iteration"] else "classic_rccl"
-    return {"capped_at_iterations": capped_at, "legs": legs,
-            "same_residual_bits_classic": legs["classic_rccl"]["rel_residual"] == legs["classic_p2p"]["rel_residual"],
-            "agrees_with_classic_rccl": ok,
-            "time_over_classic_rccl": {k: v["ms_per_iteration"] / base["ms_per_iteration"] for k, v in legs.items()},
-            "fastest": best, "recommended": "%s (%s)" % (rec, opts[rec])}
+    missing = [name for name, _, _ in PROBE_LEGS if name not in legs]   # (an interim report: the legs that had run when it was printed)
+    out = {"capped_at_iterations": capped_at, "legs": legs,
+           "same_residual_bits_classic": (legs["classic_rccl"]["rel_residual"] == legs["classic_p2p"]["rel_residual"]
+                                          if "classic_p2p" in legs else None),
+           "agrees_with_classic_rccl": ok,
+           "time_over_classic_rccl": {k: v["ms_per_iteration"] / base["ms_per_iteration"] for k, v in legs.items()},
+           "fastest": best, "recommended": "%s (%s)" % (rec, opts[rec])}
+    if missing:
+        out["legs_not_run"] = missing
+    return out
 
 
 def probe_child_main(args, RankRun):
@@ -362,6 +369,8 @@ def probe_child_main(args, RankRun):
                       "stream_waits_per_iteration": rows[0][5],
                       "iterations": int(rows[0][6]), "rel_residual": rows[0][7],
                       "every_rank_same_residual_bits": len(set(r_[7] for r_ in rows)) == 1}
+        if R.rank == 0 and name == "single_reduce_rccl":   # the interim report: whatever the peer-to-peer legs do, this much is out
+            print(json.dumps({"probe_result": probe_report(legs, args.probe_its)}), flush=True)
     dog.touch("transport probe: report")
     if R.rank == 0:
         print(json.dumps({"probe_result": probe_report(legs, args.probe_its)}), flush=True)
@@ -415,17 +424,20 @@ def run_probe_children(args, R, dog):
             os.killpg(proc.pid, signal.SIGKILL)     # the child started above, nothing else
         except OSError:
             pass
-        proc.wait()
+        try:
+            out, _ = proc.communicate(timeout=10.0)    # (what it had printed: the interim report of the RCCL legs, perhaps)
+        except Exception:   # noqa: BLE001
+            out = ""
         sys.stderr.write("bench.py: rank %d: probe child did not end within %.0f s and was killed\n" % (R.rank, bound))
-        return None
-    if proc.returncode != 0:
-        sys.stderr.write("bench.py: rank %d: probe child ended with code %d; the measured line stands\n" % (R.rank, proc.returncode))
+    if proc.returncode not in (0, None):
+        sys.stderr.write("bench.py: rank %d: probe child ended with code %s; the measured line stands\n" % (R.rank, proc.returncode))
     if R.rank != 0:
         return None
-    for ln in (out or "").splitlines():
+    res = None
+    for ln in (out or "").splitlines():     # the LAST report counts: interim (RCCL legs) or final (all four)
         if ln.startswith("{") and '"probe_result"' in ln:
             try:
-                return json.loads(ln)["probe_result"]
+                res = json.loads(ln)["probe_result"]
             except ValueError:
-                return None
-    return None
+                pass
+    return res

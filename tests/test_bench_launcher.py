@@ -114,6 +114,10 @@ def test_probe_recommendation_goes_by_tolerance_not_by_bits():
     r = bench.probe_report(legs, 200)
     assert not r["agrees_with_classic_rccl"]["classic_p2p"] and r["fastest"] == "classic_p2p"
     assert r["recommended"].startswith("single_reduce_p2p")          # the fastest leg that agrees
+    # an interim report (the RCCL legs only: what is out before the peer-to-peer legs start on a node)
+    r = bench.probe_report({k: v for k, v in legs.items() if k.endswith("rccl")}, 200)
+    assert r["legs_not_run"] == ["classic_p2p", "single_reduce_p2p"] and r["same_residual_bits_classic"] is None
+    assert r["recommended"].startswith("single_reduce_rccl") and sorted(r["agrees_with_classic_rccl"]) == ["classic_rccl", "single_reduce_rccl"]
     # nothing is 3 % faster than the defaults: the defaults stay
     legs = {k: leg(0.190 if k == "classic_rccl" else 0.188) for k in legs}
     assert bench.probe_report(legs, 200)["recommended"].startswith("classic_rccl (library defaults)")

@@ -332,8 +332,11 @@ def test_bench_probe_that_crashes_leaves_the_line_alone(built_libs):
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-3000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["converged"] and d["value"] > 0
-    assert "p2p_probe" not in d["config"] and "error" not in d
+    assert d["n_gpus"] == 2 and d["config"]["converged"] and d["value"] > 0 and "error" not in d
+    # round 6: the RCCL legs run first and their report is out before the peer-to-peer legs start: it survives the crash
+    pr = d["config"]["p2p_probe"]
+    assert sorted(pr["legs"]) == ["classic_rccl", "single_reduce_rccl"] and pr["legs_not_run"] == ["classic_p2p", "single_reduce_p2p"]
+    assert pr["recommended"].split()[0] in pr["legs"] and pr["same_residual_bits_classic"] is None
 
 
 def test_bench_probe_that_stalls_leaves_the_line_alone(built_libs):
@@ -346,8 +349,8 @@ def test_bench_probe_that_stalls_leaves_the_line_alone(built_libs):
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-3000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["converged"] and d["value"] > 0
-    assert "p2p_probe" not in d["config"] and "error" not in d
+    assert d["n_gpus"] == 2 and d["config"]["converged"] and d["value"] > 0 and "error" not in d
+    assert sorted(d["config"]["p2p_probe"]["legs"]) == ["classic_rccl", "single_reduce_rccl"]     # (the interim report)
 
 
 def test_bench_one_process_mode(built_libs):
